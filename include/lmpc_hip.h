@@ -1,0 +1,189 @@
+/*
+ * lmpc_hip.h -- C ABI of the MI355X-native batched LMPC solve path.
+ *
+ * Drop-in boundary for the per-step optimisation of MPC-Berkeley/Racing-LMPC-ROS2:
+ *   lmpc::mpc::racing_mpc::RacingMPC::solve        src/mpc/racing_mpc/src/racing_mpc.cpp:209-372
+ *   (problem definition                            src/mpc/racing_mpc/src/racing_mpc.cpp:31-202,442-543)
+ *   SingleTrackPlanarModel::compile_dynamics       src/vehicle_dynamics_models/single_track_planar_model/src/single_track_planar_model.cpp:195-418
+ *   SafeSetManager::query(SSQuery)                 src/vehicle_dynamics_models/racing_trajectory/src/safe_set.cpp:153-180
+ *
+ * Conventions
+ *   - Plain C: pointers and sizes only.  No exception crosses this boundary: every
+ *     entry point returns LMPC_OK (0) or a negative lmpc_status code; the message is
+ *     kept on the handle (lmpc_last_error).
+ *   - All `*_batch` array arguments are DEVICE pointers (HBM) unless a parameter is
+ *     documented as host.  The caller owns every buffer; the library owns only the
+ *     handle (constants, the safe-set copy, a stream).  No allocation happens inside
+ *     the `*_batch` calls.
+ *   - Batched layout is struct-of-arrays with the batch axis fastest:
+ *         field[component][knot][batch]   ->   ((c * n_knots) + i) * batch + b
+ *     so a wavefront's loads along the batch axis coalesce.
+ *   - State  x = [s, e_y, e_psi, vx, vy, omega]  (base_vehicle_model.hpp:32-40),
+ *     input  u = [u_lon, steer]                  (single_track_planar_model.hpp:62-66);
+ *     N counts knot points: X is 6 x N, U and dU are 2 x (N-1) (racing_mpc.cpp:43-45).
+ *   - A handle is not re-entrant (the reference holds traj_mutex_ across solve,
+ *     racing_mpc_node.cpp:158,360); distinct handles (one per GPU) are independent.
+ */
+#ifndef LMPC_HIP_H_
+#define LMPC_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LMPC_NX 6
+#define LMPC_NU 2
+
+/* return codes of the entry points */
+typedef enum lmpc_status {
+  LMPC_OK = 0,
+  LMPC_ERR_ARGUMENT = -1,      /* null pointer, bad size, unsupported option          */
+  LMPC_ERR_RUNTIME = -2,       /* HIP runtime error (message in lmpc_last_error)      */
+  LMPC_ERR_UNSUPPORTED = -3    /* valid reference configuration not built yet         */
+} lmpc_status;
+
+/* per-problem status written by lmpc_solve_batch (replaces "X_optm absent from out",
+ * racing_mpc.cpp:343-371 / racing_mpc_node.cpp:322-332) */
+#define LMPC_SOLVE_OPTIMAL 0
+#define LMPC_SOLVE_MAX_ITER 1
+#define LMPC_SOLVE_INFEASIBLE 2 /* x_ic outside [x_min, x_max] at knot 0, or NaN          */
+
+/* vehicle_model_factory.cpp:31-49 -- same selector names; only the first is built */
+#define LMPC_MODEL_SINGLE_TRACK_PLANAR 0
+#define LMPC_MODEL_KINEMATIC_BICYCLE 1
+#define LMPC_MODEL_DOUBLE_TRACK_PLANAR 2
+
+/* The ~25 scalars compile_dynamics/add_nlp_constraints read
+ * (base_vehicle_model_config.hpp:30-154, single_track_planar_model.hpp:31-43). */
+typedef struct lmpc_vehicle {
+  int32_t model_id;      /* LMPC_MODEL_SINGLE_TRACK_PLANAR                                */
+  int32_t reserved;
+  double m;              /* chassis.total_mass                                            */
+  double Jzz;            /* chassis.moi                                                   */
+  double l;              /* chassis.wheel_base                                            */
+  double cg_ratio;       /* chassis.cg_ratio  (lr = cg_ratio * l)                         */
+  double h;              /* chassis.cg_height                                             */
+  double b;              /* chassis.b  (body width, boundary margin adds b/2)             */
+  double fr;             /* chassis.fr (rolling resistance)                               */
+  double kd;             /* powertrain.kd  (front drive share)                            */
+  double kb;             /* front_brake.bias                                              */
+  double cd;             /* aero.drag_coeff                                               */
+  double Af;             /* aero.frontal_area                                             */
+  double rho;            /* aero.air_density                                              */
+  double cl_f;           /* aero.cl_f                                                     */
+  double cl_r;           /* aero.cl_r                                                     */
+  double mu;             /* single_track_planar.mu                                        */
+  double Bf, Cf;         /* front_tyre.pacejka_b / pacejka_c                              */
+  double Br, Cr;         /* rear_tyre.pacejka_b / pacejka_c                               */
+  double Fd_max, Fb_max; /* single_track_planar.fd_max / fb_max                           */
+  double Td, Tb;         /* single_track_planar.td / tb                                   */
+  double max_steer;      /* steer.max_steer                                               */
+  double max_steer_rate; /* steer.max_steer_rate                                          */
+} lmpc_vehicle;
+
+/* RacingMPCConfig (racing_mpc_config.hpp:37-82), numeric fields only. */
+typedef struct lmpc_config {
+  int32_t N;                  /* knot points                                                */
+  int32_t learning;           /* 0 tracking MPC, 1 LMPC (safe-set terminal set + cost)      */
+  int32_t num_ss_pts;         /* S                                                          */
+  int32_t num_ss_pts_per_lap; /* K                                                          */
+  int32_t max_lap_stored;
+  int32_t max_iter;           /* interior-point iteration cap (<=0: default 40)             */
+  double tol;                 /* KKT residual tolerance (<=0: default 1e-9)                 */
+  double margin;
+  double q_contour, q_heading, q_vel, q_vy, q_vyaw, q_boundary;
+  double R[4];                /* row-major 2x2                                              */
+  double R_d[4];
+  double x_max[LMPC_NX], x_min[LMPC_NX]; /* +-INFINITY allowed                              */
+  double u_max[LMPC_NU], u_min[LMPC_NU];
+  double convex_hull_slack[LMPC_NX];
+  double max_vel_ref_diff;
+} lmpc_config;
+
+/* Closed track as uniform periodic tables over [0, L): sample j sits at s = j*L/M.
+ * Lookup is periodic linear interpolation.  (The reference interpolates cubic
+ * B-splines of a 17-column table, racing_trajectory.cpp:25-120 -- out of scope;
+ * the tables are what RacingMPCNode samples at racing_mpc_node.cpp:261-266.) */
+typedef struct lmpc_track {
+  double L;
+  int32_t M;
+  int32_t reserved;
+  const double* curvature;   /* device, M                                                  */
+  const double* bound_left;  /* device, M  (signed lateral offset, > 0)                    */
+  const double* bound_right; /* device, M  (signed lateral offset, < 0)                    */
+  const double* vel;         /* device, M                                                  */
+} lmpc_track;
+
+typedef struct lmpc_handle lmpc_handle;
+
+/* Builds the parametric problem once, as RacingMPC::RacingMPC does
+ * (racing_mpc.cpp:31-202).  `device` is the HIP device ordinal. */
+int lmpc_create(const lmpc_config* cfg, const lmpc_vehicle* veh, int device, lmpc_handle** out);
+void lmpc_destroy(lmpc_handle* h);
+const char* lmpc_last_error(const lmpc_handle* h);
+
+/* Run subsequent launches on `hip_stream` (a hipStream_t; NULL restores the handle's own). */
+int lmpc_set_stream(lmpc_handle* h, void* hip_stream);
+/* Block until everything queued on the handle's stream has finished. */
+int lmpc_synchronize(lmpc_handle* h);
+
+/* discrete_dynamics_jacobian for every stage of every problem
+ * (single_track_planar_model.cpp:377-387, called at racing_mpc.cpp:173-182):
+ *   X_ref [6][N][B], U_ref [2][N-1][B], T_ref [N-1][B], curvatures [N][B]  ->
+ *   A [6][6][N-1][B] (row, col), Bm [6][2][N-1][B], g [6][N-1][B].                          */
+int lmpc_linearize_batch(lmpc_handle* h, int32_t batch, const double* X_ref, const double* U_ref,
+                         const double* T_ref, const double* curvatures, double* A, double* Bm,
+                         double* g);
+
+/* RacingMPC::solve for `batch` independent problems (racing_mpc.cpp:209-372).
+ *   in : x_ic [6][B], u_ic [2][B], X_ref [6][N][B], U_ref [2][N-1][B], T_ref [N-1][B],
+ *        bound_left/bound_right/curvatures/vel_ref [N][B], total_length (scalar, host value)
+ *        ss_x [6][S][B], ss_j [S][B]  (learning only, already padded/truncated to S and
+ *        with J - J[0] applied: racing_mpc.cpp:263-280; NULL for tracking)
+ *   out: X_optm [6][N][B], U_optm [2][N-1][B], dU_optm [2][N-1][B],
+ *        convex_combi_optm [S][B] (learning; may be NULL),
+ *        status [B] (LMPC_SOLVE_*), iters [B] (the reference's stats["iter_count"]),
+ *        kkt [4][B] optional: stationarity, inequality residual, complementarity mu, sigma.  */
+int lmpc_solve_batch(lmpc_handle* h, int32_t batch, const double* x_ic, const double* u_ic,
+                     const double* X_ref, const double* U_ref, const double* T_ref,
+                     const double* bound_left, const double* bound_right, const double* curvatures,
+                     const double* vel_ref, double total_length, const double* ss_x,
+                     const double* ss_j, double* X_optm, double* U_optm, double* dU_optm,
+                     double* convex_combi_optm, int32_t* status, int32_t* iters, double* kkt);
+
+/* Safe set store: SafeSetManager::add_lap / SSTrajectory::process_lap_data
+ * (safe_set.cpp:116-151).  HOST pointers: laps oldest first, lap j has n_pts[j] samples,
+ * x is the concatenation of the laps' [n_pts[j]][6] row-major state tables.  The library
+ * builds the +-L unrolled copies and the cost-to-go J on the device. */
+int lmpc_set_safe_set(lmpc_handle* h, int32_t n_laps, const int32_t* n_pts, const double* x,
+                      double total_length);
+
+/* SafeSetManager::query(SSQuery) + the pad/truncate and J - J[0] of RacingMPC::solve
+ * (safe_set.cpp:153-180, trajectory_kd_tree.cpp:53-63, racing_mpc.cpp:249-280):
+ *   query [2][B] = (s, e_y) of X_ref[:, N-1] after abscissa alignment  ->
+ *   ss_x [6][S][B], ss_j [S][B] (J - J[0]), n_found [B] (points before padding).           */
+int lmpc_ss_query_batch(lmpc_handle* h, int32_t batch, const double* query, double* ss_x,
+                        double* ss_j, int32_t* n_found);
+
+/* Cold-start input preparation of RacingMPCNode::on_step_timer
+ * (racing_mpc_node.cpp:210-235,261-292): U_ref = 1e-9, X_ref rolled out with the RK4
+ * model and the track curvature at each knot, references sampled from the track tables,
+ * vel_ref clamped to vx +- max_vel_ref_diff and the speed limit.
+ *   in : x_ic [6][B], dt, speed_scale, speed_limit
+ *   out: X_ref [6][N][B], U_ref [2][N-1][B], T_ref [N-1][B], bound_left, bound_right,
+ *        curvatures, vel_ref [N][B]                                                         */
+int lmpc_prepare_batch(lmpc_handle* h, int32_t batch, const lmpc_track* track, const double* x_ic,
+                       double dt, double speed_scale, double speed_limit, double* X_ref,
+                       double* U_ref, double* T_ref, double* bound_left, double* bound_right,
+                       double* curvatures, double* vel_ref);
+
+/* Library/kernel facts for harnesses: bytes of LDS one problem occupies, waves per CU. */
+int lmpc_query_launch(const lmpc_handle* h, int32_t* lds_bytes_per_problem,
+                      int32_t* threads_per_problem);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LMPC_HIP_H_ */

@@ -1,0 +1,56 @@
+"""Synthetic workloads for the batched LMPC solve path (product side, numpy only).
+
+The BASELINE.json configs are quoted on synthetic data of the reference's scale
+(SURVEY.md section 8d): a closed track given as uniform periodic tables
+(`lmpc_track` in include/lmpc_hip.h) plus random initial states.  Nothing here
+computes on the hot path; it only produces the inputs that are uploaded to HBM.
+
+Track statistics follow the reference's data files
+(racing_trajectory/test_data/barc/15_barc_optm.txt: L = 15.63 m, curvature
+-0.36 .. 0.96 1/m, speed 2.7 .. 5.2 m/s; putnam/10_putnam_optm.txt: L = 2849 m,
+curvature -0.027 .. 0.048 1/m, speed 15 .. 70 m/s) -- the files themselves are
+not read or copied.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def synthetic_track(kind: str = "barc", M: int = 1024) -> dict:
+    """Closed track: curvature integrates to 2*pi over one lap."""
+    s = np.arange(M, dtype=np.float64)
+    th = 2.0 * np.pi * s / M
+    if kind == "barc":
+        L = 15.6
+        k = (2.0 * np.pi / L) * (1.0 + 0.9 * np.cos(2 * th + 0.3) + 0.45 * np.cos(3 * th - 1.1))
+        half_l = 0.55 + 0.25 * np.sin(th + 0.5)
+        half_r = 0.55 + 0.25 * np.cos(2 * th - 0.2)
+        vel = 3.9 - 1.2 * np.cos(2 * th + 0.3)
+    elif kind == "putnam":
+        L = 2849.0
+        k = (2.0 * np.pi / L) * (1.0 + 8.0 * np.cos(3 * th + 0.4) ** 3 + 5.0 * np.cos(5 * th - 0.7))
+        half_l = 4.5 + 2.5 * np.sin(th + 0.5)
+        half_r = 4.5 + 2.5 * np.cos(2 * th - 0.2)
+        vel = 42.0 - 26.0 * np.abs(np.cos(3 * th + 0.4)) ** 1.5
+    else:
+        raise ValueError(kind)
+    return {"L": L, "M": M, "curvature": k, "bound_left": half_l, "bound_right": -half_r, "vel": vel}
+
+
+def sample_initial_states(kind: str, batch: int, L: float, u_lo, u_hi, seed: int = 0):
+    """Random x_ic (B, 6), u_ic (B, 2) -- SURVEY.md 8d configs 2 (barc) and 4 (putnam)."""
+    rng = np.random.default_rng(seed)
+    if kind == "barc":
+        x = np.stack([rng.uniform(0.0, L, batch), rng.uniform(-0.3, 0.3, batch),
+                      rng.normal(0.0, 0.1, batch), rng.uniform(0.5, 3.0, batch),
+                      rng.normal(0.0, 0.05, batch), rng.normal(0.0, 0.2, batch)], axis=-1)
+        u = np.stack([rng.normal(0.0, 0.002, batch), rng.normal(0.0, 0.1, batch)], axis=-1)
+    elif kind == "putnam":
+        x = np.stack([rng.uniform(0.0, L, batch), rng.uniform(-1.5, 1.5, batch),
+                      rng.normal(0.0, 0.05, batch), rng.uniform(15.0, 70.0, batch),
+                      rng.normal(0.0, 0.5, batch), rng.normal(0.0, 0.1, batch)], axis=-1)
+        u = np.stack([rng.normal(0.0, 1.0, batch), rng.normal(0.0, 0.02, batch)], axis=-1)
+    else:
+        raise ValueError(kind)
+    u = np.clip(u, np.asarray(u_lo), np.asarray(u_hi))
+    return x, u
