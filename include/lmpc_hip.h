@@ -145,7 +145,8 @@ int lmpc_linearize_batch(lmpc_handle* h, int32_t batch, const double* X_ref, con
  *   out: X_optm [6][N][B], U_optm [2][N-1][B], dU_optm [2][N-1][B],
  *        convex_combi_optm [S][B] (learning; may be NULL),
  *        status [B] (LMPC_SOLVE_*), iters [B] (the reference's stats["iter_count"]),
- *        kkt [4][B] optional: stationarity, inequality residual, complementarity mu, sigma.  */
+ *        kkt [4][B] optional: inf-norm of the last primal step, largest row residual,
+ *        complementarity mu, boundary slack sigma.                                           */
 int lmpc_solve_batch(lmpc_handle* h, int32_t batch, const double* x_ic, const double* u_ic,
                      const double* X_ref, const double* U_ref, const double* T_ref,
                      const double* bound_left, const double* bound_right, const double* curvatures,
@@ -179,9 +180,19 @@ int lmpc_prepare_batch(lmpc_handle* h, int32_t batch, const lmpc_track* track, c
                        double* U_ref, double* T_ref, double* bound_left, double* bound_right,
                        double* curvatures, double* vel_ref);
 
-/* Library/kernel facts for harnesses: bytes of LDS one problem occupies, waves per CU. */
+/* Grow the handle's device workspace (stage linearisations, 432 B per stage per problem) so
+ * that no later *_batch call with batch <= max_batch allocates. */
+int lmpc_reserve(lmpc_handle* h, int32_t max_batch);
+
+/* Library/kernel facts for harnesses: bytes of LDS one problem occupies, threads per problem. */
 int lmpc_query_launch(const lmpc_handle* h, int32_t* lds_bytes_per_problem,
                       int32_t* threads_per_problem);
+
+/* Per-kernel timing for benchmarks: when enabled, lmpc_solve_batch brackets its two launches
+ * with HIP events on the handle's stream; lmpc_last_kernel_ms waits for them and returns the
+ * durations of the linearisation kernel and of the QP kernel of the most recent call. */
+int lmpc_enable_timing(lmpc_handle* h, int32_t on);
+int lmpc_last_kernel_ms(lmpc_handle* h, float* linearize_ms, float* solve_ms);
 
 #ifdef __cplusplus
 }

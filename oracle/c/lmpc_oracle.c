@@ -238,15 +238,9 @@ static inline double Qz_entry(const prob_t* p, int i, int r, int c) {
  * Backward sweep on z = [x; u_prev] (8), v = dU (2):
  *   Y = Abar' P Abar,  H = Sv + Thv + t^2 Y_uu,  G = t Y[6:8,:],  K = H^-1 G,
  *   P <- Qz + Thz + Y - G' K.        (stage 0 only needs H^-1: dz_0 = 0)                      */
-static void riccati_factor(prob_t* p, const double* PT, const double* pT, double (*kinit)[2]) {
-  /* kinit != NULL: also run the affine value-function recursion of the ABSOLUTE problem
-   * (linear cost qx, terminal gradient pT, dynamics offset g) and return the feed-forward
-   * terms, so that the start point can be rolled out in closed loop: v = -K z - kinit.       */
+static void riccati_factor(prob_t* p, const double* PT) {
   const int N = p->N;
-  double P[64], W[64], Y[64], pv[8] = {0};
-  if (kinit) {
-    for (int r = 0; r < 6; ++r) pv[r] = p->qx[N - 1][r] + (pT ? pT[r] : 0.0);
-  }
+  double P[64], W[64], Y[64];
   for (int r = 0; r < 8; ++r)
     for (int c = 0; c < 8; ++c) {
       double e = Qz_entry(p, N - 1, r, c) + (r == c ? p->Thz[N - 1][r] : 0.0);
@@ -258,7 +252,7 @@ static void riccati_factor(prob_t* p, const double* PT, const double* pT, double
     for (int r = 0; r < 8; ++r)
       for (int c = 0; c < 8; ++c) {
         double acc = (r >= 6) ? P[r * 8 + c] : 0.0;
-        for (int k = 0; k < 6; ++k) acc += abar(p, i, k, r) * P[k * 8 + c];
+        for (int k = 0; k < 6; ++k) acc += abar(p, i, k, r) * P[c * 8 + k]; /* P[k][c] read as P[c][k] (kernel's row read) */
         W[r * 8 + c] = acc;
       }
     for (int r = 0; r < 8; ++r)
@@ -267,19 +261,6 @@ static void riccati_factor(prob_t* p, const double* PT, const double* pT, double
         for (int k = 0; k < 6; ++k) acc += W[r * 8 + k] * abar(p, i, k, c);
         Y[r * 8 + c] = acc;
       }
-    double sv[8], wv[8];
-    if (kinit) { /* s = p + P gbar,  w = Abar' s */
-      for (int r = 0; r < 8; ++r) {
-        double acc = pv[r];
-        for (int k = 0; k < 6; ++k) acc += P[r * 8 + k] * p->g[i][k];
-        sv[r] = acc;
-      }
-      for (int r = 0; r < 8; ++r) {
-        double acc = (r >= 6) ? sv[r] : 0.0;
-        for (int k = 0; k < 6; ++k) acc += abar(p, i, k, r) * sv[k];
-        wv[r] = acc;
-      }
-    }
     const double h00 = p->Sv[0] + p->Thv[i][0] + t * t * Y[6 * 8 + 6];
     const double h01 = p->Sv[1] + t * t * Y[6 * 8 + 7];
     const double h11 = p->Sv[3] + p->Thv[i][1] + t * t * Y[7 * 8 + 7];
@@ -293,13 +274,6 @@ static void riccati_factor(prob_t* p, const double* PT, const double* pT, double
       const double g0 = t * Y[6 * 8 + c], g1 = t * Y[7 * 8 + c];
       p->K[i][0 * 8 + c] = Hi[0] * g0 + Hi[1] * g1;
       p->K[i][1 * 8 + c] = Hi[2] * g0 + Hi[3] * g1;
-    }
-    if (kinit) {
-      const double h0 = t * wv[6], h1 = t * wv[7];
-      kinit[i][0] = Hi[0] * h0 + Hi[1] * h1;
-      kinit[i][1] = Hi[2] * h0 + Hi[3] * h1;
-      for (int r = 0; r < 8; ++r)
-        pv[r] = (r < 6 ? p->qx[i][r] : 0.0) + wv[r] - (p->K[i][r] * h0 + p->K[i][8 + r] * h1);
     }
     if (i >= 1)
       for (int r = 0; r < 8; ++r)
@@ -613,7 +587,7 @@ static void newton_factor(prob_t* p, work_t* w) {
   if (p->has_sigma) p->hsig += w->ths;
   double PT[36];
   if (S) term_factor(p, &w->tm, w->thl, PT);
-  riccati_factor(p, S ? PT : NULL, NULL, NULL);
+  riccati_factor(p, S ? PT : NULL);
   w->ce = 0.0;
   if (p->has_sigma) {
     for (int i = 0; i < N; ++i) {
@@ -708,42 +682,40 @@ static int ipm_solve(prob_t* p, int* iters_out, double* kkt_out) {
   const double tau = 0.995, mu0 = 1.0, thr_frac = 0.1;
   work_t* w = calloc(1, sizeof(work_t));
   /* ---- initial point: the minimiser of the cost over the dynamics alone (no inequality
-   * rows, sigma = 0), rolled out in closed loop.  The linearised model can be open-loop
-   * unstable (|eig A| > 1 at low speed), so an open-loop rollout over N knots may overflow. */
-  {
-    for (int i = 0; i < N; ++i) {
-      for (int r = 0; r < 8; ++r) p->Thz[i][r] = 0.0;
-      p->Thv[i][0] = p->Thv[i][1] = 0.0;
-    }
-    double PT0[36] = {0}, pT0[6] = {0};
-    for (int j = 0; j < S; ++j) p->lmb[j] = 1.0 / S;
-    if (S)
-      for (int k = 0; k < 6; ++k) { /* terminal cost (x - SS lmb)' D (x - SS lmb) at fixed lmb */
-        double xb = 0;
-        for (int j = 0; j < S; ++j) xb += p->ssx[k][j] * p->lmb[j];
-        PT0[k * 6 + k] = p->chs2[k];
-        pT0[k] = -p->chs2[k] * xb;
-      }
-    double (*kin)[2] = malloc(sizeof(double[NMAX][2]));
-    riccati_factor(p, S ? PT0 : NULL, S ? pT0 : NULL, kin);
-    for (int i = 0; i < N - 1; ++i) {
-      for (int a = 0; a < 2; ++a) {
-        double acc = -kin[i][a];
-        for (int c = 0; c < 8; ++c) acc -= p->K[i][a * 8 + c] * p->z[i][c];
-        p->v[i][a] = acc;
-      }
-      const double u0 = p->z[i][6] + p->dt[i] * p->v[i][0], u1 = p->z[i][7] + p->dt[i] * p->v[i][1];
-      for (int r = 0; r < 6; ++r) {
-        double acc = p->g[i][r] + p->B[i][r * 2] * u0 + p->B[i][r * 2 + 1] * u1;
-        for (int c = 0; c < 6; ++c) acc += p->A[i][r * 6 + c] * p->z[i][c];
-        p->z[i + 1][r] = acc;
-      }
-      p->z[i + 1][6] = u0;
-      p->z[i + 1][7] = u1;
-    }
-    free(kin);
+   * rows, sigma = 0).  The linearised model can be open-loop unstable (|eig A| > 1 at low speed
+   * with dt = 25 ms), so the trajectory is first rolled out under the stabilising Riccati
+   * feedback v = -K z (all row weights zero), then one Newton step from that dynamics-feasible
+   * point lands on the minimiser exactly (the cost is quadratic).                              */
+  memset(w->th, 0, sizeof(w->th));
+  memset(w->cf, 0, sizeof(w->cf));
+  w->ths = w->cfs = 0.0;
+  for (int j = 0; j < S; ++j) {
+    p->lmb[j] = 1.0 / S;
+    w->thl[j] = 1.0;
+    w->cfl[j] = 0.0;
   }
   p->sigma = 0.0;
+  newton_factor(p, w);
+  for (int i = 0; i < N - 1; ++i) {
+    for (int a = 0; a < 2; ++a) {
+      double acc = 0.0;
+      for (int c = 0; c < 8; ++c) acc -= p->K[i][a * 8 + c] * p->z[i][c];
+      p->v[i][a] = acc;
+    }
+    const double u0 = p->z[i][6] + p->dt[i] * p->v[i][0], u1 = p->z[i][7] + p->dt[i] * p->v[i][1];
+    for (int r = 0; r < 6; ++r) {
+      double acc = p->g[i][r] + p->B[i][r * 2] * u0 + p->B[i][r * 2 + 1] * u1;
+      for (int c = 0; c < 6; ++c) acc += p->A[i][r * 6 + c] * p->z[i][c];
+      p->z[i + 1][r] = acc;
+    }
+    p->z[i + 1][6] = u0;
+    p->z[i + 1][7] = u1;
+  }
+  cost_gradient(p, w);
+  newton_solve(p, w);
+  p->dsigma = 0.0;
+  for (int j = 0; j < S; ++j) p->dlmb[j] = 0.0;
+  primal_update(p, 1.0);
   int m = 0;
   for (int i = 0; i < N; ++i)
     for (int sl = 0; sl < NSLOT; ++sl) {
@@ -774,7 +746,7 @@ static int ipm_solve(prob_t* p, int* iters_out, double* kkt_out) {
   double mu = 0.0, rdmax = 0.0;
 
   /* ================= phase 1: interior point ================= */
-  for (it = 0; it < p->max_iter; ++it) {
+  for (it = 0; it <= p->max_iter; ++it) {
     double musum = 0.0;
     rdmax = 0.0;
     for (int i = 0; i < N; ++i)
@@ -808,6 +780,7 @@ static int ipm_solve(prob_t* p, int* iters_out, double* kkt_out) {
       status = LMPC_SOLVE_OPTIMAL;
       break;
     }
+    if (it == p->max_iter) break;
     cost_gradient(p, w);
     newton_factor(p, w);
     double sigc = 0.0, alpha = 1.0;

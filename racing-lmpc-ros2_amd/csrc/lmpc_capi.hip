@@ -1,0 +1,352 @@
+// lmpc_capi.hip -- host side of the C ABI declared in include/lmpc_hip.h (gfx950 / ROCm).
+//
+// The handle owns: the digested parameter block (the reference builds its parametric problem
+// once in RacingMPC::RacingMPC, racing_mpc.cpp:31-202), one HIP stream, the linearisation
+// workspace and the device copy of the safe set.  Nothing here computes on the hot path; the
+// product fails loudly (negative return code + message) rather than falling back to a CPU path.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "lmpc_device.h"
+
+template <bool WS_LAYOUT>
+__global__ void lmpc_linearize_kernel(lmpc_params, int, const double*, const double*, const double*, const double*,
+                                      double*, double*, double*);
+__global__ void lmpc_prepare_kernel(lmpc_params, int, lmpc_track, const double*, double, double, double, double*,
+                                    double*, double*, double*, double*, double*, double*);
+template <int KQ>
+__global__ void lmpc_solve_kernel(lmpc_params, int, const double*, const double*, const double*, const double*,
+                                  const double*, const double*, const double*, double*, double*, double*, int*, int*,
+                                  double*);
+__global__ void lmpc_ss_query_kernel(int, int, int, int, const int*, const int*, const double*, double, const double*,
+                                     double*, double*, int*);
+
+struct lmpc_handle {
+  lmpc_params P;
+  lmpc_config cfg;
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  double* ws = nullptr;  // [cap][N-1][LMPC_LIN_RECORD]
+  size_t ws_cap = 0;
+  // safe set (device): laps newest-first offsets
+  int ss_laps = 0;
+  int ss_total = 0;
+  int* ss_npts = nullptr;
+  int* ss_off = nullptr;
+  double* ss_x = nullptr;  // [total][6]
+  double ss_L = 0.0;
+  int ss_nmax = 0;
+  // timing
+  bool timing = false;
+  hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+  std::string err;
+};
+
+namespace {
+
+int fail(lmpc_handle* h, int code, const std::string& msg) {
+  if (h) h->err = msg;
+  return code;
+}
+
+#define HIP_TRY(h, expr)                                                                         \
+  do {                                                                                           \
+    hipError_t e_ = (expr);                                                                      \
+    if (e_ != hipSuccess)                                                                        \
+      return fail(h, LMPC_ERR_RUNTIME, std::string(#expr) + ": " + hipGetErrorString(e_));       \
+  } while (0)
+
+int kq_for(int N) {
+  const int need = (11 * N + 63) / 64;
+  const int opts[5] = {2, 4, 7, 11, 14};
+  for (int o : opts)
+    if (need <= o) return o;
+  return -1;
+}
+
+template <int KQ>
+int launch_solve(lmpc_handle* h, int B, size_t lds_bytes, const double* x_ic, const double* u_ic, const double* T_ref,
+                 const double* bl, const double* br, const double* vref, double* X, double* U, double* dU, int* status,
+                 int* iters, double* kkt) {
+  HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&lmpc_solve_kernel<KQ>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  hipLaunchKernelGGL(lmpc_solve_kernel<KQ>, dim3(B), dim3(64), lds_bytes, h->stream, h->P, B, h->ws, x_ic, u_ic, T_ref,
+                     bl, br, vref, X, U, dU, status, iters, kkt);
+  HIP_TRY(h, hipGetLastError());
+  return LMPC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int lmpc_create(const lmpc_config* cfg, const lmpc_vehicle* veh, int device, lmpc_handle** out) {
+  if (!cfg || !veh || !out) return LMPC_ERR_ARGUMENT;
+  *out = nullptr;
+  lmpc_handle* h = new (std::nothrow) lmpc_handle();
+  if (!h) return LMPC_ERR_RUNTIME;
+  *out = h;  // returned even on failure so that lmpc_last_error can be read; caller destroys it
+  if (veh->model_id != LMPC_MODEL_SINGLE_TRACK_PLANAR)
+    return fail(h, LMPC_ERR_UNSUPPORTED, "only single_track_planar_model is built (vehicle_model_factory.cpp:31-49)");
+  if (cfg->N < 3 || kq_for(cfg->N) < 0) return fail(h, LMPC_ERR_ARGUMENT, "N must be in [3, 81]");
+  if (cfg->learning && (cfg->num_ss_pts < 1 || cfg->num_ss_pts_per_lap < 1))
+    return fail(h, LMPC_ERR_ARGUMENT, "learning needs num_ss_pts >= 1 and num_ss_pts_per_lap >= 1");
+  h->cfg = *cfg;
+  h->device = device;
+  lmpc_params& P = h->P;
+  std::memset(&P, 0, sizeof(P));
+  P.N = cfg->N;
+  P.has_sigma = cfg->q_boundary > 0.0 ? 1 : 0;
+  P.learning = cfg->learning ? 1 : 0;
+  P.S = cfg->learning ? cfg->num_ss_pts : 0;
+  P.max_iter = cfg->max_iter > 0 ? cfg->max_iter : 40;
+  P.tol = cfg->tol > 0.0 ? cfg->tol : 1e-11;
+  const double qd[6] = {0.0, cfg->q_contour, cfg->q_heading, cfg->q_vel, cfg->q_vy, cfg->q_vyaw};
+  const double qt[6] = {0.0, cfg->q_contour, cfg->q_heading, cfg->q_vel, 0.0, 0.0};
+  for (int k = 0; k < 6; ++k) {
+    P.Qd[k] = 2.0 * qd[k];
+    P.Qt[k] = 20.0 * qt[k];
+    P.x_max[k] = cfg->x_max[k];
+    P.x_min[k] = cfg->x_min[k];
+    P.chs2[k] = 2.0 * cfg->convex_hull_slack[k];
+  }
+  P.qv_stage = -2.0 * cfg->q_vel;
+  P.qv_term = -20.0 * cfg->q_vel;
+  for (int a = 0; a < 2; ++a)
+    for (int c = 0; c < 2; ++c) {
+      P.Qu[a * 2 + c] = cfg->R[a * 2 + c] + cfg->R[c * 2 + a];
+      P.Sv[a * 2 + c] = cfg->R_d[a * 2 + c] + cfg->R_d[c * 2 + a];
+    }
+  P.qsig = 2.0 * cfg->q_boundary;
+  P.u_lo[0] = std::fmax(cfg->u_min[0], veh->Fb_max / 1000.0);  // single_track_planar_model.cpp:114
+  P.u_hi[0] = std::fmin(cfg->u_max[0], veh->Fd_max / 1000.0);
+  P.u_lo[1] = std::fmax(cfg->u_min[1], -veh->max_steer);       // :120
+  P.u_hi[1] = std::fmin(cfg->u_max[1], veh->max_steer);
+  P.v_lo[0] = veh->Fb_max / 1000.0 / veh->Tb;                  // :146-151
+  P.v_hi[0] = veh->Fd_max / 1000.0 / veh->Td;
+  P.v_lo[1] = -veh->max_steer_rate;
+  P.v_hi[1] = veh->max_steer_rate;
+  P.marg = cfg->margin + veh->b / 2.0;                         // racing_mpc.cpp:531
+  P.max_vel_ref_diff = cfg->max_vel_ref_diff;
+  P.veh = *veh;
+  if (!(P.Sv[0] > 0.0) || !(P.Sv[0] * P.Sv[3] - P.Sv[1] * P.Sv[2] > 0.0))
+    return fail(h, LMPC_ERR_ARGUMENT, "R_d must be positive definite");
+  HIP_TRY(h, hipSetDevice(device));
+  HIP_TRY(h, hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+  h->stream = h->own_stream;
+  for (auto& e : h->ev) HIP_TRY(h, hipEventCreate(&e));
+  return LMPC_OK;
+}
+
+void lmpc_destroy(lmpc_handle* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  if (h->ws) (void)hipFree(h->ws);
+  if (h->ss_npts) (void)hipFree(h->ss_npts);
+  if (h->ss_off) (void)hipFree(h->ss_off);
+  if (h->ss_x) (void)hipFree(h->ss_x);
+  for (auto& e : h->ev)
+    if (e) (void)hipEventDestroy(e);
+  if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+  delete h;
+}
+
+const char* lmpc_last_error(const lmpc_handle* h) { return h ? h->err.c_str() : "null handle"; }
+
+int lmpc_set_stream(lmpc_handle* h, void* hip_stream) {
+  if (!h) return LMPC_ERR_ARGUMENT;
+  h->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : h->own_stream;
+  return LMPC_OK;
+}
+
+int lmpc_synchronize(lmpc_handle* h) {
+  if (!h) return LMPC_ERR_ARGUMENT;
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return LMPC_OK;
+}
+
+int lmpc_reserve(lmpc_handle* h, int32_t max_batch) {
+  if (!h || max_batch < 0) return LMPC_ERR_ARGUMENT;
+  if ((size_t)max_batch <= h->ws_cap) return LMPC_OK;
+  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  if (h->ws) HIP_TRY(h, hipFree(h->ws));
+  h->ws = nullptr;
+  h->ws_cap = 0;
+  const size_t bytes = (size_t)max_batch * (h->P.N - 1) * LMPC_LIN_RECORD * sizeof(double);
+  HIP_TRY(h, hipMalloc(&h->ws, bytes));
+  h->ws_cap = (size_t)max_batch;
+  return LMPC_OK;
+}
+
+int lmpc_query_launch(const lmpc_handle* h, int32_t* lds_bytes_per_problem, int32_t* threads_per_problem) {
+  if (!h) return LMPC_ERR_ARGUMENT;
+  if (lds_bytes_per_problem) *lds_bytes_per_problem = lmpc_lds_doubles(h->P.N) * (int)sizeof(double);
+  if (threads_per_problem) *threads_per_problem = 64;
+  return LMPC_OK;
+}
+
+int lmpc_enable_timing(lmpc_handle* h, int32_t on) {
+  if (!h) return LMPC_ERR_ARGUMENT;
+  h->timing = on != 0;
+  return LMPC_OK;
+}
+
+int lmpc_last_kernel_ms(lmpc_handle* h, float* linearize_ms, float* solve_ms) {
+  if (!h) return LMPC_ERR_ARGUMENT;
+  if (!h->timing) return fail(h, LMPC_ERR_ARGUMENT, "timing not enabled");
+  HIP_TRY(h, hipEventSynchronize(h->ev[2]));
+  float a = 0.f, b = 0.f;
+  HIP_TRY(h, hipEventElapsedTime(&a, h->ev[0], h->ev[1]));
+  HIP_TRY(h, hipEventElapsedTime(&b, h->ev[1], h->ev[2]));
+  if (linearize_ms) *linearize_ms = a;
+  if (solve_ms) *solve_ms = b;
+  return LMPC_OK;
+}
+
+int lmpc_linearize_batch(lmpc_handle* h, int32_t batch, const double* X_ref, const double* U_ref, const double* T_ref,
+                         const double* curvatures, double* A, double* Bm, double* g) {
+  if (!h) return LMPC_ERR_ARGUMENT;
+  if (batch < 0 || !X_ref || !U_ref || !T_ref || !curvatures || !A || !Bm || !g)
+    return fail(h, LMPC_ERR_ARGUMENT, "lmpc_linearize_batch: null pointer or negative batch");
+  if (batch == 0) return LMPC_OK;
+  HIP_TRY(h, hipSetDevice(h->device));
+  dim3 grid((batch + 255) / 256, h->P.N - 1);
+  hipLaunchKernelGGL(lmpc_linearize_kernel<false>, grid, dim3(256), 0, h->stream, h->P, batch, X_ref, U_ref, T_ref,
+                     curvatures, A, Bm, g);
+  HIP_TRY(h, hipGetLastError());
+  return LMPC_OK;
+}
+
+int lmpc_solve_batch(lmpc_handle* h, int32_t batch, const double* x_ic, const double* u_ic, const double* X_ref,
+                     const double* U_ref, const double* T_ref, const double* bound_left, const double* bound_right,
+                     const double* curvatures, const double* vel_ref, double total_length, const double* ss_x,
+                     const double* ss_j, double* X_optm, double* U_optm, double* dU_optm, double* convex_combi_optm,
+                     int32_t* status, int32_t* iters, double* kkt) {
+  if (!h) return LMPC_ERR_ARGUMENT;
+  (void)total_length;  // abscissa alignment (racing_mpc.cpp:219-223) shifts s only; the QP is invariant to it
+  (void)convex_combi_optm;
+  if (batch < 0 || !x_ic || !u_ic || !X_ref || !U_ref || !T_ref || !bound_left || !bound_right || !curvatures ||
+      !vel_ref || !X_optm || !U_optm || !dU_optm || !status || !iters)
+    return fail(h, LMPC_ERR_ARGUMENT, "lmpc_solve_batch: null pointer or negative batch");
+  if (h->P.learning) {
+    if (!ss_x || !ss_j) return fail(h, LMPC_ERR_ARGUMENT, "learning=1 needs ss_x and ss_j");
+    return fail(h, LMPC_ERR_UNSUPPORTED, "LMPC terminal block (racing_mpc.cpp:479-522) not built in this round");
+  }
+  if (batch == 0) return LMPC_OK;
+  HIP_TRY(h, hipSetDevice(h->device));
+  if ((size_t)batch > h->ws_cap) {
+    const int rc = lmpc_reserve(h, batch);
+    if (rc != LMPC_OK) return rc;
+  }
+  const int N = h->P.N;
+  if (h->timing) HIP_TRY(h, hipEventRecord(h->ev[0], h->stream));
+  dim3 grid((batch + 255) / 256, N - 1);
+  hipLaunchKernelGGL(lmpc_linearize_kernel<true>, grid, dim3(256), 0, h->stream, h->P, batch, X_ref, U_ref, T_ref,
+                     curvatures, h->ws, (double*)nullptr, (double*)nullptr);
+  HIP_TRY(h, hipGetLastError());
+  if (h->timing) HIP_TRY(h, hipEventRecord(h->ev[1], h->stream));
+  const size_t lds_bytes = (size_t)lmpc_lds_doubles(N) * sizeof(double);
+  int rc = LMPC_ERR_ARGUMENT;
+  switch (kq_for(N)) {
+    case 2: rc = launch_solve<2>(h, batch, lds_bytes, x_ic, u_ic, T_ref, bound_left, bound_right, vel_ref, X_optm, U_optm, dU_optm, status, iters, kkt); break;
+    case 4: rc = launch_solve<4>(h, batch, lds_bytes, x_ic, u_ic, T_ref, bound_left, bound_right, vel_ref, X_optm, U_optm, dU_optm, status, iters, kkt); break;
+    case 7: rc = launch_solve<7>(h, batch, lds_bytes, x_ic, u_ic, T_ref, bound_left, bound_right, vel_ref, X_optm, U_optm, dU_optm, status, iters, kkt); break;
+    case 11: rc = launch_solve<11>(h, batch, lds_bytes, x_ic, u_ic, T_ref, bound_left, bound_right, vel_ref, X_optm, U_optm, dU_optm, status, iters, kkt); break;
+    case 14: rc = launch_solve<14>(h, batch, lds_bytes, x_ic, u_ic, T_ref, bound_left, bound_right, vel_ref, X_optm, U_optm, dU_optm, status, iters, kkt); break;
+    default: return fail(h, LMPC_ERR_ARGUMENT, "unsupported N");
+  }
+  if (rc != LMPC_OK) return rc;
+  if (h->timing) HIP_TRY(h, hipEventRecord(h->ev[2], h->stream));
+  return LMPC_OK;
+}
+
+int lmpc_prepare_batch(lmpc_handle* h, int32_t batch, const lmpc_track* track, const double* x_ic, double dt,
+                       double speed_scale, double speed_limit, double* X_ref, double* U_ref, double* T_ref,
+                       double* bound_left, double* bound_right, double* curvatures, double* vel_ref) {
+  if (!h) return LMPC_ERR_ARGUMENT;
+  if (batch < 0 || !track || !x_ic || !X_ref || !U_ref || !T_ref || !bound_left || !bound_right || !curvatures ||
+      !vel_ref || !track->curvature || !track->bound_left || !track->bound_right || !track->vel || track->M < 2 ||
+      !(track->L > 0.0) || !(dt > 0.0))
+    return fail(h, LMPC_ERR_ARGUMENT, "lmpc_prepare_batch: bad argument");
+  if (batch == 0) return LMPC_OK;
+  HIP_TRY(h, hipSetDevice(h->device));
+  hipLaunchKernelGGL(lmpc_prepare_kernel, dim3((batch + 255) / 256), dim3(256), 0, h->stream, h->P, batch, *track, x_ic,
+                     dt, speed_scale, speed_limit, X_ref, U_ref, T_ref, bound_left, bound_right, curvatures, vel_ref);
+  HIP_TRY(h, hipGetLastError());
+  return LMPC_OK;
+}
+
+int lmpc_set_safe_set(lmpc_handle* h, int32_t n_laps, const int32_t* n_pts, const double* x, double total_length) {
+  if (!h) return LMPC_ERR_ARGUMENT;
+  if (n_laps < 0 || (n_laps > 0 && (!n_pts || !x)) || !(total_length > 0.0))
+    return fail(h, LMPC_ERR_ARGUMENT, "lmpc_set_safe_set: bad argument");
+  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  if (h->ss_npts) HIP_TRY(h, hipFree(h->ss_npts));
+  if (h->ss_off) HIP_TRY(h, hipFree(h->ss_off));
+  if (h->ss_x) HIP_TRY(h, hipFree(h->ss_x));
+  h->ss_npts = h->ss_off = nullptr;
+  h->ss_x = nullptr;
+  h->ss_laps = 0;
+  h->ss_total = 0;
+  h->ss_nmax = 0;
+  h->ss_L = total_length;
+  // SafeSetManager keeps at most max_lap_stored laps (boost::circular_buffer, safe_set.cpp:139-151)
+  int first = 0;
+  if (h->cfg.max_lap_stored > 0 && n_laps > h->cfg.max_lap_stored) first = n_laps - h->cfg.max_lap_stored;
+  std::vector<int> npts, off;
+  size_t skip = 0, total = 0;
+  for (int l = 0; l < n_laps; ++l) {
+    if (n_pts[l] < 1) return fail(h, LMPC_ERR_ARGUMENT, "lmpc_set_safe_set: empty lap");
+    if (l < first) {
+      skip += (size_t)n_pts[l];
+      continue;
+    }
+    off.push_back((int)total);
+    npts.push_back(n_pts[l]);
+    if (n_pts[l] > h->ss_nmax) h->ss_nmax = n_pts[l];
+    total += (size_t)n_pts[l];
+  }
+  if (npts.empty()) return LMPC_OK;
+  HIP_TRY(h, hipMalloc(&h->ss_npts, npts.size() * sizeof(int)));
+  HIP_TRY(h, hipMalloc(&h->ss_off, off.size() * sizeof(int)));
+  HIP_TRY(h, hipMalloc(&h->ss_x, total * 6 * sizeof(double)));
+  HIP_TRY(h, hipMemcpy(h->ss_npts, npts.data(), npts.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIP_TRY(h, hipMemcpy(h->ss_off, off.data(), off.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIP_TRY(h, hipMemcpy(h->ss_x, x + skip * 6, total * 6 * sizeof(double), hipMemcpyHostToDevice));
+  h->ss_laps = (int)npts.size();
+  h->ss_total = (int)total;
+  return LMPC_OK;
+}
+
+int lmpc_ss_query_batch(lmpc_handle* h, int32_t batch, const double* query, double* ss_x, double* ss_j,
+                        int32_t* n_found) {
+  if (!h) return LMPC_ERR_ARGUMENT;
+  if (batch < 0 || !query || !ss_x || !ss_j || !n_found)
+    return fail(h, LMPC_ERR_ARGUMENT, "lmpc_ss_query_batch: null pointer or negative batch");
+  if (h->cfg.num_ss_pts < 1 || h->cfg.num_ss_pts_per_lap < 1)
+    return fail(h, LMPC_ERR_ARGUMENT, "num_ss_pts / num_ss_pts_per_lap not configured");
+  if (h->cfg.num_ss_pts_per_lap > 64)
+    return fail(h, LMPC_ERR_UNSUPPORTED, "num_ss_pts_per_lap > 64");
+  if (batch == 0) return LMPC_OK;
+  HIP_TRY(h, hipSetDevice(h->device));
+  const size_t lds = (size_t)3 * (h->ss_nmax > 0 ? h->ss_nmax : 1) * sizeof(double);
+  if (lds > 160 * 1024) return fail(h, LMPC_ERR_UNSUPPORTED, "lap longer than 6826 samples");
+  HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&lmpc_ss_query_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(lmpc_ss_query_kernel, dim3(batch), dim3(64), lds, h->stream, batch, h->ss_laps, h->cfg.num_ss_pts,
+                     h->cfg.num_ss_pts_per_lap, h->ss_npts, h->ss_off, h->ss_x, h->ss_L, query, ss_x, ss_j, n_found);
+  HIP_TRY(h, hipGetLastError());
+  return LMPC_OK;
+}
+
+}  // extern "C"

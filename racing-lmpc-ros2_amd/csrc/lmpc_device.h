@@ -1,0 +1,43 @@
+// lmpc_device.h -- parameter block shared by the host C-ABI layer and the gfx950 kernels.
+#ifndef LMPC_DEVICE_H_
+#define LMPC_DEVICE_H_
+
+#include "lmpc_hip.h"
+
+// Everything the kernels need from lmpc_config / lmpc_vehicle, pre-digested on the host
+// (lmpc_create).  Passed by value as a kernel argument (lands in the kernarg segment / SGPRs).
+struct lmpc_params {
+  int N;          // knot points
+  int has_sigma;  // q_boundary > 0: one shared boundary slack (racing_mpc.cpp:529-539)
+  int learning;   // LMPC terminal set + cost (racing_mpc.cpp:479-522)
+  int S;          // safe-set points
+  int max_iter;
+  int pad0;
+  double tol;      // complementarity tolerance of the interior-point iteration
+  double Qd[6];    // 2*q stage weights on x      (racing_mpc.cpp:459-463)
+  double Qt[6];    // 2*10*q terminal weights     (racing_mpc.cpp:474-476)
+  double qv_stage; // -2 q_vel      (times vel_ref_i gives the linear term)
+  double qv_term;  // -20 q_vel
+  double Qu[4];    // R + R'
+  double Sv[4];    // R_d + R_d'
+  double qsig;     // 2 q_boundary
+  double x_max[6], x_min[6];
+  double u_hi[2], u_lo[2]; // MPC box intersected with the actuator box
+  double v_hi[2], v_lo[2]; // rate box (single_track_planar_model.cpp:146-151)
+  double marg;             // margin + chassis.b / 2 (racing_mpc.cpp:531)
+  double chs2[6];          // 2 * convex_hull_slack
+  double max_vel_ref_diff;
+  lmpc_vehicle veh;
+};
+
+// LDS record sizes (in doubles) of the solve kernel; see DESIGN.md "data layout".
+#define LMPC_STAGE_STRIDE 80
+#define LMPC_KNOT_STRIDE 34
+#define LMPC_TAIL_DOUBLES 320
+#define LMPC_LIN_RECORD 54  // per stage in the linearisation workspace: ABt[8][6] | g[6]
+
+static inline int lmpc_lds_doubles(int N) {
+  return (N - 1) * LMPC_STAGE_STRIDE + N * LMPC_KNOT_STRIDE + LMPC_TAIL_DOUBLES;
+}
+
+#endif

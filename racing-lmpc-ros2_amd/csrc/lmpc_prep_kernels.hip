@@ -1,0 +1,156 @@
+// lmpc_prep_kernels.hip -- gfx950 kernels either side of the QP solve:
+//   lmpc_linearize_kernel : discrete_dynamics_jacobian (A, B, g) of every stage of every problem
+//                           (single_track_planar_model.cpp:377-387, used at racing_mpc.cpp:173-182)
+//   lmpc_prepare_kernel   : the controller node's cold-start input preparation
+//                           (racing_mpc_node.cpp:210-235, 261-292)
+// Both are one thread per unit of work with the batch axis on the lanes, so every global access
+// is a coalesced 512-byte wave transaction on the [field][knot][batch] arrays.
+#include <hip/hip_runtime.h>
+
+#include "lmpc_device.h"
+#include "lmpc_dynamics.hip.h"
+
+// One thread per (problem b, stage i).  blockIdx.y = stage, so a wave covers 64 consecutive
+// problems of one stage.  Forward-mode chain rule through the four RK4 stages:
+//   K_s = Fx(x_s) X_s + Fu(x_s) [0 I],   X_{s+1} = [I 0] + c_s dt K_s,   [A B] = [I 0] + dt/6 sum w_s K_s.
+// The primal sweep stores the sparse partials of the four points; the eight tangent columns
+// are then pushed through one at a time (keeps the live register set small).
+// WS_LAYOUT = true : workspace for the solve kernel, record per (b, i): ABt[8][6] | g[6]
+//                    (ABt[c][k] = [A B][k][c], i.e. columns contiguous)
+// WS_LAYOUT = false: C-ABI arrays A [6][6][N-1][B], Bm [6][2][N-1][B], g [6][N-1][B]
+template <bool WS_LAYOUT>
+__global__ __launch_bounds__(256) void lmpc_linearize_kernel(lmpc_params P, int B, const double* __restrict__ X_ref,
+                                                             const double* __restrict__ U_ref,
+                                                             const double* __restrict__ T_ref,
+                                                             const double* __restrict__ curv, double* __restrict__ outA,
+                                                             double* __restrict__ outB, double* __restrict__ outg) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = blockIdx.y;
+  const int N = P.N, NS = N - 1;
+  if (b >= B) return;
+  double x[6], u[2];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) x[k] = X_ref[(size_t)(k * N + i) * B + b];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) u[k] = U_ref[(size_t)(k * NS + i) * B + b];
+  const double dt = T_ref[(size_t)i * B + b];
+  const double kap = curv[(size_t)i * B + b];
+
+  lmpc_uterms ut;
+  lmpc_u_terms(P.veh, u[0], u[1], ut);
+  lmpc_fjac J[4];
+  double ks[4][6], xs[6];
+  const double cs[4] = {0.0, 0.5, 0.5, 1.0};
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+#pragma unroll
+    for (int r = 0; r < 6; ++r) xs[r] = (s == 0) ? x[r] : x[r] + cs[s] * dt * ks[s - 1][r];
+    lmpc_f<true>(P.veh, ut, xs, kap, ks[s], &J[s]);
+  }
+  double xp[6], gacc[6];
+#pragma unroll
+  for (int r = 0; r < 6; ++r) {
+    xp[r] = x[r] + dt / 6 * (ks[0][r] + 2 * ks[1][r] + 2 * ks[2][r] + ks[3][r]);
+    gacc[r] = xp[r];
+  }
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    double tu[2] = {c == 6 ? 1.0 : 0.0, c == 7 ? 1.0 : 0.0};
+    double e[6], tx[6], kc[6], acc[6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      e[r] = (r == c) ? 1.0 : 0.0;
+      tx[r] = e[r];
+      acc[r] = 0.0;
+    }
+    const double wgt[4] = {1.0, 2.0, 2.0, 1.0};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      lmpc_jvp(J[s], tx, tu, kc);
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+        acc[r] += wgt[s] * kc[r];
+        if (s < 3) tx[r] = e[r] + cs[s + 1] * dt * kc[r];
+      }
+    }
+    const double xu = (c < 6) ? x[c] : u[c - 6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      const double d = e[r] + dt / 6 * acc[r];  // [A B][r][c]
+      gacc[r] -= d * xu;
+      if (WS_LAYOUT)
+        outA[((size_t)b * NS + i) * LMPC_LIN_RECORD + c * 6 + r] = d;
+      else if (c < 6)
+        outA[((size_t)(r * 6 + c) * NS + i) * B + b] = d;
+      else
+        outB[((size_t)(r * 2 + (c - 6)) * NS + i) * B + b] = d;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 6; ++r) {
+    if (WS_LAYOUT)
+      outA[((size_t)b * NS + i) * LMPC_LIN_RECORD + 48 + r] = gacc[r];
+    else
+      outg[((size_t)r * NS + i) * B + b] = gacc[r];
+  }
+}
+
+template __global__ void lmpc_linearize_kernel<true>(lmpc_params, int, const double*, const double*, const double*,
+                                                     const double*, double*, double*, double*);
+template __global__ void lmpc_linearize_kernel<false>(lmpc_params, int, const double*, const double*, const double*,
+                                                      const double*, double*, double*, double*);
+
+// periodic linear interpolation on a uniform table of M samples over [0, L)
+__device__ __forceinline__ double track_lookup(const double* __restrict__ tab, int M, double L, double s) {
+  double u = fmod(s, L);
+  if (u < 0.0) u += L;
+  u = u / (L / M);
+  double fl = floor(u);
+  const double fr = u - fl;
+  int i0 = (int)fl;
+  i0 = i0 % M;
+  if (i0 < 0) i0 += M;
+  const int i1 = (i0 + 1 == M) ? 0 : i0 + 1;
+  return tab[i0] * (1.0 - fr) + tab[i1] * fr;
+}
+
+// One thread per problem: zero-input rollout of the reference, then reference sampling.
+__global__ __launch_bounds__(256) void lmpc_prepare_kernel(lmpc_params P, int B, lmpc_track trk,
+                                                           const double* __restrict__ x_ic, double dt,
+                                                           double speed_scale, double speed_limit,
+                                                           double* __restrict__ X_ref, double* __restrict__ U_ref,
+                                                           double* __restrict__ T_ref, double* __restrict__ bl,
+                                                           double* __restrict__ br, double* __restrict__ curv,
+                                                           double* __restrict__ vref) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int N = P.N, NS = N - 1;
+  double x[6], xn[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) x[k] = x_ic[(size_t)k * B + b];
+  const double u[2] = {1e-9, 1e-9};  // racing_mpc_node.cpp:212
+  const double d = P.max_vel_ref_diff;
+  for (int i = 0; i < N; ++i) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) X_ref[(size_t)(k * N + i) * B + b] = x[k];
+    const double s = x[0];
+    const double kap = track_lookup(trk.curvature, trk.M, trk.L, s);
+    bl[(size_t)i * B + b] = track_lookup(trk.bound_left, trk.M, trk.L, s);
+    br[(size_t)i * B + b] = track_lookup(trk.bound_right, trk.M, trk.L, s);
+    curv[(size_t)i * B + b] = kap;
+    // vel_ref clamp, racing_mpc_node.cpp:269-286
+    const double cur = x[3];
+    const double vr = track_lookup(trk.vel, trk.M, trk.L, s) * speed_scale;
+    const double lim = fmin(fmax(speed_limit, cur - d), cur + d);
+    const double clipped = fmin(fmax(vr, cur - d), cur + d);
+    vref[(size_t)i * B + b] = (vr > 0.0) ? fmin(clipped, lim) : lim;
+    if (i < NS) {
+      U_ref[(size_t)(0 * NS + i) * B + b] = u[0];
+      U_ref[(size_t)(1 * NS + i) * B + b] = u[1];
+      T_ref[(size_t)i * B + b] = dt;
+      lmpc_rk4(P.veh, x, u, kap, dt, xn);  // :216-224, curvature at the knot's own abscissa (:72-76)
+#pragma unroll
+      for (int k = 0; k < 6; ++k) x[k] = xn[k];
+    }
+  }
+}
