@@ -1,0 +1,191 @@
+"""bench.py -- QP solves/sec of the batched tracking-MPC solve path on MI355X.
+
+A step is one pass of the hot path (lmpc_solve_batch: stage linearisation + QP solve) over one
+batch of synthetic problems already resident in HBM.  Workload = BASELINE.json configs[1]:
+BARC tracking MPC, batch 4096 random x0, N = 20, fp64, per GPU (weak scaling across ranks).
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+from __graft_entry__ import load_package  # noqa: E402
+
+ALGO_BYTES_PER_SOLVE = (13 * 20 + 5) * 8 + (10 * 20 - 4) * 8 + 8  # 3696 B at N = 20 fp64
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
+
+
+def cpu_baseline(pkg, N, batch, seconds_target=12.0):
+    """Time the C restatement (oracle, 'port') on the host cores over a bounded sample."""
+    import ctypes as C
+    from concurrent.futures import ThreadPoolExecutor
+
+    from oracle import cbind, params as OP, qp as OQ, scenario as OS
+
+    veh, cfg = OP.barc_vehicle(), OP.barc_tracking_mpc(N)
+    tr = pkg.workloads.synthetic_track("barc")
+    u_lo, u_hi, _, _ = OQ.effective_bounds(cfg, veh)
+    cores = os.cpu_count() or 1
+    B = min(batch, 1024)
+    x, u = pkg.workloads.sample_initial_states("barc", B, tr["L"], u_lo, u_hi, 0)
+    inp = OS.cold_start_inputs(cfg, veh, tr, x, u, 0.025)
+    cbind.lib()
+    t0 = time.perf_counter()
+    cbind.solve_batch(cfg, veh, inp, b0=0, b1=32)
+    per = (time.perf_counter() - t0) / 32
+    reps = max(1, int(seconds_target * cores / (per * B)))
+    reps = min(reps, 64)
+    chunks = np.linspace(0, B, cores + 1).astype(int)
+
+    def work(c):
+        for _ in range(reps):
+            cbind.solve_batch(cfg, veh, inp, b0=int(chunks[c]), b1=int(chunks[c + 1]))
+
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:
+        list(ex.map(work, range(cores)))
+    dt = time.perf_counter() - t0
+    return {"value": reps * B / dt, "unit": "solves/s", "cores": cores, "kind": "port",
+            "sample": f"{reps} x {B} problems of the bench workload, static split over {cores} threads, "
+                      f"oracle/c/lmpc_oracle.c -O3 ({dt:.1f} s)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=4096)
+    ap.add_argument("--horizon", type=int, default=20)
+    ap.add_argument("--no-gather", action="store_true", help="skip the RCCL result gather for N > 1")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU path)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    pkg = load_package()
+    N, B = args.horizon, args.batch
+    solver = pkg.Solver(pkg.presets.barc_tracking_mpc(N), pkg.presets.barc_vehicle(), device=local)
+    solver.use_current_stream()
+    solver.reserve(B)
+    tr = pkg.workloads.synthetic_track("barc")
+    P = solver.config
+    u_lo = [max(P["u_min"][0], -0.015), max(P["u_min"][1], -0.314159)]
+    u_hi = [min(P["u_max"][0], 0.015), min(P["u_max"][1], 0.314159)]
+    x, u = pkg.workloads.sample_initial_states("barc", B, tr["L"], u_lo, u_hi, seed=rank)
+    inp = solver.prepare(tr, x.T.copy(), 0.025)   # node cold start on the device (racing_mpc_node.cpp:210-292)
+    inp["u_ic"] = torch.as_tensor(u.T.copy(), dtype=torch.float64, device=dev)
+    outs = [solver.alloc_outputs(B), solver.alloc_outputs(B)]
+    gather = world > 1 and not args.no_gather
+    if gather:
+        import torch.distributed as dist
+        flat = [torch.empty((10 * N - 4) * B, dtype=torch.float64, device=dev) for _ in range(2)]
+        gbuf = [torch.empty(world * flat[0].numel(), dtype=torch.float64, device=dev) for _ in range(2)]
+
+    def step(k, handle_prev):
+        o = outs[k & 1]
+        solver.solve(inp, o)
+        if gather:
+            if handle_prev is not None:
+                handle_prev.wait()
+            f = flat[k & 1]
+            torch.cat([o["X_optm"].reshape(-1), o["U_optm"].reshape(-1), o["dU_optm"].reshape(-1)], out=f)
+            return dist.all_gather_into_tensor(gbuf[k & 1], f, async_op=True)
+        return None
+
+    h = None
+    for k in range(args.warmup):
+        h = step(k, h)
+    if h is not None:
+        h.wait()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    h = None
+    for k in range(args.steps):
+        h = step(k, h)
+    if h is not None:
+        h.wait()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    # ---- per-call latency distribution and the dominant kernel's duration (rank 0, untimed) ----
+    lat, lin_ms, sol_ms = [], [], []
+    if rank == 0:
+        solver.enable_timing(True)
+        n_lat = max(100, min(1000, args.steps * 4))
+        for k in range(n_lat):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            solver.solve(inp, outs[0])
+            e1.record()
+            e1.synchronize()
+            lat.append(e0.elapsed_time(e1))
+            a, b = solver.last_kernel_ms()
+            lin_ms.append(a)
+            sol_ms.append(b)
+        solver.enable_timing(False)
+        st = outs[0]["status"].cpu().numpy()
+        iters = outs[0]["iters"].cpu().numpy()
+    if world > 1:
+        dist.barrier()
+
+    if rank == 0:
+        value = world * B * args.steps / elapsed
+        sol_avg = float(np.mean(sol_ms))
+        achieved = ALGO_BYTES_PER_SOLVE * B / (sol_avg * 1e-3) / 1e9
+        res = {
+            "metric": "QP solves/sec (nx=6,nu=2,N=%d)" % N, "value": value, "unit": "solves/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "BARC tracking MPC, batch=%d random x0 per GPU, N=%d, fp64 (BASELINE configs[1])" % (B, N),
+                       "batch_per_gpu": B, "horizon": N, "result_gather": "rccl all_gather (async)" if gather else "none"},
+            "p50_solve_ms": float(np.percentile(lat, 50)), "p99_solve_ms": float(np.percentile(lat, 99)),
+            "latency_samples": len(lat),
+            "solved_fraction": float((st == 0).mean()), "mean_ipm_iters": float(iters.mean()),
+            "kernels_ms": {"linearize": float(np.mean(lin_ms)), "qp_solve": sol_avg},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "note": "algorithmic bytes 3696 B/solve x batch / lmpc_solve_kernel time; the kernel is "
+                                 "FP64-VALU/LDS-latency bound (DESIGN.md), HBM fraction is reported as required"},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            res["cpu_baseline"] = cpu_baseline(pkg, N, B)
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -123,7 +123,10 @@ def linearize_batch(cfg: MPCConfig, veh: Vehicle, inp: dict):
 def ss_query_batch(laps_x, L: float, S: int, K: int, query: np.ndarray):
     """laps_x: list of (n_j, 6) arrays oldest first; query (2, B)."""
     n_pts = np.array([a.shape[0] for a in laps_x], dtype=np.int32)
-    x = np.ascontiguousarray(np.concatenate([np.asarray(a, dtype=np.float64) for a in laps_x], axis=0))
+    x = (np.ascontiguousarray(np.concatenate([np.asarray(a, dtype=np.float64) for a in laps_x], axis=0))
+         if len(laps_x) else np.zeros((1, 6)))
+    if n_pts.size == 0:
+        n_pts = np.zeros(1, dtype=np.int32)
     query = _c(query)
     B = query.shape[1]
     ss_x = np.zeros((6, S, B))

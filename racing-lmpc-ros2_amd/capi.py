@@ -1,0 +1,250 @@
+"""ctypes binding of include/lmpc_hip.h (lib/liblmpc_hip.so).
+
+`Solver` mirrors the reference's RacingMPC surface for a whole batch: it is constructed from a
+config and a vehicle (RacingMPC::RacingMPC, racing_mpc.cpp:31-35) and `solve()` takes/returns the
+same keys as RacingMPC::solve's DMDict (racing_mpc.cpp:215-228, 347-353) with a trailing batch
+axis.  Tensors are torch CUDA (ROCm) fp64 tensors; only their device pointers cross the ABI.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+_HERE = Path(__file__).resolve().parent
+_LIB = None
+
+SOLVE_OPTIMAL, SOLVE_MAX_ITER, SOLVE_INFEASIBLE = 0, 1, 2
+
+_ABI_SYMBOLS = ("lmpc_create", "lmpc_destroy", "lmpc_last_error", "lmpc_set_stream", "lmpc_synchronize",
+                "lmpc_linearize_batch", "lmpc_solve_batch", "lmpc_set_safe_set", "lmpc_ss_query_batch",
+                "lmpc_prepare_batch", "lmpc_reserve", "lmpc_query_launch", "lmpc_enable_timing",
+                "lmpc_last_kernel_ms")
+
+
+class LmpcError(RuntimeError):
+    pass
+
+
+class CVehicle(C.Structure):
+    _fields_ = [("model_id", C.c_int32), ("reserved", C.c_int32)] + [
+        (n, C.c_double) for n in
+        ("m Jzz l cg_ratio h b fr kd kb cd Af rho cl_f cl_r mu Bf Cf Br Cr Fd_max Fb_max Td Tb "
+         "max_steer max_steer_rate").split()]
+
+
+class CConfig(C.Structure):
+    _fields_ = [("N", C.c_int32), ("learning", C.c_int32), ("num_ss_pts", C.c_int32),
+                ("num_ss_pts_per_lap", C.c_int32), ("max_lap_stored", C.c_int32),
+                ("max_iter", C.c_int32), ("tol", C.c_double), ("margin", C.c_double),
+                ("q_contour", C.c_double), ("q_heading", C.c_double), ("q_vel", C.c_double),
+                ("q_vy", C.c_double), ("q_vyaw", C.c_double), ("q_boundary", C.c_double),
+                ("R", C.c_double * 4), ("R_d", C.c_double * 4),
+                ("x_max", C.c_double * 6), ("x_min", C.c_double * 6),
+                ("u_max", C.c_double * 2), ("u_min", C.c_double * 2),
+                ("convex_hull_slack", C.c_double * 6), ("max_vel_ref_diff", C.c_double)]
+
+
+class CTrack(C.Structure):
+    _fields_ = [("L", C.c_double), ("M", C.c_int32), ("reserved", C.c_int32),
+                ("curvature", C.c_void_p), ("bound_left", C.c_void_p), ("bound_right", C.c_void_p),
+                ("vel", C.c_void_p)]
+
+
+def _fill(struct, values: dict):
+    for name, ctype in struct._fields_:
+        if name == "reserved":
+            continue
+        v = values[name]
+        if hasattr(ctype, "_length_"):
+            getattr(struct, name)[:] = [float(a) for a in v]
+        elif ctype is C.c_int32:
+            setattr(struct, name, int(v))
+        else:
+            setattr(struct, name, float(v))
+    return struct
+
+
+def library_path() -> Path:
+    return _HERE / "lib" / "liblmpc_hip.so"
+
+
+def load_library():
+    """Load liblmpc_hip.so.  Raises if it has not been built (no CPU fallback exists)."""
+    global _LIB
+    if _LIB is None:
+        so = library_path()
+        if not so.exists():
+            raise LmpcError(f"{so} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                            f"or `make -C {_HERE / 'csrc'}`")
+        lib = C.CDLL(str(so))
+        for sym in _ABI_SYMBOLS:
+            getattr(lib, sym)
+        lib.lmpc_last_error.restype = C.c_char_p
+        lib.lmpc_last_error.argtypes = [C.c_void_p]
+        lib.lmpc_destroy.restype = None
+        lib.lmpc_destroy.argtypes = [C.c_void_p]
+        _LIB = lib
+    return _LIB
+
+
+def _ptr(t):
+    if t is None:
+        return C.c_void_p(0)
+    return C.c_void_p(t.data_ptr())
+
+
+class Solver:
+    """Batched RacingMPC on one GPU.  Not re-entrant; one instance per device."""
+
+    def __init__(self, config: dict, vehicle: dict, device: int = 0):
+        import torch
+
+        self._torch = torch
+        self.lib = load_library()
+        self.config = dict(config)
+        self.N = int(config["N"])
+        self.device = torch.device("cuda", device)
+        self._h = C.c_void_p(0)
+        cc, cv = _fill(CConfig(), config), _fill(CVehicle(), vehicle)
+        rc = self.lib.lmpc_create(C.byref(cc), C.byref(cv), C.c_int(device), C.byref(self._h))
+        if rc != 0:
+            msg = self.lib.lmpc_last_error(self._h).decode() if self._h else "allocation failed"
+            if self._h:
+                self.lib.lmpc_destroy(self._h)
+                self._h = C.c_void_p(0)
+            raise LmpcError(f"lmpc_create -> {rc}: {msg}")
+        self._track_keepalive = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.lmpc_destroy(self._h)
+            self._h = C.c_void_p(0)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise LmpcError(f"{what} -> {rc}: {self.lib.lmpc_last_error(self._h).decode()}")
+
+    def _t(self, x):
+        torch = self._torch
+        t = torch.as_tensor(x, dtype=torch.float64, device=self.device)
+        return t.contiguous()
+
+    def use_current_stream(self):
+        """Queue launches on torch's current stream (so torch ops and events order with them)."""
+        s = self._torch.cuda.current_stream(self.device).cuda_stream
+        self._check(self.lib.lmpc_set_stream(self._h, C.c_void_p(s)), "lmpc_set_stream")
+
+    def synchronize(self):
+        self._check(self.lib.lmpc_synchronize(self._h), "lmpc_synchronize")
+
+    def reserve(self, max_batch: int):
+        self._check(self.lib.lmpc_reserve(self._h, C.c_int32(max_batch)), "lmpc_reserve")
+
+    def enable_timing(self, on: bool = True):
+        self._check(self.lib.lmpc_enable_timing(self._h, C.c_int32(int(on))), "lmpc_enable_timing")
+
+    def last_kernel_ms(self):
+        a, b = C.c_float(0), C.c_float(0)
+        self._check(self.lib.lmpc_last_kernel_ms(self._h, C.byref(a), C.byref(b)), "lmpc_last_kernel_ms")
+        return a.value, b.value
+
+    def launch_info(self):
+        a, b = C.c_int32(0), C.c_int32(0)
+        self._check(self.lib.lmpc_query_launch(self._h, C.byref(a), C.byref(b)), "lmpc_query_launch")
+        return {"lds_bytes_per_problem": a.value, "threads_per_problem": b.value}
+
+    # ---- input preparation (racing_mpc_node.cpp:210-235,261-292) ----
+    def prepare(self, track: dict, x_ic, dt: float, speed_scale: float = 1.0, speed_limit: float | None = None):
+        torch = self._torch
+        x_ic = self._t(x_ic)
+        B, N = x_ic.shape[1], self.N
+        tabs = {k: self._t(track[k]) for k in ("curvature", "bound_left", "bound_right", "vel")}
+        ct = CTrack(float(track["L"]), int(tabs["curvature"].numel()), 0, tabs["curvature"].data_ptr(),
+                    tabs["bound_left"].data_ptr(), tabs["bound_right"].data_ptr(), tabs["vel"].data_ptr())
+        if speed_limit is None:
+            speed_limit = float(self.config["x_max"][3])
+        kw = dict(dtype=torch.float64, device=self.device)
+        out = {"X_ref": torch.empty((6, N, B), **kw), "U_ref": torch.empty((2, N - 1, B), **kw),
+               "T_ref": torch.empty((N - 1, B), **kw), "bound_left": torch.empty((N, B), **kw),
+               "bound_right": torch.empty((N, B), **kw), "curvatures": torch.empty((N, B), **kw),
+               "vel_ref": torch.empty((N, B), **kw)}
+        rc = self.lib.lmpc_prepare_batch(self._h, C.c_int32(B), C.byref(ct), _ptr(x_ic), C.c_double(dt),
+                                         C.c_double(speed_scale), C.c_double(speed_limit),
+                                         *[_ptr(out[k]) for k in ("X_ref", "U_ref", "T_ref", "bound_left",
+                                                                  "bound_right", "curvatures", "vel_ref")])
+        self._check(rc, "lmpc_prepare_batch")
+        self._track_keepalive = tabs
+        out["x_ic"] = x_ic
+        out["L"] = float(track["L"])
+        return out
+
+    # ---- discrete_dynamics_jacobian (single_track_planar_model.cpp:377-387) ----
+    def linearize(self, inp: dict):
+        torch = self._torch
+        X, U, T, kap = (self._t(inp[k]) for k in ("X_ref", "U_ref", "T_ref", "curvatures"))
+        B, N = X.shape[2], self.N
+        kw = dict(dtype=torch.float64, device=self.device)
+        A = torch.empty((6, 6, N - 1, B), **kw)
+        Bm = torch.empty((6, 2, N - 1, B), **kw)
+        g = torch.empty((6, N - 1, B), **kw)
+        rc = self.lib.lmpc_linearize_batch(self._h, C.c_int32(B), _ptr(X), _ptr(U), _ptr(T), _ptr(kap), _ptr(A),
+                                           _ptr(Bm), _ptr(g))
+        self._check(rc, "lmpc_linearize_batch")
+        return A, Bm, g
+
+    # ---- RacingMPC::solve (racing_mpc.cpp:209-372) ----
+    def alloc_outputs(self, B: int):
+        torch = self._torch
+        N = self.N
+        kw = dict(dtype=torch.float64, device=self.device)
+        return {"X_optm": torch.empty((6, N, B), **kw), "U_optm": torch.empty((2, N - 1, B), **kw),
+                "dU_optm": torch.empty((2, N - 1, B), **kw),
+                "status": torch.empty((B,), dtype=torch.int32, device=self.device),
+                "iters": torch.empty((B,), dtype=torch.int32, device=self.device),
+                "kkt": torch.empty((4, B), **kw)}
+
+    def solve(self, inp: dict, out: dict | None = None, ss_x=None, ss_j=None):
+        keys = ("x_ic", "u_ic", "X_ref", "U_ref", "T_ref", "bound_left", "bound_right", "curvatures", "vel_ref")
+        a = [self._t(inp[k]) for k in keys]
+        B = a[0].shape[1]
+        if out is None:
+            out = self.alloc_outputs(B)
+        ss_x = None if ss_x is None else self._t(ss_x)
+        ss_j = None if ss_j is None else self._t(ss_j)
+        rc = self.lib.lmpc_solve_batch(self._h, C.c_int32(B), *[_ptr(t) for t in a], C.c_double(float(inp["L"])),
+                                       _ptr(ss_x), _ptr(ss_j), _ptr(out["X_optm"]), _ptr(out["U_optm"]),
+                                       _ptr(out["dU_optm"]), _ptr(out.get("convex_combi_optm")),
+                                       _ptr(out["status"]), _ptr(out["iters"]), _ptr(out.get("kkt")))
+        self._check(rc, "lmpc_solve_batch")
+        out["_inputs_keepalive"] = a
+        return out
+
+    # ---- safe set (safe_set.cpp:116-180) ----
+    def set_safe_set(self, laps_x, total_length: float):
+        import numpy as np
+
+        n_pts = np.array([np.asarray(a).shape[0] for a in laps_x], dtype=np.int32)
+        x = np.ascontiguousarray(np.concatenate([np.asarray(a, dtype=np.float64).reshape(-1, 6) for a in laps_x], 0)) \
+            if len(laps_x) else np.zeros((0, 6))
+        rc = self.lib.lmpc_set_safe_set(self._h, C.c_int32(len(laps_x)), n_pts.ctypes.data_as(C.c_void_p),
+                                        x.ctypes.data_as(C.c_void_p), C.c_double(total_length))
+        self._check(rc, "lmpc_set_safe_set")
+
+    def ss_query(self, query):
+        torch = self._torch
+        q = self._t(query)
+        B = q.shape[1]
+        S = int(self.config["num_ss_pts"])
+        kw = dict(dtype=torch.float64, device=self.device)
+        ss_x = torch.zeros((6, S, B), **kw)
+        ss_j = torch.zeros((S, B), **kw)
+        nf = torch.zeros((B,), dtype=torch.int32, device=self.device)
+        rc = self.lib.lmpc_ss_query_batch(self._h, C.c_int32(B), _ptr(q), _ptr(ss_x), _ptr(ss_j), _ptr(nf))
+        self._check(rc, "lmpc_ss_query_batch")
+        return ss_x, ss_j, nf

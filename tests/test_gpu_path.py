@@ -1,0 +1,157 @@
+"""Parity tests proper: the HIP path (through the C ABI) against the oracle.  Need an MI355X."""
+import numpy as np
+import pytest
+
+from conftest import scaled_err
+from oracle import cbind, dynamics as D, params as P, qp as Q, scenario as S
+from tolerances import TOL_DU, TOL_LINEARIZE_REL, TOL_MEDIAN, TOL_TWIN, TOL_XU
+
+pytestmark = pytest.mark.gpu
+
+PRESETS = {"barc20": ("barc_vehicle", "barc_tracking_mpc", 20, "barc"),
+           "barc10": ("barc_vehicle", "barc_tracking_mpc", 10, "barc"),
+           "iac40": ("iac_vehicle", "iac_tracking_mpc", 40, "putnam")}
+
+
+def make(pkg, key, B, seed):
+    vname, cname, N, kind = PRESETS[key]
+    veh, cfg = getattr(P, vname)(), getattr(P, cname)(N)
+    solver = pkg.Solver(getattr(pkg.presets, cname)(N), getattr(pkg.presets, vname)(), device=0)
+    tr = pkg.workloads.synthetic_track(kind)
+    u_lo, u_hi, _, _ = Q.effective_bounds(cfg, veh)
+    x, u = pkg.workloads.sample_initial_states(kind, B, tr["L"], u_lo, u_hi, seed)
+    return veh, cfg, solver, tr, x, u
+
+
+def to_np(out):
+    return {k: v.cpu().numpy() for k, v in out.items() if hasattr(v, "cpu")}
+
+
+@pytest.mark.parametrize("key", ["barc20", "iac40"])
+def test_linearize_matches_complex_step(pkg, key):
+    veh, cfg, solver, tr, x, u = make(pkg, key, 300, 11)
+    inp = S.cold_start_inputs(cfg, veh, tr, x, u, 0.025)
+    rng = np.random.default_rng(5)  # linearise about a non-trivial input reference too
+    inp["U_ref"] = inp["U_ref"] + rng.normal(0, 1.0, inp["U_ref"].shape) * np.array([0.004, 0.1])[:, None, None]
+    A, Bm, g = (t.cpu().numpy() for t in solver.linearize(inp))
+    N = cfg.N
+    Ar, Br, gr = D.rk4_jacobian_cs(inp["X_ref"][:, :N - 1].transpose(1, 2, 0), inp["U_ref"].transpose(1, 2, 0),
+                                   inp["curvatures"][:N - 1], inp["T_ref"], veh)
+    assert np.abs(A.transpose(2, 3, 0, 1) - Ar).max() <= TOL_LINEARIZE_REL * np.abs(Ar).max()
+    assert np.abs(Bm.transpose(2, 3, 0, 1) - Br).max() <= TOL_LINEARIZE_REL * np.abs(Br).max()
+    assert np.abs(g.transpose(1, 2, 0) - gr).max() <= 10 * TOL_LINEARIZE_REL * max(1.0, np.abs(gr).max())
+
+
+@pytest.mark.parametrize("key", ["barc20", "iac40"])
+def test_prepare_matches_node_cold_start(pkg, key):
+    veh, cfg, solver, tr, x, u = make(pkg, key, 257, 12)
+    ref = S.cold_start_inputs(cfg, veh, tr, x, u, 0.025, speed_scale=0.9)
+    got = solver.prepare(tr, x.T.copy(), 0.025, speed_scale=0.9)
+    for k in ("X_ref", "U_ref", "T_ref", "bound_left", "bound_right", "curvatures", "vel_ref"):
+        a, b = got[k].cpu().numpy(), ref[k]
+        assert a.shape == b.shape
+        assert np.abs(a - b).max() <= 1e-10 * max(1.0, np.abs(b).max()), k
+
+
+@pytest.mark.parametrize("name,key", [("qp_barc_tracking_n20", "barc20"), ("qp_barc_tracking_n10", "barc10"),
+                                      ("qp_iac_tracking_n40", "iac40")])
+def test_solve_matches_golden_and_twin(pkg, golden, name, key):
+    g = golden(name)
+    veh, cfg, solver, *_ = make(pkg, key, 1, 0)
+    out = to_np(solver.solve(g))
+    assert (out["status"] == 0).all(), out["status"]
+    ex = scaled_err(out["X_optm"], g["X_optm"], P.SCALE_X)
+    eu = scaled_err(out["U_optm"], g["U_optm"], P.SCALE_U)
+    ed = scaled_err(out["dU_optm"], g["dU_optm"], P.SCALE_U)
+    assert ex < TOL_XU and eu < TOL_XU and ed < TOL_DU, (ex, eu, ed)
+    twin = cbind.solve_batch(cfg, veh, g)
+    assert np.array_equal(out["iters"], twin["iters"]), (out["iters"], twin["iters"])
+    for k, sc in (("X_optm", P.SCALE_X), ("U_optm", P.SCALE_U), ("dU_optm", P.SCALE_U)):
+        assert scaled_err(out[k], twin[k], sc) < TOL_TWIN, k
+
+
+def test_solve_kkt_certificate_on_fresh_problems(pkg):
+    veh, cfg, solver, tr, x, u = make(pkg, "barc20", 48, 21)
+    inp = S.cold_start_inputs(cfg, veh, tr, x, u, 0.025)
+    out = to_np(solver.solve(inp))
+    assert (out["status"] == 0).all()
+    per = []
+    for b in range(48):
+        qp = Q.build_qp(cfg, veh, S.problem(inp, b))
+        y = Q.pack(qp, out["X_optm"][:, :, b], out["U_optm"][:, :, b], out["dU_optm"][:, :, b], sigma=out["kkt"][3, b])
+        yex, info = Q.solve_dense(qp)
+        assert info["status"] == 0
+        assert np.abs(qp.A @ y - qp.b).max() < 1e-9            # dynamics, rate and initial equalities
+        assert (qp.C @ y - qp.d).max() < 1e-8                  # every inequality row
+        assert qp.objective(y) - qp.objective(yex) < 1e-7 * (1 + abs(qp.objective(yex)))
+        o = qp.split(yex)
+        per.append(max(np.abs((out["X_optm"][:, :, b] - o["X_optm"]) / P.SCALE_X[:, None]).max(),
+                       np.abs((out["U_optm"][:, :, b] - o["U_optm"]) / P.SCALE_U[:, None]).max()))
+    assert max(per) < TOL_XU and np.median(per) < TOL_MEDIAN
+
+
+def test_full_batch_properties(pkg):
+    """BASELINE config 2 at full size (batch 4096, N = 20, fp64): size-independent properties."""
+    B = 4096
+    veh, cfg, solver, tr, x, u = make(pkg, "barc20", B, 0)
+    inp = solver.prepare(tr, x.T.copy(), 0.025)
+    inp["u_ic"] = u.T.copy()
+    out = solver.solve(inp)
+    o = to_np(out)
+    assert (o["status"] == 0).mean() > 0.998, np.bincount(o["status"])
+    ok = o["status"] == 0
+    A, Bm, g = (t.cpu().numpy() for t in solver.linearize(inp))
+    X, U, dU = o["X_optm"], o["U_optm"], o["dU_optm"]
+    # dynamics: x_{i+1} = A x_i + B u_i + g   (racing_mpc.cpp:186)
+    pred = np.einsum("rcib,cib->rib", A, X[:, :-1]) + np.einsum("rcib,cib->rib", Bm, U) + g
+    assert np.abs(pred - X[:, 1:])[:, :, ok].max() < 1e-8
+    # rate: u_{i-1} + dU_i t_i = u_i   (racing_mpc.cpp:190-196)
+    T = inp["T_ref"].cpu().numpy()
+    uprev = np.concatenate([u.T[:, None, :], U[:, :-1]], axis=1)
+    assert np.abs(uprev + dU * T - U)[:, :, ok].max() < 1e-10
+    assert np.abs(X[:, 0] - x.T).max() == 0.0
+    u_lo, u_hi, du_lo, du_hi = Q.effective_bounds(cfg, veh)
+    tol = 1e-8
+    assert (U[:, :, ok] <= u_hi[:, None, None] + tol).all() and (U[:, :, ok] >= u_lo[:, None, None] - tol).all()
+    assert (dU[:, :, ok] <= du_hi[:, None, None] + tol).all() and (dU[:, :, ok] >= du_lo[:, None, None] - tol).all()
+    assert (X[3:, 1:-1][:, :, ok] <= cfg.x_max[3:, None, None] + tol).all()
+    assert (X[3:, 1:-1][:, :, ok] >= cfg.x_min[3:, None, None] - tol).all()
+    sig = o["kkt"][3]
+    marg = cfg.margin + veh.b / 2
+    bl, br = inp["bound_left"].cpu().numpy(), inp["bound_right"].cpu().numpy()
+    assert (X[1][:, ok] <= (bl - marg + sig + tol)[:, ok]).all() and (X[1][:, ok] >= (br + marg - sig - tol)[:, ok]).all()
+    assert (sig[ok] >= -tol).all()
+    # a slice against the serial twin
+    sl = {k: (v.cpu().numpy() if hasattr(v, "cpu") else v) for k, v in inp.items()}
+    sub = {k: (v[..., :128] if isinstance(v, np.ndarray) else v) for k, v in sl.items()}
+    twin = cbind.solve_batch(cfg, veh, sub)
+    same = (twin["status"] == 0) & ok[:128]
+    assert np.array_equal(o["iters"][:128][same], twin["iters"][same])
+    assert np.abs((X[:, :, :128] - twin["X_optm"]) / P.SCALE_X[:, None, None])[:, :, same].max() < TOL_TWIN
+
+
+def test_infeasible_initial_state_and_determinism(pkg):
+    veh, cfg, solver, tr, x, u = make(pkg, "barc10", 64, 4)
+    x[5, 3] = 0.05  # vx below x_min[3] at knot 0 -> the reference's QP is infeasible
+    inp = S.cold_start_inputs(cfg, veh, tr, x, u, 0.025)
+    o1 = to_np(solver.solve(inp))
+    o2 = to_np(solver.solve(inp))
+    assert o1["status"][5] == 2 and (np.delete(o1["status"], 5) == 0).all()
+    for k in ("X_optm", "U_optm", "dU_optm"):
+        assert np.array_equal(o1[k], o2[k])  # bitwise repeatable
+
+
+def test_ss_query_matches_oracle(pkg):
+    from test_safe_set_oracle import load_laps
+    laps = load_laps()
+    L = 17.05
+    rng = np.random.default_rng(3)
+    q = np.stack([rng.uniform(-1.0, L + 1.0, 777), rng.uniform(-0.3, 0.3, 777)])
+    for n_laps in (3, 1):
+        solver = pkg.Solver(pkg.presets.barc_lmpc(20, n_laps), pkg.presets.barc_vehicle(), device=0)
+        solver.set_safe_set(laps, L)
+        ss_x, ss_j, nf = (t.cpu().numpy() for t in solver.ss_query(q))
+        rx, rj, rn = cbind.ss_query_batch(laps[-n_laps:], L, 32 * n_laps, 32, q)
+        assert np.array_equal(nf, rn)
+        assert np.array_equal(ss_x, rx)  # gathered values: bit exact
+        assert np.array_equal(ss_j, rj)

@@ -1,0 +1,72 @@
+"""Oracle checks for the QP: golden vectors carry KKT certificates; the C twin reproduces them (CPU)."""
+import numpy as np
+import pytest
+
+from conftest import scaled_err
+from oracle import cbind, params as P, qp as Q, scenario as S
+from tolerances import TOL_DU, TOL_MEDIAN, TOL_XU
+
+CASES = [("qp_barc_tracking_n20", P.barc_vehicle, lambda: P.barc_tracking_mpc(20)),
+         ("qp_barc_tracking_n10", P.barc_vehicle, lambda: P.barc_tracking_mpc(10)),
+         ("qp_iac_tracking_n40", P.iac_vehicle, lambda: P.iac_tracking_mpc(40))]
+
+
+@pytest.mark.parametrize("name,veh,cfg", CASES)
+def test_golden_solutions_are_certified_optima(golden, name, veh, cfg):
+    g = golden(name)
+    veh, cfg = veh(), cfg()
+    assert g["certified"].all()
+    stat, eq, ineq, comp = g["kkt_cert"]
+    assert stat.max() < 1e-9 and eq.max() < 1e-9 and ineq.max() < 1e-10 and comp.max() < 1e-9
+    # re-certify two problems from scratch: solver-independent NNLS multipliers on the rebuilt QP
+    for b in (0, g["x_ic"].shape[1] - 1):
+        qp = Q.build_qp(cfg, veh, S.problem(g, b))
+        y = Q.pack(qp, g["X_optm"][:, :, b], g["U_optm"][:, :, b], g["dU_optm"][:, :, b], sigma=g["sigma"][b])
+        c = Q.kkt_certificate(qp, y)
+        assert c["stat"] < 1e-8 and c["eq"] < 1e-9 and c["ineq"] < 1e-9 and c["comp"] < 1e-8, c
+        assert abs(qp.objective(y) - g["objective"][b]) < 1e-9 * (1 + abs(g["objective"][b]))
+
+
+@pytest.mark.parametrize("name,veh,cfg", CASES)
+def test_c_twin_matches_golden(golden, name, veh, cfg):
+    g = golden(name)
+    veh, cfg = veh(), cfg()
+    out = cbind.solve_batch(cfg, veh, g)
+    assert (out["status"] == 0).all(), out["status"]
+    assert out["iters"].max() <= 30
+    ex = scaled_err(out["X_optm"], g["X_optm"], P.SCALE_X)
+    eu = scaled_err(out["U_optm"], g["U_optm"], P.SCALE_U)
+    ed = scaled_err(out["dU_optm"], g["dU_optm"], P.SCALE_U)
+    assert ex < TOL_XU and eu < TOL_XU and ed < TOL_DU, (ex, eu, ed)
+    per = np.abs((out["X_optm"] - g["X_optm"]) / P.SCALE_X[:, None, None]).max(axis=(0, 1))
+    assert np.median(per) < TOL_MEDIAN
+    # the objective is reproduced far more tightly than the (flat-direction) variables
+    for b in range(0, g["x_ic"].shape[1], 5):
+        qp = Q.build_qp(cfg, veh, S.problem(g, b))
+        y = Q.pack(qp, out["X_optm"][:, :, b], out["U_optm"][:, :, b], out["dU_optm"][:, :, b], sigma=out["kkt"][3, b])
+        assert qp.objective(y) - g["objective"][b] < 1e-7 * (1 + abs(g["objective"][b]))
+        assert np.abs(qp.A @ y - qp.b).max() < 1e-9
+        assert (qp.C @ y - qp.d).max() < 1e-8
+
+
+def test_cold_start_inputs_layout(pkg):
+    veh, cfg = P.barc_vehicle(), P.barc_tracking_mpc(12)
+    tr = pkg.workloads.synthetic_track("barc")
+    u_lo, u_hi, _, _ = Q.effective_bounds(cfg, veh)
+    x, u = pkg.workloads.sample_initial_states("barc", 5, tr["L"], u_lo, u_hi, 0)
+    inp = S.cold_start_inputs(cfg, veh, tr, x, u, 0.025)
+    assert inp["X_ref"].shape == (6, 12, 5) and inp["U_ref"].shape == (2, 11, 5)
+    assert np.allclose(inp["X_ref"][:, 0, :], x.T)
+    assert np.all(np.abs(inp["vel_ref"] - inp["X_ref"][3]) <= cfg.max_vel_ref_diff + 1e-12)
+    assert np.all(inp["bound_left"] > 0) and np.all(inp["bound_right"] < 0)
+
+
+def test_infeasible_initial_state_is_reported():
+    veh, cfg = P.barc_vehicle(), P.barc_tracking_mpc(10)
+    from __graft_entry__ import load_package
+    wl = load_package().workloads
+    tr = wl.synthetic_track("barc")
+    x = np.array([[1.0, 0.0, 0.0, 0.05, 0.0, 0.0], [1.0, 0.0, 0.0, 1.0, 0.0, 0.0]])  # vx < x_min[3] = 0.1
+    inp = S.cold_start_inputs(cfg, veh, tr, x, np.zeros((2, 2)), 0.025)
+    out = cbind.solve_batch(cfg, veh, inp)
+    assert out["status"][0] == 2 and out["status"][1] == 0
