@@ -87,7 +87,6 @@ def main():
     pkg = load_package()
     N, B = args.horizon, args.batch
     solver = pkg.Solver(pkg.presets.barc_tracking_mpc(N), pkg.presets.barc_vehicle(), device=local)
-    solver.use_current_stream()
     solver.reserve(B)
     tr = pkg.workloads.synthetic_track("barc")
     P = solver.config

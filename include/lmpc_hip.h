@@ -13,8 +13,9 @@
  *     kept on the handle (lmpc_last_error).
  *   - All `*_batch` array arguments are DEVICE pointers (HBM) unless a parameter is
  *     documented as host.  The caller owns every buffer; the library owns only the
- *     handle (constants, the safe-set copy, a stream).  No allocation happens inside
- *     the `*_batch` calls.
+ *     handle (constants, the safe-set copy, a linearisation workspace).  Launches go to
+ *     the stream set by lmpc_set_stream.  After lmpc_reserve(max_batch) no `*_batch` call
+ *     with batch <= max_batch allocates.
  *   - Batched layout is struct-of-arrays with the batch axis fastest:
  *         field[component][knot][batch]   ->   ((c * n_knots) + i) * batch + b
  *     so a wavefront's loads along the batch axis coalesce.
@@ -121,10 +122,12 @@ typedef struct lmpc_handle lmpc_handle;
 /* Builds the parametric problem once, as RacingMPC::RacingMPC does
  * (racing_mpc.cpp:31-202).  `device` is the HIP device ordinal. */
 int lmpc_create(const lmpc_config* cfg, const lmpc_vehicle* veh, int device, lmpc_handle** out);
+/* On failure *out may still be non-NULL so that lmpc_last_error(*out) can be read; destroy it. */
 void lmpc_destroy(lmpc_handle* h);
 const char* lmpc_last_error(const lmpc_handle* h);
 
-/* Run subsequent launches on `hip_stream` (a hipStream_t; NULL restores the handle's own). */
+/* Run subsequent launches on `hip_stream` (a hipStream_t).  A new handle uses the device's
+ * default (null) stream; NULL selects it again. */
 int lmpc_set_stream(lmpc_handle* h, void* hip_stream);
 /* Block until everything queued on the handle's stream has finished. */
 int lmpc_synchronize(lmpc_handle* h);

@@ -136,9 +136,12 @@ class Solver:
         return t.contiguous()
 
     def use_current_stream(self):
-        """Queue launches on torch's current stream (so torch ops and events order with them)."""
+        """Queue launches on torch's current stream, so that torch copies, ops and events order
+        with the kernels.  Called by every method below before it launches."""
         s = self._torch.cuda.current_stream(self.device).cuda_stream
-        self._check(self.lib.lmpc_set_stream(self._h, C.c_void_p(s)), "lmpc_set_stream")
+        if s != getattr(self, "_stream", None):
+            self._check(self.lib.lmpc_set_stream(self._h, C.c_void_p(s)), "lmpc_set_stream")
+            self._stream = s
 
     def synchronize(self):
         self._check(self.lib.lmpc_synchronize(self._h), "lmpc_synchronize")
@@ -162,6 +165,7 @@ class Solver:
     # ---- input preparation (racing_mpc_node.cpp:210-235,261-292) ----
     def prepare(self, track: dict, x_ic, dt: float, speed_scale: float = 1.0, speed_limit: float | None = None):
         torch = self._torch
+        self.use_current_stream()
         x_ic = self._t(x_ic)
         B, N = x_ic.shape[1], self.N
         tabs = {k: self._t(track[k]) for k in ("curvature", "bound_left", "bound_right", "vel")}
@@ -187,6 +191,7 @@ class Solver:
     # ---- discrete_dynamics_jacobian (single_track_planar_model.cpp:377-387) ----
     def linearize(self, inp: dict):
         torch = self._torch
+        self.use_current_stream()
         X, U, T, kap = (self._t(inp[k]) for k in ("X_ref", "U_ref", "T_ref", "curvatures"))
         B, N = X.shape[2], self.N
         kw = dict(dtype=torch.float64, device=self.device)
@@ -210,6 +215,7 @@ class Solver:
                 "kkt": torch.empty((4, B), **kw)}
 
     def solve(self, inp: dict, out: dict | None = None, ss_x=None, ss_j=None):
+        self.use_current_stream()
         keys = ("x_ic", "u_ic", "X_ref", "U_ref", "T_ref", "bound_left", "bound_right", "curvatures", "vel_ref")
         a = [self._t(inp[k]) for k in keys]
         B = a[0].shape[1]
@@ -238,6 +244,7 @@ class Solver:
 
     def ss_query(self, query):
         torch = self._torch
+        self.use_current_stream()
         q = self._t(query)
         B = q.shape[1]
         S = int(self.config["num_ss_pts"])

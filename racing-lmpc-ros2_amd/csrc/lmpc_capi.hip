@@ -31,8 +31,7 @@ struct lmpc_handle {
   lmpc_params P;
   lmpc_config cfg;
   int device = 0;
-  hipStream_t own_stream = nullptr;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;  // nullptr = the device's default (null) stream
   double* ws = nullptr;  // [cap][N-1][LMPC_LIN_RECORD]
   size_t ws_cap = 0;
   // safe set (device): laps newest-first offsets
@@ -139,8 +138,6 @@ int lmpc_create(const lmpc_config* cfg, const lmpc_vehicle* veh, int device, lmp
   if (!(P.Sv[0] > 0.0) || !(P.Sv[0] * P.Sv[3] - P.Sv[1] * P.Sv[2] > 0.0))
     return fail(h, LMPC_ERR_ARGUMENT, "R_d must be positive definite");
   HIP_TRY(h, hipSetDevice(device));
-  HIP_TRY(h, hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
-  h->stream = h->own_stream;
   for (auto& e : h->ev) HIP_TRY(h, hipEventCreate(&e));
   return LMPC_OK;
 }
@@ -148,14 +145,13 @@ int lmpc_create(const lmpc_config* cfg, const lmpc_vehicle* veh, int device, lmp
 void lmpc_destroy(lmpc_handle* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
-  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  (void)hipStreamSynchronize(h->stream);
   if (h->ws) (void)hipFree(h->ws);
   if (h->ss_npts) (void)hipFree(h->ss_npts);
   if (h->ss_off) (void)hipFree(h->ss_off);
   if (h->ss_x) (void)hipFree(h->ss_x);
   for (auto& e : h->ev)
     if (e) (void)hipEventDestroy(e);
-  if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   delete h;
 }
 
@@ -163,7 +159,7 @@ const char* lmpc_last_error(const lmpc_handle* h) { return h ? h->err.c_str() : 
 
 int lmpc_set_stream(lmpc_handle* h, void* hip_stream) {
   if (!h) return LMPC_ERR_ARGUMENT;
-  h->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : h->own_stream;
+  h->stream = reinterpret_cast<hipStream_t>(hip_stream);
   return LMPC_OK;
 }
 
