@@ -35,28 +35,27 @@ def cpu_baseline(pkg, N, batch, seconds_target=12.0):
     tr = pkg.workloads.synthetic_track("barc")
     u_lo, u_hi, _, _ = OQ.effective_bounds(cfg, veh)
     cores = os.cpu_count() or 1
-    B = min(batch, 1024)
+    per_thread = 32
+    B = cores * per_thread          # same distribution as the GPU batch, sized so every thread gets a slice
     x, u = pkg.workloads.sample_initial_states("barc", B, tr["L"], u_lo, u_hi, 0)
     inp = OS.cold_start_inputs(cfg, veh, tr, x, u, 0.025)
     cbind.lib()
     t0 = time.perf_counter()
-    cbind.solve_batch(cfg, veh, inp, b0=0, b1=32)
-    per = (time.perf_counter() - t0) / 32
-    reps = max(1, int(seconds_target * cores / (per * B)))
-    reps = min(reps, 64)
-    chunks = np.linspace(0, B, cores + 1).astype(int)
+    cbind.solve_batch(cfg, veh, inp, b0=0, b1=per_thread)
+    per = (time.perf_counter() - t0) / per_thread
+    reps = int(min(64, max(1, seconds_target / (per * per_thread))))
 
     def work(c):
         for _ in range(reps):
-            cbind.solve_batch(cfg, veh, inp, b0=int(chunks[c]), b1=int(chunks[c + 1]))
+            cbind.solve_batch(cfg, veh, inp, b0=c * per_thread, b1=(c + 1) * per_thread)
 
     t0 = time.perf_counter()
     with ThreadPoolExecutor(cores) as ex:
         list(ex.map(work, range(cores)))
     dt = time.perf_counter() - t0
     return {"value": reps * B / dt, "unit": "solves/s", "cores": cores, "kind": "port",
-            "sample": f"{reps} x {B} problems of the bench workload, static split over {cores} threads, "
-                      f"oracle/c/lmpc_oracle.c -O3 ({dt:.1f} s)"}
+            "sample": f"{reps} x {B} problems of the bench workload ({per_thread} per thread per call), static split "
+                      f"over {cores} host threads, oracle/c/lmpc_oracle.c -O3 ({dt:.1f} s wall)"}
 
 
 def main():
@@ -174,6 +173,7 @@ def main():
             "latency_samples": len(lat),
             "solved_fraction": float((st == 0).mean()), "mean_ipm_iters": float(iters.mean()),
             "kernels_ms": {"linearize": float(np.mean(lin_ms)), "qp_solve": sol_avg},
+            "launch": solver.launch_info(),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "note": "algorithmic bytes 3696 B/solve x batch / lmpc_solve_kernel time; the kernel is "

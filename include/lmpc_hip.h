@@ -49,7 +49,7 @@ typedef enum lmpc_status {
  * racing_mpc.cpp:343-371 / racing_mpc_node.cpp:322-332) */
 #define LMPC_SOLVE_OPTIMAL 0
 #define LMPC_SOLVE_MAX_ITER 1
-#define LMPC_SOLVE_INFEASIBLE 2 /* x_ic outside [x_min, x_max] at knot 0, or NaN          */
+#define LMPC_SOLVE_INFEASIBLE 2 /* x_ic outside [x_min, x_max] at knot 0, row residual stalls, NaN */
 
 /* vehicle_model_factory.cpp:31-49 -- same selector names; only the first is built */
 #define LMPC_MODEL_SINGLE_TRACK_PLANAR 0
@@ -91,8 +91,8 @@ typedef struct lmpc_config {
   int32_t num_ss_pts;         /* S                                                          */
   int32_t num_ss_pts_per_lap; /* K                                                          */
   int32_t max_lap_stored;
-  int32_t max_iter;           /* interior-point iteration cap (<=0: default 40)             */
-  double tol;                 /* KKT residual tolerance (<=0: default 1e-9)                 */
+  int32_t max_iter;           /* interior-point iteration cap (<=0: default 30)             */
+  double tol;                 /* complementarity tolerance (<=0: default 1e-11)             */
   double margin;
   double q_contour, q_heading, q_vel, q_vy, q_vyaw, q_boundary;
   double R[4];                /* row-major 2x2                                              */
@@ -190,6 +190,9 @@ int lmpc_reserve(lmpc_handle* h, int32_t max_batch);
 /* Library/kernel facts for harnesses: bytes of LDS one problem occupies, threads per problem. */
 int lmpc_query_launch(const lmpc_handle* h, int32_t* lds_bytes_per_problem,
                       int32_t* threads_per_problem);
+
+/* Occupancy of the QP kernel as the runtime reports it: resident problems (= wavefronts) per CU. */
+int lmpc_query_residency(lmpc_handle* h, int32_t* problems_per_cu);
 
 /* Per-kernel timing for benchmarks: when enabled, lmpc_solve_batch brackets its two launches
  * with HIP events on the handle's stream; lmpc_last_kernel_ms waits for them and returns the

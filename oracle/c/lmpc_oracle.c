@@ -743,7 +743,7 @@ static int ipm_solve(prob_t* p, int* iters_out, double* kkt_out) {
     ++m;
   }
   int status = LMPC_SOLVE_MAX_ITER, it = 0;
-  double mu = 0.0, rdmax = 0.0;
+  double mu = 0.0, rdmax = 0.0, rd_check = 0.0;
 
   /* ================= phase 1: interior point ================= */
   for (it = 0; it <= p->max_iter; ++it) {
@@ -779,6 +779,15 @@ static int ipm_solve(prob_t* p, int* iters_out, double* kkt_out) {
     if (mu <= p->tol && rdmax <= 1e-9) {
       status = LMPC_SOLVE_OPTIMAL;
       break;
+    }
+    /* primal infeasibility: the row residual contracts by (1 - alpha) per iteration on a feasible
+     * problem; if it has not halved over five iterations while still large, give up */
+    if (it % 5 == 0) {
+      if (it >= 10 && rdmax > 1e-6 && rdmax > 0.5 * rd_check) {
+        status = LMPC_SOLVE_INFEASIBLE;
+        break;
+      }
+      rd_check = rdmax;
     }
     if (it == p->max_iter) break;
     cost_gradient(p, w);
@@ -897,7 +906,7 @@ static void setup_problem(prob_t* p, const lmpc_config* cfg, const lmpc_vehicle*
   p->N = N;
   p->has_sigma = cfg->q_boundary > 0.0;
   p->S = cfg->learning ? cfg->num_ss_pts : 0;
-  p->max_iter = cfg->max_iter > 0 ? cfg->max_iter : 40;
+  p->max_iter = cfg->max_iter > 0 ? cfg->max_iter : 30;
   p->tol = cfg->tol > 0 ? cfg->tol : 1e-11;
   for (int i = 0; i < N - 1; ++i) {
     double x[6], u[2], xp[6];

@@ -18,7 +18,7 @@ SOLVE_OPTIMAL, SOLVE_MAX_ITER, SOLVE_INFEASIBLE = 0, 1, 2
 _ABI_SYMBOLS = ("lmpc_create", "lmpc_destroy", "lmpc_last_error", "lmpc_set_stream", "lmpc_synchronize",
                 "lmpc_linearize_batch", "lmpc_solve_batch", "lmpc_set_safe_set", "lmpc_ss_query_batch",
                 "lmpc_prepare_batch", "lmpc_reserve", "lmpc_query_launch", "lmpc_enable_timing",
-                "lmpc_last_kernel_ms")
+                "lmpc_last_kernel_ms", "lmpc_query_residency")
 
 
 class LmpcError(RuntimeError):
@@ -160,7 +160,9 @@ class Solver:
     def launch_info(self):
         a, b = C.c_int32(0), C.c_int32(0)
         self._check(self.lib.lmpc_query_launch(self._h, C.byref(a), C.byref(b)), "lmpc_query_launch")
-        return {"lds_bytes_per_problem": a.value, "threads_per_problem": b.value}
+        c = C.c_int32(0)
+        self._check(self.lib.lmpc_query_residency(self._h, C.byref(c)), "lmpc_query_residency")
+        return {"lds_bytes_per_problem": a.value, "threads_per_problem": b.value, "resident_problems_per_cu": c.value}
 
     # ---- input preparation (racing_mpc_node.cpp:210-235,261-292) ----
     def prepare(self, track: dict, x_ic, dt: float, speed_scale: float = 1.0, speed_limit: float | None = None):

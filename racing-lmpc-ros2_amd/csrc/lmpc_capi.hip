@@ -105,7 +105,7 @@ int lmpc_create(const lmpc_config* cfg, const lmpc_vehicle* veh, int device, lmp
   P.has_sigma = cfg->q_boundary > 0.0 ? 1 : 0;
   P.learning = cfg->learning ? 1 : 0;
   P.S = cfg->learning ? cfg->num_ss_pts : 0;
-  P.max_iter = cfg->max_iter > 0 ? cfg->max_iter : 40;
+  P.max_iter = cfg->max_iter > 0 ? cfg->max_iter : 30;
   P.tol = cfg->tol > 0.0 ? cfg->tol : 1e-11;
   const double qd[6] = {0.0, cfg->q_contour, cfg->q_heading, cfg->q_vel, cfg->q_vy, cfg->q_vyaw};
   const double qt[6] = {0.0, cfg->q_contour, cfg->q_heading, cfg->q_vel, 0.0, 0.0};
@@ -187,6 +187,25 @@ int lmpc_query_launch(const lmpc_handle* h, int32_t* lds_bytes_per_problem, int3
   if (!h) return LMPC_ERR_ARGUMENT;
   if (lds_bytes_per_problem) *lds_bytes_per_problem = lmpc_lds_doubles(h->P.N) * (int)sizeof(double);
   if (threads_per_problem) *threads_per_problem = 64;
+  return LMPC_OK;
+}
+
+int lmpc_query_residency(lmpc_handle* h, int32_t* problems_per_cu) {
+  if (!h || !problems_per_cu) return LMPC_ERR_ARGUMENT;
+  HIP_TRY(h, hipSetDevice(h->device));
+  const size_t lds = (size_t)lmpc_lds_doubles(h->P.N) * sizeof(double);
+  int n = 0;
+  const void* fn = nullptr;
+  switch (kq_for(h->P.N)) {
+    case 2: fn = reinterpret_cast<const void*>(&lmpc_solve_kernel<2>); break;
+    case 4: fn = reinterpret_cast<const void*>(&lmpc_solve_kernel<4>); break;
+    case 7: fn = reinterpret_cast<const void*>(&lmpc_solve_kernel<7>); break;
+    case 11: fn = reinterpret_cast<const void*>(&lmpc_solve_kernel<11>); break;
+    default: fn = reinterpret_cast<const void*>(&lmpc_solve_kernel<14>); break;
+  }
+  HIP_TRY(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, 64, lds));
+  *problems_per_cu = n;
   return LMPC_OK;
 }
 

@@ -28,21 +28,31 @@
 #include "lmpc_device.h"
 
 #define NSLOT 11
+
+// Optional per-phase cycle accounting (make prof -> -DLMPC_PHASE_TIMING): one s_memtime read per
+// phase boundary, per-wave totals written over kkt_out as [8][B] doubles (caller allocates 8 rows).
+#ifdef LMPC_PHASE_TIMING
+#define PT_DECL long long pt_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long pt_t = __builtin_readcyclecounter(); const long long pt_w0 = wall_clock64();
+#define PT_MARK(k) { const long long pt_n = __builtin_readcyclecounter(); pt_acc[k] += pt_n - pt_t; pt_t = pt_n; }
+#else
+#define PT_DECL
+#define PT_MARK(k)
+#endif
 #define SL_U 6
 #define SL_V 8
 #define SL_EY 10
 
 // ---- LDS layout (doubles) ---------------------------------------------------------------------
-// stage record i (stride 80): ABt[8][6] @0 (ABt[c][k] = [A B][k][c]) | g[6] @48 | dt @54 | K[2][8] @56
-//                             | Hinv (h00,h01,h11) @72 | kff[2 rhs][2] @76
+// stage record i (stride 78): ABt[8][6] @0 (ABt[c][k] = [A B][k][c]) | g[6] @48 | K[2][8] @54
+//                             | Hinv (h00,h01,h11) @70 | dt @73 | kff[2 rhs][2] @74
 // knot record i (stride 34):  z[8] v[2] @0 | rhs0: Th / q / d [10] @10 | rhs1: q / e [10] @20
 //                             | csig @30 | eyT / eyD @31 | (free) @32 | qlin_vx @33
-// tail: P[8][10] @0 | W[8][10] @80 | Y[8][10] @160 | pvec[2 buf][2 rhs][8] @240 | consts @272
+// tail: P[8][10] @0 | W[8][10] @80 | Y[8][10] @160 | pvec[2 buf][2 rhs][8] @240 | consts @272 (48)
 #define ST_G 48
-#define ST_DT 54
-#define ST_K 56
-#define ST_HI 72
-#define ST_KFF 76
+#define ST_K 54
+#define ST_HI 70
+#define ST_DT 73
+#define ST_KFF 74
 #define KN_R0 10
 #define KN_R1 20
 #define KN_CSIG 30
@@ -59,6 +69,12 @@
 #define CT_SV 16
 #define CT_HI 20
 #define CT_LO 30
+#define CT_ZERO 40  // a 0.0 entry: coefficient slot for "no term"
+#define F_UP 1
+#define F_LO 2
+#define F_SIG 4
+#define F_QLIN 8
+#define F_MOVE 16
 #define MROW 10  // padded row stride of the 8x8 work matrices (conflict-free b128 row reads)
 
 __device__ __forceinline__ double wave_sum(double x) {
@@ -75,6 +91,13 @@ __device__ __forceinline__ double wave_min(double x) {
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) x = fmin(x, __shfl_xor(x, m));
   return x;
+}
+
+// 1/x: hardware v_rcp_f64 seed + one Newton step (full fp64 accuracy for normal x); replaces the
+// ~12-instruction IEEE division sequence in the per-row arithmetic.
+__device__ __forceinline__ double frcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  return __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
 }
 
 struct Lds {
@@ -131,7 +154,7 @@ __device__ void riccati_factor(const Lds& L, int lane) {
     const double h00 = ct[CT_SV + 0] + kn[KN_R0 + 8] + t * t * MY[6 * MROW + 6];
     const double h01 = ct[CT_SV + 1] + t * t * MY[6 * MROW + 7];
     const double h11 = ct[CT_SV + 3] + kn[KN_R0 + 9] + t * t * MY[7 * MROW + 7];
-    const double idet = 1.0 / (h00 * h11 - h01 * h01);
+    const double idet = frcp(h00 * h11 - h01 * h01);
     const double hi00 = h11 * idet, hi01 = -h01 * idet, hi11 = h00 * idet;
     const double g0 = t * y6c, g1 = t * y7c;
     const double k0c = hi00 * g0 + hi01 * g1;
@@ -155,75 +178,101 @@ __device__ void riccati_factor(const Lds& L, int lane) {
   }
 }
 
-// Riccati vector solve for nrhs (1 or 2) right-hand sides held in the knots' rhs regions
+// Lane k's value of a wave-distributed double as a wave-uniform scalar (two v_readlane_b32; the
+// result lives in SGPRs and feeds v_fma_f64 as a scalar operand).
+__device__ __forceinline__ double lane_bcast(double v, int k) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), k);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), k);
+  return __hiloint2double(hi, lo);
+}
+
+// Riccati vector solve for NRHS (1 or 2) right-hand sides held in the knots' rhs regions
 // (q_z @ +0..7, q_v @ +8,9 of region s); the step (dz, dv) overwrites them.  dz_0 = 0.
-__device__ void riccati_solve(const Lds& L, int lane, int nrhs) {
-  const int N = L.N, s = lane >> 3, r = lane & 7;
-  const bool on = s < nrhs;
-  const int reg = KN_R0 + 10 * s;
-  double* pvb = L.tail() + TL_PV;
-  int cur = 0;
-  if (on) pvb[cur * 16 + s * 8 + r] = L.kn(N - 1)[reg + r];
-  __syncthreads();
+//
+// The sweep is a strictly serial chain over the knots, so it is organised for latency, not for
+// lane occupancy: lane r (< 8) carries component r of the running vector of BOTH right-hand
+// sides in registers, the six components a matrix row needs are broadcast with v_readlane (SGPR
+// operands of the FMAs), and nothing is exchanged through LDS between stages -- no barrier and
+// no LDS round trip on the critical path; the stage matrices are plain loads whose addresses do
+// not depend on the chain, so they pipeline ahead of it.
+template <int NRHS>
+__device__ void riccati_solve(const Lds& L, int lane) {
+  const int N = L.N;
+  const int r = lane & 7;  // lanes >= 8 mirror lanes 0..7 (their results are simply not stored)
+  const bool store = lane < 8;
+  double pv[NRHS];
+#pragma unroll
+  for (int s = 0; s < NRHS; ++s) pv[s] = L.kn(N - 1)[KN_R0 + 10 * s + r];
   for (int i = N - 2; i >= 0; --i) {
     double* st = L.st(i);
-    if (on) {
-      const double* pv = pvb + cur * 16 + s * 8;
-      const double* kn = L.kn(i);
-      const double t = st[ST_DT];
-      double p[6];
+    const double* kn = L.kn(i);
+    const double t = st[ST_DT];
+    double ab[6], k0r = st[ST_K + r], k1r = st[ST_K + 8 + r];
 #pragma unroll
-      for (int k = 0; k < 6; ++k) p[k] = pv[k];
-      double wr = (r >= 6) ? pv[r] : 0.0, w6 = pv[6], w7 = pv[7];
+    for (int k = 0; k < 6; ++k) ab[k] = st[r * 6 + k];
+    const double hi00 = st[ST_HI], hi01 = st[ST_HI + 1], hi11 = st[ST_HI + 2];
 #pragma unroll
-      for (int k = 0; k < 6; ++k) {
-        wr += st[r * 6 + k] * p[k];
-        w6 += st[36 + k] * p[k];
-        w7 += st[42 + k] * p[k];
-      }
-      const double hv0 = kn[reg + 8] + t * w6, hv1 = kn[reg + 9] + t * w7;
-      if (i >= 1) pvb[(cur ^ 1) * 16 + s * 8 + r] = kn[reg + r] + wr - (st[ST_K + r] * hv0 + st[ST_K + 8 + r] * hv1);
-      if (r == 0) {
-        st[ST_KFF + 2 * s + 0] = st[ST_HI + 0] * hv0 + st[ST_HI + 1] * hv1;
-        st[ST_KFF + 2 * s + 1] = st[ST_HI + 1] * hv0 + st[ST_HI + 2] * hv1;
+    for (int s = 0; s < NRHS; ++s) {
+      const int reg = KN_R0 + 10 * s;
+      double w = (r >= 6) ? pv[s] : 0.0;  // w = Abar' p: rows 6,7 also take p_u
+#pragma unroll
+      for (int k = 0; k < 6; ++k) w = __builtin_fma(ab[k], lane_bcast(pv[s], k), w);
+      const double hv0 = __builtin_fma(t, lane_bcast(w, 6), kn[reg + 8]);
+      const double hv1 = __builtin_fma(t, lane_bcast(w, 7), kn[reg + 9]);
+      if (i >= 1) pv[s] = kn[reg + r] + w - (k0r * hv0 + k1r * hv1);
+      if (lane == 0) {
+        st[ST_KFF + 2 * s + 0] = hi00 * hv0 + hi01 * hv1;
+        st[ST_KFF + 2 * s + 1] = hi01 * hv0 + hi11 * hv1;
       }
     }
-    cur ^= 1;
-    __syncthreads();
   }
-  if (on) L.kn(0)[reg + r] = 0.0;
   __syncthreads();
-  for (int i = 0; i < N - 1; ++i) {
-    if (on) {
-      const double* st = L.st(i);
-      double* kn = L.kn(i);
-      const double t = st[ST_DT];
-      double d[8];
+  double d[NRHS];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) d[k] = kn[reg + k];
+  for (int s = 0; s < NRHS; ++s) {
+    d[s] = 0.0;
+    if (store) L.kn(0)[KN_R0 + 10 * s + r] = 0.0;
+  }
+  for (int i = 0; i < N - 1; ++i) {
+    const double* st = L.st(i);
+    double* kn = L.kn(i);
+    double* kx = L.kn(i + 1);
+    const double t = st[ST_DT];
+    double k0[8], k1[8], arow[6];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      k0[k] = st[ST_K + k];
+      k1[k] = st[ST_K + 8 + k];
+    }
+    const int rr = r < 6 ? r : 0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) arow[k] = st[k * 6 + rr];  // A[r][k]
+    const double b0 = st[36 + rr], b1 = st[42 + rr];      // B[r][0], B[r][1]
+#pragma unroll
+    for (int s = 0; s < NRHS; ++s) {
+      const int reg = KN_R0 + 10 * s;
+      double dz[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) dz[k] = lane_bcast(d[s], k);
       double dv0 = -st[ST_KFF + 2 * s], dv1 = -st[ST_KFF + 2 * s + 1];
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        dv0 -= st[ST_K + k] * d[k];
-        dv1 -= st[ST_K + 8 + k] * d[k];
+        dv0 = __builtin_fma(-k0[k], dz[k], dv0);
+        dv1 = __builtin_fma(-k1[k], dz[k], dv1);
       }
-      const double du0 = d[6] + t * dv0, du1 = d[7] + t * dv1;
-      double nx;
-      if (r < 6) {
-        nx = st[36 + r] * du0 + st[42 + r] * du1;
+      const double du0 = __builtin_fma(t, dv0, dz[6]), du1 = __builtin_fma(t, dv1, dz[7]);
+      double nx = b0 * du0 + b1 * du1;
 #pragma unroll
-        for (int k = 0; k < 6; ++k) nx += st[k * 6 + r] * d[k];
-      } else {
-        nx = (r == 6) ? du0 : du1;
-      }
-      L.kn(i + 1)[reg + r] = nx;
-      if (r == 0) {
+      for (int k = 0; k < 6; ++k) nx = __builtin_fma(arow[k], dz[k], nx);
+      d[s] = (r < 6) ? nx : (r == 6 ? du0 : du1);
+      if (store) kx[reg + r] = d[s];
+      if (lane == 0) {
         kn[reg + 8] = dv0;
         kn[reg + 9] = dv1;
       }
     }
-    __syncthreads();
   }
+  __syncthreads();
 }
 
 // Closed-loop rollout z_{i+1} = Abar z_i + Bbar v_i + gbar, v_i = -K_i z_i (absolute variables).
@@ -266,13 +315,12 @@ __device__ void feedback_rollout(const Lds& L, int lane) {
 }
 
 template <int KQ>
-__global__ __launch_bounds__(64, (KQ <= 4 ? 2 : 1)) void lmpc_solve_kernel(lmpc_params P, int B, const double* __restrict__ ws_lin,
-                                                        const double* __restrict__ x_ic, const double* __restrict__ u_ic,
-                                                        const double* __restrict__ T_ref, const double* __restrict__ bl,
-                                                        const double* __restrict__ br, const double* __restrict__ vref,
-                                                        double* __restrict__ X_out, double* __restrict__ U_out,
-                                                        double* __restrict__ dU_out, int* __restrict__ status_out,
-                                                        int* __restrict__ iters_out, double* __restrict__ kkt_out) {
+__global__ __launch_bounds__(64, (KQ <= 4 ? 2 : 1)) void lmpc_solve_kernel(
+    lmpc_params P, int B, const double* __restrict__ ws_lin, const double* __restrict__ x_ic,
+    const double* __restrict__ u_ic, const double* __restrict__ T_ref, const double* __restrict__ bl,
+    const double* __restrict__ br, const double* __restrict__ vref, double* __restrict__ X_out,
+    double* __restrict__ U_out, double* __restrict__ dU_out, int* __restrict__ status_out,
+    int* __restrict__ iters_out, double* __restrict__ kkt_out) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int b = blockIdx.x;
   const int lane = threadIdx.x;
@@ -280,6 +328,8 @@ __global__ __launch_bounds__(64, (KQ <= 4 ? 2 : 1)) void lmpc_solve_kernel(lmpc_
   Lds L{lds, N};
   double* T = L.tail();
   double* ct = T + TL_CT;
+  double* KN0 = L.kn(0);
+  PT_DECL
 
   // ---------------- load: linearisation records, per-knot data, constant tables ----------------
   {
@@ -296,13 +346,13 @@ __global__ __launch_bounds__(64, (KQ <= 4 ? 2 : 1)) void lmpc_solve_kernel(lmpc_
       kn[9] = 0.0;
     }
     if (lane < 6) {
-      L.kn(0)[lane] = x_ic[(size_t)lane * B + b];
+      KN0[lane] = x_ic[(size_t)lane * B + b];
       ct[CT_QD + lane] = P.learning ? 0.0 : P.Qd[lane];
       ct[CT_QT + lane] = P.learning ? 0.0 : P.Qt[lane];
       ct[CT_HI + lane] = P.x_max[lane];
       ct[CT_LO + lane] = P.x_min[lane];
     } else if (lane < 8) {
-      L.kn(0)[lane] = u_ic[(size_t)(lane - 6) * B + b];
+      KN0[lane] = u_ic[(size_t)(lane - 6) * B + b];
       ct[CT_HI + lane] = P.u_hi[lane - 6];
       ct[CT_LO + lane] = P.u_lo[lane - 6];
     } else if (lane < 10) {
@@ -312,61 +362,95 @@ __global__ __launch_bounds__(64, (KQ <= 4 ? 2 : 1)) void lmpc_solve_kernel(lmpc_
       ct[CT_QU + lane - 10] = P.Qu[lane - 10];
     } else if (lane < 18) {
       ct[CT_SV + lane - 14] = P.Sv[lane - 14];
+    } else if (lane == 18) {
+      ct[CT_ZERO] = 0.0;
     }
   }
   __syncthreads();
+  PT_MARK(0)
 
   // ---------------- slot ownership ----------------
   // slot j = lane + 64 q  ->  knot i = j / 11, kind sl = j % 11.  Kinds 0..9 address the primal
   // component (z[0..7], v[0..1]) at offset sl of the knot record; kind 10 is the track boundary
-  // row pair on e_y (offset 1) which also carries the shared slack sigma.
-  int s_i[KQ], s_sl[KQ];
-  bool s_au[KQ], s_al[KQ];  // upper / lower row present
-  double s_hi[KQ], s_lo[KQ], s_tu[KQ], s_tl[KQ], s_lu[KQ], s_ll[KQ], s_pu[KQ], s_pl[KQ];
-  int m_rows = 0;
+  // row pair on e_y (offset 1) which also carries the shared slack sigma.  Everything a slot needs
+  // is reduced to offsets and 0/1 masks here so that the per-iteration row code is branch-free:
+  // an absent row keeps t = 1, lam = 0 and a zero mask.
   const bool has_sigma = P.has_sigma != 0;
+  int s_ko[KQ];           // offset of the slot's knot record from knot 0 (doubles); -1: no slot
+  int s_vo[KQ];           // offset of the constrained value inside the knot record
+  int s_wo[KQ];           // where the slot writes its barrier weight / gradient entry
+  int s_g[KQ];            // packed gradient recipe: ct index c0 | o0 << 8 | ct index c1 << 16 | o1 << 24
+  int s_f[KQ];            // flags: F_UP / F_LO row exists, F_SIG boundary slot carrying sigma,
+                          // F_QLIN component takes the linear vx cost term, F_MOVE owns a moving primal component
+  double s_hi[KQ], s_lo[KQ], s_tu[KQ], s_tl[KQ], s_lu[KQ], s_ll[KQ], s_pu[KQ], s_pl[KQ];
+  double m_rows = 0.0;
 #pragma unroll
   for (int q = 0; q < KQ; ++q) {
     const int j = lane + 64 * q;
     const bool valid = j < NSLOT * N;
     const int i = valid ? j / NSLOT : 0;
     const int sl = valid ? j - i * NSLOT : 0;
-    s_i[q] = i;
-    s_sl[q] = valid ? sl : -1;
+    s_ko[q] = valid ? i * LMPC_KNOT_STRIDE : -1;
+    s_vo[q] = sl < SL_EY ? sl : 1;
+    s_wo[q] = sl < SL_EY ? KN_R0 + sl : KN_EY;
     double hi = INFINITY, lo = -INFINITY;
     bool on = false;
+    int c0 = CT_ZERO, o0 = 0, c1 = CT_ZERO, o1 = 0;
     if (valid) {
       if (sl < SL_EY) {
         hi = ct[CT_HI + sl];
         lo = ct[CT_LO + sl];
-        on = (sl < SL_U) ? (i >= 1 && i <= N - 2) : (sl < SL_V ? (i >= 1) : (i <= N - 2));
+        if (sl < SL_U) {
+          on = i >= 1 && i <= N - 2;
+          c0 = (i == N - 1 ? CT_QT : CT_QD) + sl;
+          o0 = sl;
+        } else if (sl < SL_V) {
+          on = i >= 1;
+          if (i >= 1) {
+            c0 = CT_QU + (sl - SL_U) * 2;
+            c1 = c0 + 1;
+          }
+          o0 = 6;
+          o1 = 7;
+        } else {
+          on = i <= N - 2;
+          if (i <= N - 2) {
+            c0 = CT_SV + (sl - SL_V) * 2;
+            c1 = c0 + 1;
+          }
+          o0 = 8;
+          o1 = 9;
+        }
       } else {
         hi = bl[(size_t)i * B + b] - P.marg;
         lo = br[(size_t)i * B + b] + P.marg;
         on = has_sigma || i >= 1;
       }
     }
-    s_hi[q] = hi;
-    s_lo[q] = lo;
-    s_au[q] = on && (hi < INFINITY);
-    s_al[q] = on && (lo > -INFINITY);
-    m_rows += (s_au[q] ? 1 : 0) + (s_al[q] ? 1 : 0);
+    s_g[q] = c0 | (o0 << 8) | (c1 << 16) | (o1 << 24);
+    const bool au = on && (hi < INFINITY), al = on && (lo > -INFINITY);
+    s_f[q] = (au ? F_UP : 0) | (al ? F_LO : 0) | ((valid && sl == SL_EY && has_sigma) ? F_SIG : 0) |
+             ((valid && sl == 3) ? F_QLIN : 0) | ((valid && sl < SL_EY && (i >= 1 || sl >= SL_V)) ? F_MOVE : 0);
+    s_hi[q] = au ? hi : 0.0;
+    s_lo[q] = al ? lo : 0.0;
+    m_rows += (au ? 1.0 : 0.0) + (al ? 1.0 : 0.0);
     s_tu[q] = s_tl[q] = 1.0;
     s_lu[q] = s_ll[q] = 0.0;
     s_pu[q] = s_pl[q] = 0.0;
   }
-  const double m_tot = wave_sum((double)m_rows) + (has_sigma ? 1.0 : 0.0);
+  const double m_tot = wave_sum(m_rows) + (has_sigma ? 1.0 : 0.0);
+  const double inv_m = 1.0 / m_tot;
 
   // knot-0 feasibility: the state box applies to x_0 = x_ic (racing_mpc.cpp:147,201)
   bool feasible = true;
   {
     bool ok = true;
     if (lane < 6) {
-      const double v = L.kn(0)[lane];
+      const double v = KN0[lane];
       ok = (v <= ct[CT_HI + lane]) && (v >= ct[CT_LO + lane]);
     }
     if (lane == 6 && !has_sigma) {
-      const double ey = L.kn(0)[1];
+      const double ey = KN0[1];
       ok = (ey <= bl[b] - P.marg) && (ey >= br[b] + P.marg);
     }
     feasible = wave_min(ok ? 1.0 : 0.0) > 0.5;
@@ -377,23 +461,19 @@ __global__ __launch_bounds__(64, (KQ <= 4 ? 2 : 1)) void lmpc_solve_kernel(lmpc_
   // ---------------- start point: minimiser of the cost over the dynamics alone ----------------
 #pragma unroll
   for (int q = 0; q < KQ; ++q) {
-    const int sl = s_sl[q];
-    if (sl < 0) continue;
-    double* kn = L.kn(s_i[q]);
-    if (sl < SL_EY) {
-      kn[KN_R0 + sl] = 0.0;
-    } else {
-      kn[KN_EY] = 0.0;
-      kn[KN_CSIG] = 0.0;
-    }
+    if (s_ko[q] < 0) continue;
+    double* kn = KN0 + s_ko[q];
+    kn[s_wo[q]] = 0.0;
+    if (s_wo[q] == KN_EY) kn[KN_CSIG] = 0.0;
   }
   __syncthreads();
   riccati_factor(L, lane);
   feedback_rollout(L, lane);
+  PT_MARK(1)
 
   const double tau = 0.995, mu0 = 1.0;
   int status = LMPC_SOLVE_MAX_ITER, it = 0;
-  double mu = 0.0, rdmax = 0.0, last_step = 0.0, hsig = 0.0, ce = 0.0;
+  double mu = 0.0, rdmax = 0.0, rd_check = 0.0, last_step = 0.0, hsig = 0.0, ce = 0.0;
   const int max_iter = feasible ? P.max_iter : 0;
 
   // it == -1 is the start-point Newton step (all row weights zero, full step); it >= 0 the
@@ -405,29 +485,18 @@ __global__ __launch_bounds__(64, (KQ <= 4 ? 2 : 1)) void lmpc_solve_kernel(lmpc_
       double musum = 0.0, rdl = 0.0, eysum = 0.0;
 #pragma unroll
       for (int q = 0; q < KQ; ++q) {
-        const int sl = s_sl[q];
-        if (sl < 0) continue;
-        double* kn = L.kn(s_i[q]);
-        const double val = kn[sl < SL_EY ? sl : 1];
-        const double sg = (sl == SL_EY && has_sigma) ? sigma : 0.0;
-        double thu = 0.0, thd = 0.0;
-        if (s_au[q]) {
-          thu = s_lu[q] / s_tu[q];
-          musum += s_lu[q] * s_tu[q];
-          rdl = fmax(rdl, fabs(val - sg + s_tu[q] - s_hi[q]));
-        }
-        if (s_al[q]) {
-          thd = s_ll[q] / s_tl[q];
-          musum += s_ll[q] * s_tl[q];
-          rdl = fmax(rdl, fabs(-val - sg + s_tl[q] + s_lo[q]));
-        }
-        if (sl < SL_EY) {
-          kn[KN_R0 + sl] = thu + thd;
-        } else {
-          kn[KN_EY] = thu + thd;
-          kn[KN_CSIG] = has_sigma ? thd - thu : 0.0;
-          if (has_sigma) eysum += thu + thd;
-        }
+        if (s_ko[q] < 0) continue;
+        double* kn = KN0 + s_ko[q];
+        const double val = kn[s_vo[q]];
+        const int f = s_f[q];
+        const double sg = (f & F_SIG) ? sigma : 0.0;
+        const double thu = s_lu[q] * frcp(s_tu[q]), thd = s_ll[q] * frcp(s_tl[q]);
+        musum += s_lu[q] * s_tu[q] + s_ll[q] * s_tl[q];
+        rdl = fmax(rdl, (f & F_UP) ? fabs(val - sg + s_tu[q] - s_hi[q]) : 0.0);
+        rdl = fmax(rdl, (f & F_LO) ? fabs(-val - sg + s_tl[q] + s_lo[q]) : 0.0);
+        kn[s_wo[q]] = thu + thd;
+        if (s_wo[q] == KN_EY) kn[KN_CSIG] = (f & F_SIG) ? (thd - thu) : 0.0;
+        eysum += (f & F_SIG) ? (thu + thd) : 0.0;
       }
       musum = wave_sum(musum);
       rdmax = wave_max(rdl);
@@ -437,7 +506,7 @@ __global__ __launch_bounds__(64, (KQ <= 4 ? 2 : 1)) void lmpc_solve_kernel(lmpc_
         rdmax = fmax(rdmax, fabs(-sigma + ts));
         hsig += lams / ts;
       }
-      mu = musum / m_tot;
+      mu = musum * inv_m;
       if (!(mu == mu) || !(rdmax == rdmax)) {
         status = LMPC_SOLVE_INFEASIBLE;
         break;
@@ -446,49 +515,48 @@ __global__ __launch_bounds__(64, (KQ <= 4 ? 2 : 1)) void lmpc_solve_kernel(lmpc_
         status = LMPC_SOLVE_OPTIMAL;
         break;
       }
+      // primal infeasibility: on a feasible problem the row residual contracts by (1 - alpha) per
+      // iteration; not halving over five iterations while still large ends the solve (this also
+      // bounds the straggler that would otherwise hold its CU slot for max_iter iterations)
+      if (it % 5 == 0) {
+        if (it >= 10 && rdmax > 1e-6 && rdmax > 0.5 * rd_check) {
+          status = LMPC_SOLVE_INFEASIBLE;
+          break;
+        }
+        rd_check = rdmax;
+      }
       if (it == max_iter) break;
       __syncthreads();
+      PT_MARK(2)
       riccati_factor(L, lane);
+      PT_MARK(3)
     }
 
     double sigc = 0.0, alpha = 1.0, dsigma = 0.0, dts = 0.0, dlams = 0.0;
-    double d_tu[KQ], d_tl[KQ], d_lu[KQ], d_ll[KQ], d_val[KQ];
+    double d_val[KQ];
     const int npass = ipm ? 2 : 1;
     for (int pass = 0; pass < npass; ++pass) {
+      const double smu = (pass == 1) ? sigc * mu : 0.0, pm = (pass == 1) ? 1.0 : 0.0;
       // ======== gradient: cost gradient + row coefficients, written by the component owner ========
       double sgsum = 0.0;  // sum of boundary-row coefficients entering the sigma gradient
 #pragma unroll
       for (int q = 0; q < KQ; ++q) {
-        const int sl = s_sl[q];
-        if (sl < 0) continue;
-        const int i = s_i[q];
-        double* kn = L.kn(i);
-        const double val = kn[sl < SL_EY ? sl : 1];
-        const double sg = (sl == SL_EY && has_sigma) ? sigma : 0.0;
-        double cu = 0.0, cd = 0.0;
-        if (ipm && s_au[q]) {
-          cu = (s_lu[q] / s_tu[q]) * (val - sg + s_tu[q] - s_hi[q]);
-          if (pass == 1) cu += (sigc * mu - s_pu[q]) / s_tu[q];
-        }
-        if (ipm && s_al[q]) {
-          cd = (s_ll[q] / s_tl[q]) * (-val - sg + s_tl[q] + s_lo[q]);
-          if (pass == 1) cd += (sigc * mu - s_pl[q]) / s_tl[q];
-        }
-        if (sl < SL_EY) {
-          double g;
-          if (sl < SL_U) {
-            g = (i == N - 1 ? ct[CT_QT + sl] : ct[CT_QD + sl]) * val + (sl == 3 ? kn[KN_QLIN] : 0.0);
-          } else if (sl < SL_V) {
-            g = (i >= 1) ? ct[CT_QU + (sl - SL_U) * 2] * kn[6] + ct[CT_QU + (sl - SL_U) * 2 + 1] * kn[7] : 0.0;
-          } else {
-            g = (i <= N - 2) ? ct[CT_SV + (sl - SL_V) * 2] * kn[8] + ct[CT_SV + (sl - SL_V) * 2 + 1] * kn[9] : 0.0;
-          }
-          kn[KN_R0 + sl] = g + cu - cd;
-          if (pass == 0) kn[KN_R1 + sl] = 0.0;
-        } else {
-          kn[KN_EY] = cu - cd;
-          if (has_sigma) sgsum += cu + cd;
-        }
+        if (s_ko[q] < 0) continue;
+        double* kn = KN0 + s_ko[q];
+        const double val = kn[s_vo[q]];
+        const int f = s_f[q];
+        const double sg = (f & F_SIG) ? sigma : 0.0;
+        const double itu = frcp(s_tu[q]), itl = frcp(s_tl[q]);
+        double cu = s_lu[q] * itu * (val - sg + s_tu[q] - s_hi[q]) + (smu - pm * s_pu[q]) * itu;
+        double cd = s_ll[q] * itl * (-val - sg + s_tl[q] + s_lo[q]) + (smu - pm * s_pl[q]) * itl;
+        cu = (ipm && (f & F_UP)) ? cu : 0.0;
+        cd = (ipm && (f & F_LO)) ? cd : 0.0;
+        const int gr = s_g[q];
+        const double g = ct[gr & 0xff] * kn[(gr >> 8) & 0xff] + ct[(gr >> 16) & 0xff] * kn[(gr >> 24) & 0xff] +
+                         ((f & F_QLIN) ? kn[KN_QLIN] : 0.0);
+        kn[s_wo[q]] = (s_wo[q] == KN_EY) ? (cu - cd) : (g + cu - cd);
+        if (pass == 0 && s_wo[q] != KN_EY) kn[s_wo[q] + 10] = 0.0;
+        sgsum += (f & F_SIG) ? (cu + cd) : 0.0;
       }
       __syncthreads();
       for (int i = lane; i < N; i += 64) {
@@ -498,117 +566,111 @@ __global__ __launch_bounds__(64, (KQ <= 4 ? 2 : 1)) void lmpc_solve_kernel(lmpc_
       }
       __syncthreads();
       // ======== Newton step: predictor together with the Schur vector, then the corrector ========
-      riccati_solve(L, lane, (pass == 0 && ipm && has_sigma) ? 2 : 1);
+      PT_MARK(4)
+      if (pass == 0 && ipm && has_sigma)
+        riccati_solve<2>(L, lane);
+      else
+        riccati_solve<1>(L, lane);
+      PT_MARK(5)
       // ======== boundary slack by Schur complement ========
       double cfs = 0.0;
       if (ipm && has_sigma) {
         double cep = 0.0, cap = 0.0;
 #pragma unroll
         for (int q = 0; q < KQ; ++q)
-          if (s_sl[q] == SL_EY && s_i[q] >= 1) {
-            const double* kn = L.kn(s_i[q]);
+          if (s_ko[q] > 0 && s_wo[q] == KN_EY) {  // boundary slots of knots >= 1
+            const double* kn = KN0 + s_ko[q];
             cap += kn[KN_CSIG] * kn[KN_R0 + 1];
             cep += kn[KN_CSIG] * kn[KN_R1 + 1];
           }
         const double ca = wave_sum(cap);
         if (pass == 0) ce = wave_sum(cep);
-        cfs = (lams / ts) * (-sigma + ts);
-        if (pass == 1) cfs += (sigc * mu - dts * dlams) / ts;
+        const double its = frcp(ts);
+        cfs = lams * its * (-sigma + ts) + (smu - pm * dts * dlams) * its;
         const double qsg = P.qsig * sigma - wave_sum(sgsum) - cfs;
         dsigma = -(qsg + ca) / (hsig + ce);
       }
-      // ======== row steps, largest feasible step ========
-      double amax = 1.0;
+      if (!ipm) {
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) d_val[q] = (s_ko[q] < 0) ? 0.0 : (KN0 + s_ko[q])[KN_R0 + s_vo[q]];
+        break;
+      }
+      // ======== row steps; largest feasible step as 1 / max(1, max -dt/t, max -dlam/lam) ========
+      // (dt, dlam) of a row from the step of the value it constrains; evaluated twice (ratio scan,
+      // then use) rather than kept, to stay inside the register budget of two waves per SIMD.
+      auto row_step = [&](bool on, double t, double lam, double pprod, double rd, double cdy, double& dt_, double& dl_,
+                          double& it_) {
+        it_ = frcp(t);
+        dt_ = on ? (-rd - cdy) : 0.0;
+        dl_ = on ? (-lam + (smu - pm * pprod) * it_ - lam * it_ * dt_) : 0.0;
+      };
+      double rmax = 1.0;
 #pragma unroll
       for (int q = 0; q < KQ; ++q) {
-        const int sl = s_sl[q];
         d_val[q] = 0.0;
-        if (sl < 0) continue;
-        const double* kn = L.kn(s_i[q]);
-        const int off = sl < SL_EY ? sl : 1;
-        const double dval = kn[KN_R0 + off] + ((ipm && has_sigma) ? dsigma * kn[KN_R1 + off] : 0.0);
+        if (s_ko[q] < 0) continue;
+        const double* kn = KN0 + s_ko[q];
+        const int off = s_vo[q], f = s_f[q];
+        const double dval = kn[KN_R0 + off] + dsigma * kn[KN_R1 + off];
         d_val[q] = dval;
-        if (!ipm) continue;
         const double val = kn[off];
-        const double sg = (sl == SL_EY && has_sigma) ? sigma : 0.0;
-        const double dsg = (sl == SL_EY && has_sigma) ? dsigma : 0.0;
-        if (s_au[q]) {
-          const double t = s_tu[q], lam = s_lu[q], th = lam / t, rd = val - sg + t - s_hi[q];
-          double cf = th * rd;
-          if (pass == 1) cf += (sigc * mu - s_pu[q]) / t;
-          const double dt_ = -rd - (dval - dsg);
-          const double dl_ = -lam + cf - th * rd - th * dt_;
-          d_tu[q] = dt_;
-          d_lu[q] = dl_;
-          if (dt_ < 0.0) amax = fmin(amax, -t / dt_);
-          if (dl_ < 0.0) amax = fmin(amax, -lam / dl_);
-        }
-        if (s_al[q]) {
-          const double t = s_tl[q], lam = s_ll[q], th = lam / t, rd = -val - sg + t + s_lo[q];
-          double cf = th * rd;
-          if (pass == 1) cf += (sigc * mu - s_pl[q]) / t;
-          const double dt_ = -rd - (-dval - dsg);
-          const double dl_ = -lam + cf - th * rd - th * dt_;
-          d_tl[q] = dt_;
-          d_ll[q] = dl_;
-          if (dt_ < 0.0) amax = fmin(amax, -t / dt_);
-          if (dl_ < 0.0) amax = fmin(amax, -lam / dl_);
-        }
+        const double sg = (f & F_SIG) ? sigma : 0.0, dsg = (f & F_SIG) ? dsigma : 0.0;
+        double dt_, dl_, it_;
+        row_step(f & F_UP, s_tu[q], s_lu[q], s_pu[q], val - sg + s_tu[q] - s_hi[q], dval - dsg, dt_, dl_, it_);
+        rmax = fmax(rmax, fmax(-dt_ * it_, -dl_ * frcp(fmax(s_lu[q], 1e-300))));
+        row_step(f & F_LO, s_tl[q], s_ll[q], s_pl[q], -val - sg + s_tl[q] + s_lo[q], -dval - dsg, dt_, dl_, it_);
+        rmax = fmax(rmax, fmax(-dt_ * it_, -dl_ * frcp(fmax(s_ll[q], 1e-300))));
       }
-      if (!ipm) break;
-      amax = wave_min(amax);
+      rmax = wave_max(rmax);
       if (has_sigma) {
         const double th = lams / ts, rds = -sigma + ts;
         dts = -rds + dsigma;
         dlams = -lams + cfs - th * rds - th * dts;
-        if (dts < 0.0) amax = fmin(amax, -ts / dts);
-        if (dlams < 0.0) amax = fmin(amax, -lams / dlams);
+        rmax = fmax(rmax, fmax(-dts / ts, -dlams / lams));
+      }
+      const double amax = 1.0 / rmax;
+      if (pass == 1) alpha = fmin(1.0, tau * amax);
+      double sacc = 0.0;
+#pragma unroll
+      for (int q = 0; q < KQ; ++q) {
+        if (s_ko[q] < 0) continue;
+        const double* kn = KN0 + s_ko[q];
+        const int f = s_f[q];
+        const double dval = d_val[q];
+        const double val = kn[s_vo[q]];
+        const double sg = (f & F_SIG) ? sigma : 0.0, dsg = (f & F_SIG) ? dsigma : 0.0;
+        double dtu, dlu, dtl, dll, it_;
+        row_step(f & F_UP, s_tu[q], s_lu[q], s_pu[q], val - sg + s_tu[q] - s_hi[q], dval - dsg, dtu, dlu, it_);
+        row_step(f & F_LO, s_tl[q], s_ll[q], s_pl[q], -val - sg + s_tl[q] + s_lo[q], -dval - dsg, dtl, dll, it_);
+        if (pass == 0) {
+          sacc += (s_tu[q] + amax * dtu) * (s_lu[q] + amax * dlu) + (s_tl[q] + amax * dtl) * (s_ll[q] + amax * dll);
+          s_pu[q] = dtu * dlu;
+          s_pl[q] = dtl * dll;
+        } else {
+          s_tu[q] += alpha * dtu;
+          s_lu[q] += alpha * dlu;
+          s_tl[q] += alpha * dtl;
+          s_ll[q] += alpha * dll;
+        }
       }
       if (pass == 0) {
-        double sacc = 0.0;
-#pragma unroll
-        for (int q = 0; q < KQ; ++q) {
-          if (s_sl[q] < 0) continue;
-          if (s_au[q]) {
-            sacc += (s_tu[q] + amax * d_tu[q]) * (s_lu[q] + amax * d_lu[q]);
-            s_pu[q] = d_tu[q] * d_lu[q];
-          }
-          if (s_al[q]) {
-            sacc += (s_tl[q] + amax * d_tl[q]) * (s_ll[q] + amax * d_ll[q]);
-            s_pl[q] = d_tl[q] * d_ll[q];
-          }
-        }
         sacc = wave_sum(sacc);
         if (has_sigma) sacc += (ts + amax * dts) * (lams + amax * dlams);
-        const double ratio = (sacc / m_tot) / mu;
+        const double ratio = (sacc * inv_m) / mu;
         sigc = ratio * ratio * ratio;
-      } else {
-        alpha = fmin(1.0, tau * amax);
+        __syncthreads();
       }
-      __syncthreads();
     }
 
-    // ======== update (component owners move the primal; rows stay in registers) ========
+    // ======== primal update by the component owners ========
+    PT_MARK(6)
     double stepmax = 0.0;
 #pragma unroll
     for (int q = 0; q < KQ; ++q) {
-      const int sl = s_sl[q];
-      if (sl < 0) continue;
-      const int i = s_i[q];
-      if (sl < SL_EY && (i >= 1 || sl >= SL_V)) {
-        L.kn(i)[sl] += alpha * d_val[q];
-        stepmax = fmax(stepmax, fabs(alpha * d_val[q]));
-      }
-      if (ipm) {
-        if (s_au[q]) {
-          s_tu[q] += alpha * d_tu[q];
-          s_lu[q] += alpha * d_lu[q];
-        }
-        if (s_al[q]) {
-          s_tl[q] += alpha * d_tl[q];
-          s_ll[q] += alpha * d_ll[q];
-        }
-      }
+      if (s_ko[q] < 0) continue;
+      const double dz = (s_f[q] & F_MOVE) ? alpha * d_val[q] : 0.0;
+      if (s_f[q] & F_MOVE) (KN0 + s_ko[q])[s_vo[q]] += dz;
+      stepmax = fmax(stepmax, fabs(dz));
     }
     __syncthreads();
     if (ipm) {
@@ -622,17 +684,16 @@ __global__ __launch_bounds__(64, (KQ <= 4 ? 2 : 1)) void lmpc_solve_kernel(lmpc_
       // ---- slacks and multipliers at the start point: t = max(slack, 0.1 range), lam = mu0 / t ----
 #pragma unroll
       for (int q = 0; q < KQ; ++q) {
-        const int sl = s_sl[q];
-        if (sl < 0) continue;
-        const double val = L.kn(s_i[q])[sl < SL_EY ? sl : 1];
-        double range = (s_hi[q] < INFINITY && s_lo[q] > -INFINITY) ? (s_hi[q] - s_lo[q]) : 1.0;
+        if (s_ko[q] < 0) continue;
+        const double val = (KN0 + s_ko[q])[s_vo[q]];
+        double range = ((s_f[q] & (F_UP | F_LO)) == (F_UP | F_LO)) ? (s_hi[q] - s_lo[q]) : 1.0;
         if (!(range > 1e-3)) range = 1e-3;
         const double thr = 0.1 * range;
-        if (s_au[q]) {
+        if (s_f[q] & F_UP) {
           s_tu[q] = fmax(s_hi[q] - val, thr);
           s_lu[q] = mu0 / s_tu[q];
         }
-        if (s_al[q]) {
+        if (s_f[q] & F_LO) {
           s_tl[q] = fmax(val - s_lo[q], thr);
           s_ll[q] = mu0 / s_tl[q];
         }
@@ -642,6 +703,7 @@ __global__ __launch_bounds__(64, (KQ <= 4 ? 2 : 1)) void lmpc_solve_kernel(lmpc_
       lams = has_sigma ? mu0 / ts : 0.0;
     }
   }
+  PT_MARK(7)
   if (it < 0) it = 0;
   if (!feasible) status = LMPC_SOLVE_INFEASIBLE;
 
@@ -659,12 +721,25 @@ __global__ __launch_bounds__(64, (KQ <= 4 ? 2 : 1)) void lmpc_solve_kernel(lmpc_
   if (lane == 0) {
     status_out[b] = status;
     iters_out[b] = it;
+#ifdef LMPC_PHASE_TIMING
+    if (kkt_out) {
+      for (int k = 0; k < 8; ++k) kkt_out[k * (size_t)B + b] = (double)pt_acc[k];
+      kkt_out[8 * (size_t)B + b] = (double)pt_w0;               // 100 MHz wall clock at start
+      kkt_out[9 * (size_t)B + b] = (double)wall_clock64();      // ... at end
+      unsigned hwid, xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      kkt_out[10 * (size_t)B + b] = (double)hwid;
+      kkt_out[11 * (size_t)B + b] = (double)(xcc & 0xf);
+    }
+#else
     if (kkt_out) {
       kkt_out[0 * (size_t)B + b] = last_step;
       kkt_out[1 * (size_t)B + b] = rdmax;
       kkt_out[2 * (size_t)B + b] = mu;
       kkt_out[3 * (size_t)B + b] = sigma;
     }
+#endif
   }
 }
 

@@ -10,11 +10,12 @@ polished, KKT-certified optimum:
 The worst case is set by the plain Riccati recursion's conditioning late in the iteration
 ("numerics"); the dense oracle itself is accurate to ~1e-12.
 HIP kernel vs its serial C twin (identical algorithm; FMA contraction and summation order
-differ, and the ill-conditioned late iterations amplify that): same bound as against the
-optimum (1e-4), iteration counts equal on >= 90 % of problems and never more than 1 apart.
+differ, and the ill-conditioned late iterations amplify that): twice the bound against the
+optimum (each twin may be 1e-4 off on its own), iteration counts equal on >= 90 % of problems
+and never more than 1 apart.
 """
 TOL_XU = 1e-4
 TOL_DU = 2e-3
 TOL_MEDIAN = 1e-7
-TOL_TWIN = 1e-4
+TOL_TWIN = 2e-4
 TOL_LINEARIZE_REL = 1e-11
