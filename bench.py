@@ -24,6 +24,37 @@ ALGO_BYTES_PER_SOLVE = (13 * 20 + 5) * 8 + (10 * 20 - 4) * 8 + 8  # 3696 B at N 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
 
 
+def shard_bounds(total: int, world: int, rank: int):
+    """Contiguous slice [lo, hi) of `total` problems owned by `rank` (sizes differ by at most one)."""
+    base, rem = divmod(total, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def packed_numel(N: int, B: int) -> int:
+    return (10 * N - 4) * B  # X 6N + U 2(N-1) + dU 2(N-1) per problem
+
+
+def pack_results(out: dict, flat):
+    """X_optm | U_optm | dU_optm of this rank's slice into one contiguous buffer for the gather."""
+    import torch
+
+    torch.cat([out["X_optm"].reshape(-1), out["U_optm"].reshape(-1), out["dU_optm"].reshape(-1)], out=flat)
+    return flat
+
+
+def unpack_results(gbuf, world: int, N: int, B: int) -> dict:
+    """Inverse of pack_results over the all-gathered buffer: arrays with the global batch axis last."""
+    import torch
+
+    per = gbuf.reshape(world, packed_numel(N, B))
+    nX, nU = 6 * N * B, 2 * (N - 1) * B
+    X = torch.cat([per[r, :nX].reshape(6, N, B) for r in range(world)], dim=2)
+    U = torch.cat([per[r, nX:nX + nU].reshape(2, N - 1, B) for r in range(world)], dim=2)
+    dU = torch.cat([per[r, nX + nU:].reshape(2, N - 1, B) for r in range(world)], dim=2)
+    return {"X_optm": X, "U_optm": U, "dU_optm": dU}
+
+
 def cpu_baseline(pkg, N, batch, seconds_target=12.0):
     """Time the C restatement (oracle, 'port') on the host cores over a bounded sample."""
     import ctypes as C
@@ -98,7 +129,7 @@ def main():
     gather = world > 1 and not args.no_gather
     if gather:
         import torch.distributed as dist
-        flat = [torch.empty((10 * N - 4) * B, dtype=torch.float64, device=dev) for _ in range(2)]
+        flat = [torch.empty(packed_numel(N, B), dtype=torch.float64, device=dev) for _ in range(2)]
         gbuf = [torch.empty(world * flat[0].numel(), dtype=torch.float64, device=dev) for _ in range(2)]
 
     def step(k, handle_prev):
@@ -107,8 +138,7 @@ def main():
         if gather:
             if handle_prev is not None:
                 handle_prev.wait()
-            f = flat[k & 1]
-            torch.cat([o["X_optm"].reshape(-1), o["U_optm"].reshape(-1), o["dU_optm"].reshape(-1)], out=f)
+            f = pack_results(o, flat[k & 1])
             return dist.all_gather_into_tensor(gbuf[k & 1], f, async_op=True)
         return None
 

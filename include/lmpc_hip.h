@@ -157,6 +157,19 @@ int lmpc_solve_batch(lmpc_handle* h, int32_t batch, const double* x_ic, const do
                      const double* ss_j, double* X_optm, double* U_optm, double* dU_optm,
                      double* convex_combi_optm, int32_t* status, int32_t* iters, double* kkt);
 
+/* RacingMPC::solve for ONE problem with HOST pointers in the reference's own (CasADi DM,
+ * column-major) layout: X_ref is 6 x N with a knot's state contiguous, U_ref 2 x (N-1), the
+ * per-knot rows are plain arrays.  Stages the data through buffers owned by the handle, runs
+ * lmpc_solve_batch with batch = 1 and waits.  This is what the C++ facade (RacingMPC class,
+ * racing-lmpc-ros2_amd/host/) calls.  ss_x is 6 x S column-major, ss_j has S entries
+ * (learning only; NULL otherwise); convex_combi_optm may be NULL. */
+int lmpc_solve_host(lmpc_handle* h, const double* x_ic, const double* u_ic, const double* X_ref,
+                    const double* U_ref, const double* T_ref, const double* bound_left,
+                    const double* bound_right, const double* curvatures, const double* vel_ref,
+                    double total_length, const double* ss_x, const double* ss_j, double* X_optm,
+                    double* U_optm, double* dU_optm, double* convex_combi_optm, int32_t* status,
+                    int32_t* iters);
+
 /* Safe set store: SafeSetManager::add_lap / SSTrajectory::process_lap_data
  * (safe_set.cpp:116-151).  HOST pointers: laps oldest first, lap j has n_pts[j] samples,
  * x is the concatenation of the laps' [n_pts[j]][6] row-major state tables.  The library

@@ -18,7 +18,7 @@ SOLVE_OPTIMAL, SOLVE_MAX_ITER, SOLVE_INFEASIBLE = 0, 1, 2
 _ABI_SYMBOLS = ("lmpc_create", "lmpc_destroy", "lmpc_last_error", "lmpc_set_stream", "lmpc_synchronize",
                 "lmpc_linearize_batch", "lmpc_solve_batch", "lmpc_set_safe_set", "lmpc_ss_query_batch",
                 "lmpc_prepare_batch", "lmpc_reserve", "lmpc_query_launch", "lmpc_enable_timing",
-                "lmpc_last_kernel_ms", "lmpc_query_residency")
+                "lmpc_last_kernel_ms", "lmpc_query_residency", "lmpc_solve_host")
 
 
 class LmpcError(RuntimeError):

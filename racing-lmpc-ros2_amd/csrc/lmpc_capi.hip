@@ -42,6 +42,10 @@ struct lmpc_handle {
   double* ss_x = nullptr;  // [total][6]
   double ss_L = 0.0;
   int ss_nmax = 0;
+  // staging for lmpc_solve_host (device + pinned-free host mirror)
+  double* stage_dev = nullptr;
+  size_t stage_doubles = 0;
+  int* stage_int = nullptr;
   // timing
   bool timing = false;
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
@@ -150,6 +154,8 @@ void lmpc_destroy(lmpc_handle* h) {
   if (h->ss_npts) (void)hipFree(h->ss_npts);
   if (h->ss_off) (void)hipFree(h->ss_off);
   if (h->ss_x) (void)hipFree(h->ss_x);
+  if (h->stage_dev) (void)hipFree(h->stage_dev);
+  if (h->stage_int) (void)hipFree(h->stage_int);
   for (auto& e : h->ev)
     if (e) (void)hipEventDestroy(e);
   delete h;
@@ -281,6 +287,71 @@ int lmpc_solve_batch(lmpc_handle* h, int32_t batch, const double* x_ic, const do
   }
   if (rc != LMPC_OK) return rc;
   if (h->timing) HIP_TRY(h, hipEventRecord(h->ev[2], h->stream));
+  return LMPC_OK;
+}
+
+int lmpc_solve_host(lmpc_handle* h, const double* x_ic, const double* u_ic, const double* X_ref, const double* U_ref,
+                    const double* T_ref, const double* bound_left, const double* bound_right, const double* curvatures,
+                    const double* vel_ref, double total_length, const double* ss_x, const double* ss_j, double* X_optm,
+                    double* U_optm, double* dU_optm, double* convex_combi_optm, int32_t* status, int32_t* iters) {
+  if (!h) return LMPC_ERR_ARGUMENT;
+  if (!x_ic || !u_ic || !X_ref || !U_ref || !T_ref || !bound_left || !bound_right || !curvatures || !vel_ref ||
+      !X_optm || !U_optm || !dU_optm || !status || !iters)
+    return fail(h, LMPC_ERR_ARGUMENT, "lmpc_solve_host: null pointer");
+  const int N = h->P.N, NS = N - 1, S = h->P.S;
+  // staging layout (doubles): inputs then outputs, each in the batch = 1 device layout
+  const size_t o_x = 0, o_u = 6, o_X = 8, o_U = o_X + 6 * N, o_T = o_U + 2 * NS, o_bl = o_T + NS, o_br = o_bl + N,
+               o_k = o_br + N, o_v = o_k + N, o_sx = o_v + N, o_sj = o_sx + 6 * (size_t)S, o_Xo = o_sj + S,
+               o_Uo = o_Xo + 6 * N, o_dUo = o_Uo + 2 * NS, o_lam = o_dUo + 2 * NS, total = o_lam + S;
+  HIP_TRY(h, hipSetDevice(h->device));
+  if (h->stage_doubles < total) {
+    if (h->stage_dev) HIP_TRY(h, hipFree(h->stage_dev));
+    h->stage_dev = nullptr;
+    HIP_TRY(h, hipMalloc(&h->stage_dev, total * sizeof(double)));
+    h->stage_doubles = total;
+  }
+  if (!h->stage_int) HIP_TRY(h, hipMalloc(&h->stage_int, 2 * sizeof(int)));
+  std::vector<double> host(total, 0.0);
+  for (int k = 0; k < 6; ++k) host[o_x + k] = x_ic[k];
+  for (int k = 0; k < 2; ++k) host[o_u + k] = u_ic[k];
+  for (int i = 0; i < N; ++i)
+    for (int k = 0; k < 6; ++k) host[o_X + (size_t)k * N + i] = X_ref[(size_t)i * 6 + k];  // column-major -> [6][N]
+  for (int i = 0; i < NS; ++i) {
+    for (int k = 0; k < 2; ++k) host[o_U + (size_t)k * NS + i] = U_ref[(size_t)i * 2 + k];
+    host[o_T + i] = T_ref[i];
+  }
+  for (int i = 0; i < N; ++i) {
+    host[o_bl + i] = bound_left[i];
+    host[o_br + i] = bound_right[i];
+    host[o_k + i] = curvatures[i];
+    host[o_v + i] = vel_ref[i];
+  }
+  if (S && ss_x && ss_j)
+    for (int j = 0; j < S; ++j) {
+      for (int k = 0; k < 6; ++k) host[o_sx + (size_t)k * S + j] = ss_x[(size_t)j * 6 + k];
+      host[o_sj + j] = ss_j[j];
+    }
+  double* d = h->stage_dev;
+  HIP_TRY(h, hipMemcpyAsync(d, host.data(), o_Xo * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  const int rc = lmpc_solve_batch(h, 1, d + o_x, d + o_u, d + o_X, d + o_U, d + o_T, d + o_bl, d + o_br, d + o_k, d + o_v,
+                                  total_length, S ? d + o_sx : nullptr, S ? d + o_sj : nullptr, d + o_Xo, d + o_Uo,
+                                  d + o_dUo, S ? d + o_lam : nullptr, h->stage_int, h->stage_int + 1, nullptr);
+  if (rc != LMPC_OK) return rc;
+  int si[2] = {0, 0};
+  HIP_TRY(h, hipMemcpyAsync(host.data() + o_Xo, d + o_Xo, (total - o_Xo) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(si, h->stage_int, sizeof(si), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  for (int i = 0; i < N; ++i)
+    for (int k = 0; k < 6; ++k) X_optm[(size_t)i * 6 + k] = host[o_Xo + (size_t)k * N + i];
+  for (int i = 0; i < NS; ++i)
+    for (int k = 0; k < 2; ++k) {
+      U_optm[(size_t)i * 2 + k] = host[o_Uo + (size_t)k * NS + i];
+      dU_optm[(size_t)i * 2 + k] = host[o_dUo + (size_t)k * NS + i];
+    }
+  if (S && convex_combi_optm)
+    for (int j = 0; j < S; ++j) convex_combi_optm[j] = host[o_lam + j];
+  *status = si[0];
+  *iters = si[1];
   return LMPC_OK;
 }
 

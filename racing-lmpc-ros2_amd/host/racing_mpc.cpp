@@ -1,0 +1,137 @@
+// racing_mpc.cpp -- see racing_mpc.hpp.  Plain C++17, links liblmpc_hip.so only.
+#include "racing_mpc.hpp"
+
+#include <cmath>
+#include <iostream>
+#include <stdexcept>
+
+namespace lmpc {
+namespace mpc {
+namespace racing_mpc {
+
+namespace {
+// lmpc_utils/utils.hpp:35-41 (sign(0) = 0 as in CasADi)
+double align_abscissa(double s1, double s2, double s_total) {
+  const double k = std::fabs(s2 - s1) + s_total / 2.0;
+  const double l = k - std::fmod(k, s_total);
+  const double d = s2 - s1;
+  return s1 + l * ((d > 0) - (d < 0));
+}
+}  // namespace
+
+RacingMPC::RacingMPC(RacingMPCConfig::SharedPtr mpc_config, VehicleModel::SharedPtr model, const bool& full_dynamics,
+                     int device)
+    : config_(mpc_config), model_(model), full_dynamics_(full_dynamics), solved_(false), h_(nullptr) {
+  if (!config_ || !model_) throw std::invalid_argument("RacingMPC: null config or model");
+  if (model_->name != "single_track_planar_model")
+    throw std::runtime_error("RacingMPC: vehicle model '" + model_->name + "' is not built");
+  model_->v.model_id = LMPC_MODEL_SINGLE_TRACK_PLANAR;
+  const int rc = lmpc_create(&config_->c, &model_->v, device, &h_);
+  if (rc != LMPC_OK) {
+    const std::string msg = h_ ? lmpc_last_error(h_) : "allocation failed";
+    if (h_) lmpc_destroy(h_);
+    h_ = nullptr;
+    throw std::runtime_error("RacingMPC: lmpc_create failed: " + msg);
+  }
+}
+
+RacingMPC::~RacingMPC() { lmpc_destroy(h_); }
+
+const RacingMPCConfig& RacingMPC::get_config() const { return *config_; }
+VehicleModel& RacingMPC::get_model() { return *model_; }
+const bool& RacingMPC::solved() const { return solved_; }
+
+void RacingMPC::solve(const DMDict& in, DMDict& out, Dict& stats) {
+  const std::size_t N = static_cast<std::size_t>(config_->c.N);
+  const double total_length = static_cast<double>(in.at("total_length"));
+  const DM& x_ic = in.at("x_ic");
+  const DM& u_ic = in.at("u_ic");
+  (void)in.at("t_ic");  // consumed by the lap recorder upstream (racing_mpc.cpp:218,246)
+  DM X_ref = in.at("X_ref");
+  for (std::size_t i = 0; i < N; ++i)  // racing_mpc.cpp:219-223
+    X_ref(0, i) = align_abscissa(X_ref(0, i), x_ic(0, 0), total_length);
+  DM U_ref = in.at("U_ref");
+  const DM& bound_left = in.at("bound_left");
+  const DM& bound_right = in.at("bound_right");
+  const DM& curvatures = in.at("curvatures");
+  const DM& vel_ref = in.at("vel_ref");
+  // warm start keys are accepted; the interior-point solve does not use a primal warm start, but
+  // T_optm_ref replaces T_ref exactly as upstream (racing_mpc.cpp:293-315)
+  const DM& T = in.count("X_optm_ref") ? in.at("T_optm_ref") : in.at("T_ref");
+  if (X_ref.rows != 6 || X_ref.cols != N || U_ref.rows != 2 || U_ref.cols != N - 1 || T.data.size() != N - 1 ||
+      bound_left.data.size() != N || bound_right.data.size() != N || curvatures.data.size() != N ||
+      vel_ref.data.size() != N || x_ic.data.size() != 6 || u_ic.data.size() != 2)
+    throw std::length_error("RacingMPC::solve: input dimension does not match MPC dimension");
+  if (config_->c.learning) {
+    std::cerr << "RacingMPC::solve: LMPC terminal block not built in this round" << '\n';
+    return;
+  }
+  DM X(6, N), U(2, N - 1), dU(2, N - 1);
+  int32_t status = 0, iters = 0, total_iters = 0;
+  const int n_sqp = full_dynamics_ ? 8 : 1;
+  for (int k = 0; k < n_sqp; ++k) {
+    const int rc = lmpc_solve_host(h_, x_ic.data.data(), u_ic.data.data(), X_ref.data.data(), U_ref.data.data(),
+                                   T.data.data(), bound_left.data.data(), bound_right.data.data(),
+                                   curvatures.data.data(), vel_ref.data.data(), total_length, nullptr, nullptr,
+                                   X.data.data(), U.data.data(), dU.data.data(), nullptr, &status, &iters);
+    if (rc != LMPC_OK) {
+      std::cerr << "RacingMPC::solve: " << lmpc_last_error(h_) << '\n';
+      return;
+    }
+    total_iters += iters;
+    if (status != LMPC_SOLVE_OPTIMAL) break;
+    if (!full_dynamics_) break;
+    // sequential QP on the nonlinear dynamics: re-linearise about the new trajectory until it stops moving
+    double move = 0.0;
+    for (std::size_t j = 0; j < X.data.size(); ++j) move = std::fmax(move, std::fabs(X.data[j] - X_ref.data[j]));
+    X_ref = X;
+    U_ref = U;
+    if (move < 1e-8) break;
+  }
+  stats["iter_count"] = static_cast<double>(total_iters);
+  if (status != LMPC_SOLVE_OPTIMAL) {
+    std::cerr << "RacingMPC::solve: QP " << (status == LMPC_SOLVE_INFEASIBLE ? "infeasible" : "hit the iteration cap")
+              << '\n';
+    return;  // out lacks X_optm, solved_ unchanged (racing_mpc.cpp:358-371)
+  }
+  solved_ = true;
+  out["X_optm"] = X;
+  out["U_optm"] = U;
+  out["dU_optm"] = dU;
+}
+
+void RacingMPC::create_warm_start(const DMDict& in, DMDict& out) {
+  const std::size_t N = static_cast<std::size_t>(config_->c.N);
+  const DM& P0 = in.at("P0");
+  const DM& Yaws = in.at("Yaws");
+  const DM& Radii = in.at("Radii");
+  const double current_vel = static_cast<double>(in.at("current_vel"));
+  const double target_vel = static_cast<double>(in.at("target_vel"));
+  if (P0.size2() != N) throw std::length_error("create_warm_start: P0 dimension does not match MPC dimension.");
+  if (Yaws.size2() != N) throw std::length_error("create_warm_start: Yaws dimension does not match MPC dimension.");
+  if (current_vel <= 0.0) throw std::range_error("Current velocity cannot be smaller than or equal to zero.");
+  if (target_vel <= 0.0) throw std::range_error("Target velocity cannot be smaller than or equal to zero.");
+  DM X_ref(6, N), U_ref(2, N - 1);
+  for (std::size_t i = 0; i < N; ++i) {
+    X_ref(0, i) = P0(0, i);
+    X_ref(1, i) = P0(1, i);
+    X_ref(2, i) = Yaws.data[i];
+    X_ref(3, i) = current_vel + (target_vel - current_vel) * (N > 1 ? double(i) / double(N - 1) : 0.0);
+    X_ref(5, i) = X_ref(3, i) / Radii.data[i];
+  }
+  for (std::size_t i = 0; i + 1 < N; ++i) {
+    const double v0 = X_ref(3, i), v1 = X_ref(3, i + 1);
+    const double d = std::hypot(P0(0, i) - P0(0, i + 1), P0(1, i) - P0(1, i + 1));
+    const double a = (v1 * v1 - v0 * v0) / (2 * d);
+    // upstream writes a force into the 3-control layout (racing_mpc.cpp:413-418); with the simplified
+    // longitudinal control one unit of u_lon is 1000 N (single_track_planar_model.cpp:215-216)
+    U_ref(0, i) = model_->v.m * a / 1000.0;
+    U_ref(1, i) = std::atan(model_->v.l / Radii.data[i]);
+  }
+  out["X_ref"] = X_ref;
+  out["U_ref"] = U_ref;
+}
+
+}  // namespace racing_mpc
+}  // namespace mpc
+}  // namespace lmpc

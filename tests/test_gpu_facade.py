@@ -1,0 +1,37 @@
+"""The C++ RacingMPC facade (reference class surface) end to end on the GPU."""
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+LIB = ROOT / "racing-lmpc-ros2_amd" / "lib"
+
+pytestmark = pytest.mark.gpu
+
+
+def _dm(f, a):
+    a = np.atleast_2d(np.asarray(a, dtype=np.float64))
+    f.write(f"{a.shape[0]} {a.shape[1]}\n")
+    f.write(" ".join(repr(float(v)) for v in a.T.reshape(-1)) + "\n")  # column-major
+
+
+def test_facade_solves_like_the_reference_class(golden, tmp_path):
+    g = golden("qp_barc_tracking_n20")
+    exe = LIB / "test_facade"
+    assert exe.exists(), "run __graft_entry__.build() first"
+    for b in (0, 7):
+        p = tmp_path / f"problem{b}.txt"
+        with open(p, "w") as f:
+            f.write("20\n")
+            _dm(f, g["x_ic"][:, b:b + 1])
+            _dm(f, g["u_ic"][:, b:b + 1])
+            _dm(f, g["X_ref"][:, :, b])
+            _dm(f, g["U_ref"][:, :, b])
+            for k in ("T_ref", "bound_left", "bound_right", "curvatures", "vel_ref"):
+                _dm(f, g[k][:, b][None, :])
+            _dm(f, g["X_optm"][:, :, b])
+            _dm(f, g["U_optm"][:, :, b])
+        r = subprocess.run([str(exe), str(p)], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0 and "PASS" in r.stdout, (r.stdout, r.stderr)
