@@ -202,7 +202,8 @@ typedef struct {
   /* cost: diag state Hessian + linear term per knot, 2x2 blocks, slack weight */
   double Qx[NMAX][6], qx[NMAX][6], Qu[4], Sv[4], qsig;
   /* LMPC terminal block */
-  double ssx[6][SMAX], ssj[SMAX], chs2[6]; /* 2*convex_hull_slack */
+  double ssx[6][SMAX], ssj[SMAX], chs2[6]; /* safe-set points CENTRED on ss0 = first point; 2*convex_hull_slack */
+  double ss0[6];
   /* bounds per slot */
   double hi[NMAX][NSLOT], lo[NMAX][NSLOT];
   int act[NMAX][NSLOT][2]; /* [upper, lower] */
@@ -330,19 +331,34 @@ static inline double slot_val(double (*z)[8], double (*v)[2], int i, int sl) {
 }
 
 /* LMPC terminal block -------------------------------------------------------------------------
- * Terminal variables lambda (S) and eps = x_T - SS lambda (eliminated):
- *   cost  ss_j' lambda + eps' D eps,  1' lambda = 1,  lambda >= 0        (racing_mpc.cpp:484-504)
- * Newton step in lambda for given (theta_l, gradient rhs) and the coupling to dx_T is
- * condensed into a quadratic in dx_T:  1/2 dx' PT dx + pT' dx.
- * With E = 2D, U = SS (6xS), Th = diag(theta_l):
- *   M = Th + U'EU ;  minimise over dl (1'dl = r1):  1/2 dl'M dl + (bl - U'E dx)' dl
- * Woodbury: M^-1 = Th^-1 - Th^-1 U' F^-1 U Th^-1,  F = E^-1 + U Th^-1 U'  (6x6 SPD).
- */
+ * Terminal variables lambda (S) and eps = x_T - U lambda (eliminated), U = SS (6 x S):
+ *   cost  ss_j' lambda + eps' D eps,   1' lambda = 1,   lambda >= 0        (racing_mpc.cpp:484-504)
+ * With E = 2D and barrier weights Th = diag(theta_l), the Newton step in lambda for a given
+ * terminal-state step dx is
+ *     dl = Z (U'E dx - bl) + M^-1 1 r1 / s11,   M = Th + U'EU,   Z = M^-1 - M^-1 1 1'M^-1 / s11,
+ * (bl: gradient wrt lambda, r1 = 1 - 1'lambda, s11 = 1'M^-1 1) and eliminating it leaves a quadratic
+ * in dx:  1/2 dx' PT dx + pT' dx  with  PT = E - E U Z U' E.
+ * Woodbury (M^-1 = Th^-1 - Th^-1 U' F^-1 U Th^-1, F = E^-1 + T, T = U Th^-1 U') reduces everything
+ * to 6x6 algebra on three kinds of sums over the S points:
+ *     T = U Th^-1 U' (21 sums),  a = U Th^-1 1 (6),  sth = sum 1/theta (1)      -- per factorisation
+ *     beta = U Th^-1 bl (6),  sbl = sum bl/theta (1)                             -- per right-hand side
+ * which is what the GPU kernel reduces across the wave:
+ *     U M^-1 U' = T - T F^-1 T =: G,   U M^-1 1 = a - T F^-1 a =: g,   s11 = sth - a'F^-1 a,
+ *     PT = E - E (G - g g'/s11) E,
+ *     U dl0 = -(beta - T F^-1 beta) + g (sbl - a'F^-1 beta + r1)/s11,   pT = -E U dl0,
+ *     dl_j = (r_j - u_j'F^-1 gamma)/theta_j - Mi1_j (oMr - r1)/s11,  r_j = u_j'E dx - bl_j,
+ *            gamma = T E dx - beta,  oMr = a'E dx - sbl - a'F^-1 gamma,  Mi1_j = (1 - u_j'F^-1 a)/theta_j. */
 typedef struct {
-  double F[36], Fi[36];  /* F and its inverse                                     */
-  double Mi1[SMAX];      /* M^-1 1                                                */
-  double s11;            /* 1' M^-1 1                                             */
+  double T[36], Fi[36], a[6], Fia[6], s11;
+  double beta[6], Fibeta[6], sbl;
 } term_t;
+
+/* floor on the simplex rows' barrier weight inside the Newton matrix: keeps 1/theta of the points
+ * with lambda > 0 from swamping E^-1 in F = E^-1 + T.  It only regularises the Newton matrix (a
+ * proximal term on d lambda); residuals and row updates use the true weights, so the fixed point is
+ * unchanged.  Measured on BARC LMPC problems: 1e-3 gives 1e-9 agreement with the dense optimum,
+ * 1e-6 gives 1e-5, none stalls at mu ~ 1e-8. */
+#define TH_L_MIN 1e-3
 
 static void sym_inv6(const double* F, double* Fi) { /* Cholesky inverse of SPD 6x6 */
   double Lc[36] = {0};
@@ -373,80 +389,86 @@ static void sym_inv6(const double* F, double* Fi) { /* Cholesky inverse of SPD 6
   }
 }
 
-/* y = M^-1 r  (Woodbury) */
-static void term_minv(const prob_t* p, const term_t* tm, const double* thl, const double* r, double* y) {
-  const int S = p->S;
-  double a[6] = {0}, b[6];
-  for (int j = 0; j < S; ++j)
-    for (int k = 0; k < 6; ++k) a[k] += p->ssx[k][j] * r[j] / thl[j];
-  for (int k = 0; k < 6; ++k) {
-    b[k] = 0;
-    for (int c = 0; c < 6; ++c) b[k] += tm->Fi[k * 6 + c] * a[c];
-  }
-  for (int j = 0; j < S; ++j) {
+static void mv6(const double* M, const double* x, double* y) {
+  for (int r = 0; r < 6; ++r) {
     double s = 0;
-    for (int k = 0; k < 6; ++k) s += p->ssx[k][j] * b[k];
-    y[j] = (r[j] - s) / thl[j];
+    for (int c = 0; c < 6; ++c) s += M[r * 6 + c] * x[c];
+    y[r] = s;
   }
 }
 
+/* All subtractions between large quantities are avoided through F - T = E^-1:
+ *   PT = E - E U Z U'E = F^-1 + (F^-1 a)(F^-1 a)'/s11,   pT = F^-1 beta - F^-1 a (sbl - a'F^-1 beta + r1)/s11;
+ * only s11 = sth - a'F^-1 a remains a difference (relative error ~ eps * sth / s11, bounded by the floor). */
 static void term_factor(prob_t* p, term_t* tm, const double* thl, double* PT) {
   const int S = p->S;
-  for (int r = 0; r < 6; ++r)
-    for (int c = 0; c < 6; ++c) {
-      double acc = (r == c) ? 1.0 / p->chs2[r] : 0.0;
-      for (int j = 0; j < S; ++j) acc += p->ssx[r][j] * p->ssx[c][j] / thl[j];
-      tm->F[r * 6 + c] = acc;
-    }
-  sym_inv6(tm->F, tm->Fi);
-  double ones[SMAX];
-  for (int j = 0; j < S; ++j) ones[j] = 1.0;
-  term_minv(p, tm, thl, ones, tm->Mi1);
-  tm->s11 = 0;
-  for (int j = 0; j < S; ++j) tm->s11 += tm->Mi1[j];
-  /* PT = E - E U (M^-1 - M^-1 1 1' M^-1 / s11) U' E   (lambda eliminated on 1'dl = const) */
-  double col[SMAX], y[SMAX];
-  for (int c = 0; c < 6; ++c) {
-    for (int j = 0; j < S; ++j) col[j] = p->ssx[c][j] * p->chs2[c]; /* (U'E)[:, c] */
-    term_minv(p, tm, thl, col, y);
-    double s1 = 0;
-    for (int j = 0; j < S; ++j) s1 += y[j];
-    for (int j = 0; j < S; ++j) y[j] -= tm->Mi1[j] * s1 / tm->s11;
+  double F[36], sth = 0.0;
+  for (int r = 0; r < 6; ++r) {
+    tm->a[r] = 0.0;
+    for (int c = 0; c < 6; ++c) tm->T[r * 6 + c] = 0.0;
+  }
+  for (int j = 0; j < S; ++j) {
+    const double it = 1.0 / fmax(thl[j], TH_L_MIN);
+    sth += it;
     for (int r = 0; r < 6; ++r) {
-      double acc = 0;
-      for (int j = 0; j < S; ++j) acc += p->ssx[r][j] * y[j];
-      PT[r * 6 + c] = (r == c ? p->chs2[r] : 0.0) - p->chs2[r] * acc;
+      tm->a[r] += p->ssx[r][j] * it;
+      for (int c = 0; c < 6; ++c) tm->T[r * 6 + c] += p->ssx[r][j] * p->ssx[c][j] * it;
     }
   }
+  for (int r = 0; r < 6; ++r)
+    for (int c = 0; c < 6; ++c) F[r * 6 + c] = tm->T[r * 6 + c] + (r == c ? 1.0 / p->chs2[r] : 0.0);
+  sym_inv6(F, tm->Fi);
+  mv6(tm->Fi, tm->a, tm->Fia);
+  tm->s11 = sth;
+  for (int r = 0; r < 6; ++r) tm->s11 -= tm->a[r] * tm->Fia[r];
+  for (int r = 0; r < 6; ++r)
+    for (int c = 0; c < 6; ++c) PT[r * 6 + c] = tm->Fi[r * 6 + c] + tm->Fia[r] * tm->Fia[c] / tm->s11;
 }
 
-/* Given gradient bl wrt lambda (at dx=0) and target 1'dl = r1:
- *   dl(dx) = dl0 + Z U'E dx,  Z = M^-1 - M^-1 1 1'M^-1/s11
- *   dl0 = -Z bl + M^-1 1 r1 / s11 ;  returns dl0 and pT = gradient wrt dx_T contributed:
- *   pT = gx - E U dl0   where gx = E eps-part is added by the caller. */
-static void term_dl0(const prob_t* p, const term_t* tm, const double* thl, const double* bl, double r1,
-                     double* dl0) {
+/* per right-hand side: sums with bl, returns the terminal-gradient contribution pT = -E U dl0 */
+static void term_rhs(const prob_t* p, term_t* tm, const double* thl, const double* bl, double r1, double* pT) {
   const int S = p->S;
-  double y[SMAX];
-  term_minv(p, tm, thl, bl, y);
-  double s1 = 0;
-  for (int j = 0; j < S; ++j) s1 += y[j];
-  for (int j = 0; j < S; ++j) dl0[j] = -(y[j] - tm->Mi1[j] * s1 / tm->s11) + tm->Mi1[j] * r1 / tm->s11;
+  tm->sbl = 0.0;
+  for (int r = 0; r < 6; ++r) tm->beta[r] = 0.0;
+  for (int j = 0; j < S; ++j) {
+    const double w = bl[j] / fmax(thl[j], TH_L_MIN);
+    tm->sbl += w;
+    for (int r = 0; r < 6; ++r) tm->beta[r] += p->ssx[r][j] * w;
+  }
+  mv6(tm->Fi, tm->beta, tm->Fibeta);
+  double aFib = 0.0;
+  for (int r = 0; r < 6; ++r) aFib += tm->a[r] * tm->Fibeta[r];
+  const double coef = (tm->sbl - aFib + r1) / tm->s11;
+  for (int r = 0; r < 6; ++r) pT[r] = tm->Fibeta[r] - tm->Fia[r] * coef;
 }
 
-static void term_dl_of_dx(const prob_t* p, const term_t* tm, const double* thl, const double* dl0,
+static void term_dl_of_dx(const prob_t* p, const term_t* tm, const double* thl, const double* bl, double r1,
                           const double* dx, double* dl) {
   const int S = p->S;
-  double r[SMAX], y[SMAX];
+  double e[6], gam[6] = {0}, Figam[6], sr = 0.0, aFig = 0.0;
+  for (int k = 0; k < 6; ++k) e[k] = p->chs2[k] * dx[k];
+  /* gamma = U Th^-1 r and sr = 1'Th^-1 r summed from the per-point residuals r_j = u_j'E dx - bl_j
+   * (small for points with lambda > 0) rather than as T e - beta, which cancels */
   for (int j = 0; j < S; ++j) {
-    double s = 0;
-    for (int k = 0; k < 6; ++k) s += p->ssx[k][j] * p->chs2[k] * dx[k];
-    r[j] = s;
+    double rj = -bl[j];
+    for (int k = 0; k < 6; ++k) rj += p->ssx[k][j] * e[k];
+    const double w = rj / fmax(thl[j], TH_L_MIN);
+    sr += w;
+    for (int k = 0; k < 6; ++k) gam[k] += p->ssx[k][j] * w;
   }
-  term_minv(p, tm, thl, r, y);
-  double s1 = 0;
-  for (int j = 0; j < S; ++j) s1 += y[j];
-  for (int j = 0; j < S; ++j) dl[j] = dl0[j] + y[j] - tm->Mi1[j] * s1 / tm->s11;
+  mv6(tm->Fi, gam, Figam);
+  for (int k = 0; k < 6; ++k) aFig += tm->a[k] * Figam[k];
+  const double coef = (sr - aFig - r1) / tm->s11;
+  for (int j = 0; j < S; ++j) {
+    double rj = -bl[j], ug = 0.0, ua = 0.0;
+    for (int k = 0; k < 6; ++k) {
+      rj += p->ssx[k][j] * e[k];
+      ug += p->ssx[k][j] * Figam[k];
+      ua += p->ssx[k][j] * tm->Fia[k];
+    }
+    const double it = 1.0 / fmax(thl[j], TH_L_MIN);
+    dl[j] = (rj - ug) * it - (1.0 - ua) * it * coef;
+  }
 }
 
 /* ---- shared Newton machinery -------------------------------------------------------------
@@ -466,7 +488,8 @@ typedef struct {
   double az[NMAX][8], av[NMAX][2];
   double ce;
   term_t tm;
-  double dl0[SMAX];
+  double bl[SMAX];
+  int frozen_lambda; /* start point: lambda held fixed, terminal cost = eps'D eps only */
 } work_t;
 
 /* gradient of the objective at the current iterate (no multipliers) */
@@ -485,7 +508,7 @@ static void cost_gradient(const prob_t* p, work_t* w) {
     for (int j = 0; j < S; ++j) sl_ += p->lmb[j];
     w->r1 = 1.0 - sl_;
     for (int k = 0; k < 6; ++k) {
-      double s = p->z[N - 1][k];
+      double s = p->z[N - 1][k] - p->ss0[k]; /* centred: x_T - ss0 - (SS - ss0 1') lambda, valid as 1'lambda = 1 */
       for (int j = 0; j < S; ++j) s -= p->ssx[k][j] * p->lmb[j];
       w->eps_T[k] = s;
       w->gz[N - 1][k] += p->chs2[k] * s;
@@ -585,8 +608,10 @@ static void newton_factor(prob_t* p, work_t* w) {
     }
   }
   if (p->has_sigma) p->hsig += w->ths;
-  double PT[36];
-  if (S) term_factor(p, &w->tm, w->thl, PT);
+  double PT[36] = {0};
+  if (S && !w->frozen_lambda) term_factor(p, &w->tm, w->thl, PT);
+  if (S && w->frozen_lambda)
+    for (int k = 0; k < 6; ++k) PT[k * 6 + k] = p->chs2[k];
   riccati_factor(p, S ? PT : NULL);
   w->ce = 0.0;
   if (p->has_sigma) {
@@ -625,19 +650,15 @@ static void newton_solve(prob_t* p, work_t* w) {
     }
   }
   if (p->has_sigma) qsg -= w->cfs;
-  if (S) {
-    double bl[SMAX];
+  if (S && !w->frozen_lambda) {
+    double pT[6];
     for (int j = 0; j < S; ++j) {
-      double s = p->ssj[j] - w->cfl[j];
-      for (int k = 0; k < 6; ++k) s -= p->ssx[k][j] * p->chs2[k] * w->eps_T[k];
-      bl[j] = s;
+      double sgr = p->ssj[j] - w->cfl[j];
+      for (int k = 0; k < 6; ++k) sgr -= p->ssx[k][j] * p->chs2[k] * w->eps_T[k];
+      w->bl[j] = sgr;
     }
-    term_dl0(p, &w->tm, w->thl, bl, w->r1, w->dl0);
-    for (int k = 0; k < 6; ++k) {
-      double s = 0;
-      for (int j = 0; j < S; ++j) s += p->ssx[k][j] * w->dl0[j];
-      w->az[N - 1][k] -= p->chs2[k] * s;
-    }
+    term_rhs(p, &w->tm, w->thl, w->bl, w->r1, pT);
+    for (int k = 0; k < 6; ++k) w->az[N - 1][k] += pT[k];
   }
   riccati_solve(p, w->az, w->av, p->dz, p->dv);
   if (p->has_sigma) {
@@ -654,7 +675,9 @@ static void newton_solve(prob_t* p, work_t* w) {
   } else {
     p->dsigma = 0.0;
   }
-  if (S) term_dl_of_dx(p, &w->tm, w->thl, w->dl0, p->dz[N - 1], p->dlmb);
+  if (S && !w->frozen_lambda) term_dl_of_dx(p, &w->tm, w->thl, w->bl, w->r1, p->dz[N - 1], p->dlmb);
+  if (S && w->frozen_lambda)
+    for (int j = 0; j < S; ++j) p->dlmb[j] = 0.0;
 }
 
 static void primal_update(prob_t* p, double alpha) {
@@ -695,6 +718,7 @@ static int ipm_solve(prob_t* p, int* iters_out, double* kkt_out) {
     w->cfl[j] = 0.0;
   }
   p->sigma = 0.0;
+  w->frozen_lambda = 1;
   newton_factor(p, w);
   for (int i = 0; i < N - 1; ++i) {
     for (int a = 0; a < 2; ++a) {
@@ -714,8 +738,8 @@ static int ipm_solve(prob_t* p, int* iters_out, double* kkt_out) {
   cost_gradient(p, w);
   newton_solve(p, w);
   p->dsigma = 0.0;
-  for (int j = 0; j < S; ++j) p->dlmb[j] = 0.0;
   primal_update(p, 1.0);
+  w->frozen_lambda = 0;
   int m = 0;
   for (int i = 0; i < N; ++i)
     for (int sl = 0; sl < NSLOT; ++sl) {
@@ -943,7 +967,8 @@ static void setup_problem(prob_t* p, const lmpc_config* cfg, const lmpc_vehicle*
   if (p->S) {
     for (int k = 0; k < 6; ++k) {
       p->chs2[k] = 2.0 * cfg->convex_hull_slack[k];
-      for (int j = 0; j < p->S; ++j) p->ssx[k][j] = ss_x[(size_t)(k * p->S + j) * B + b];
+      p->ss0[k] = ss_x[(size_t)(k * p->S) * B + b];
+      for (int j = 0; j < p->S; ++j) p->ssx[k][j] = ss_x[(size_t)(k * p->S + j) * B + b] - p->ss0[k];
     }
     for (int j = 0; j < p->S; ++j) p->ssj[j] = ss_j[(size_t)j * B + b];
   }
