@@ -20,10 +20,10 @@ __global__ void lmpc_linearize_kernel(lmpc_params, int, const double*, const dou
                                       double*, double*, double*);
 __global__ void lmpc_prepare_kernel(lmpc_params, int, lmpc_track, const double*, double, double, double, double*,
                                     double*, double*, double*, double*, double*, double*);
-template <int KQ>
+template <int KQ, int KS>
 __global__ void lmpc_solve_kernel(lmpc_params, int, const double*, const double*, const double*, const double*,
-                                  const double*, const double*, const double*, double*, double*, double*, int*, int*,
-                                  double*);
+                                  const double*, const double*, const double*, const double*, const double*, double*,
+                                  double*, double*, double*, int*, int*, double*);
 __global__ void lmpc_ss_query_kernel(int, int, int, int, const int*, const int*, const double*, double, const double*,
                                      double*, double*, int*);
 
@@ -74,15 +74,51 @@ int kq_for(int N) {
   return -1;
 }
 
-template <int KQ>
-int launch_solve(lmpc_handle* h, int B, size_t lds_bytes, const double* x_ic, const double* u_ic, const double* T_ref,
-                 const double* bl, const double* br, const double* vref, double* X, double* U, double* dU, int* status,
-                 int* iters, double* kkt) {
-  HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&lmpc_solve_kernel<KQ>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-  hipLaunchKernelGGL(lmpc_solve_kernel<KQ>, dim3(B), dim3(64), lds_bytes, h->stream, h->P, B, h->ws, x_ic, u_ic, T_ref,
-                     bl, br, vref, X, U, dU, status, iters, kkt);
-  HIP_TRY(h, hipGetLastError());
+int ks_for(int S) { return S <= 0 ? 0 : (S <= 128 ? 2 : (S <= 192 ? 3 : -1)); }
+
+struct solve_args {
+  int B;
+  size_t lds_bytes;
+  const double *x_ic, *u_ic, *T_ref, *bl, *br, *vref, *ss_x, *ss_j;
+  double *lam, *X, *U, *dU;
+  int *status, *iters;
+  double* kkt;
+};
+
+template <int KQ, int KS>
+const void* solve_fn() {
+  return reinterpret_cast<const void*>(&lmpc_solve_kernel<KQ, KS>);
+}
+
+// the (KQ, KS) instantiations that exist: KQ = ceil(11 N / 64) rounded up to {2,4,7,11,14}, KS = safe-set points / 64
+const void* pick_solve_fn(int kq, int ks) {
+  if (ks == 0) {
+    switch (kq) {
+      case 2: return solve_fn<2, 0>();
+      case 4: return solve_fn<4, 0>();
+      case 7: return solve_fn<7, 0>();
+      case 11: return solve_fn<11, 0>();
+      case 14: return solve_fn<14, 0>();
+    }
+  } else if (ks == 2) {
+    if (kq <= 4) return solve_fn<4, 2>();
+    if (kq == 7) return solve_fn<7, 2>();
+  } else if (ks == 3) {
+    if (kq <= 4) return solve_fn<4, 3>();
+    if (kq == 7) return solve_fn<7, 3>();
+  }
+  return nullptr;
+}
+
+int launch_solve(lmpc_handle* h, const void* fn, const solve_args& a) {
+  HIP_TRY(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)a.lds_bytes));
+  lmpc_params P = h->P;
+  int B = a.B;
+  const double* ws = h->ws;
+  void* args[] = {(void*)&P,        (void*)&B,      (void*)&ws,      (void*)&a.x_ic, (void*)&a.u_ic, (void*)&a.T_ref,
+                  (void*)&a.bl,     (void*)&a.br,   (void*)&a.vref,  (void*)&a.ss_x, (void*)&a.ss_j, (void*)&a.lam,
+                  (void*)&a.X,      (void*)&a.U,    (void*)&a.dU,    (void*)&a.status, (void*)&a.iters, (void*)&a.kkt};
+  HIP_TRY(h, hipLaunchKernel(fn, dim3(a.B), dim3(64), args, a.lds_bytes, h->stream));
   return LMPC_OK;
 }
 
@@ -101,6 +137,16 @@ int lmpc_create(const lmpc_config* cfg, const lmpc_vehicle* veh, int device, lmp
   if (cfg->N < 3 || kq_for(cfg->N) < 0) return fail(h, LMPC_ERR_ARGUMENT, "N must be in [3, 81]");
   if (cfg->learning && (cfg->num_ss_pts < 1 || cfg->num_ss_pts_per_lap < 1))
     return fail(h, LMPC_ERR_ARGUMENT, "learning needs num_ss_pts >= 1 and num_ss_pts_per_lap >= 1");
+  if (cfg->learning && (ks_for(cfg->num_ss_pts) < 0 || cfg->N > 40))
+    return fail(h, LMPC_ERR_UNSUPPORTED, "LMPC kernel is built for num_ss_pts <= 192 and N <= 40");
+  if (cfg->learning) {
+    bool any = false;
+    for (int k = 0; k < 6; ++k) any = any || cfg->convex_hull_slack[k] > 0.0;
+    for (int k = 0; k < 6; ++k)
+      if (any && !(cfg->convex_hull_slack[k] > 0.0))
+        return fail(h, LMPC_ERR_UNSUPPORTED, "convex_hull_slack must be positive in every component");
+    if (!any) return fail(h, LMPC_ERR_UNSUPPORTED, "hard convex-hull equality (all-zero convex_hull_slack, racing_mpc.cpp:501)");
+  }
   h->cfg = *cfg;
   h->device = device;
   lmpc_params& P = h->P;
@@ -191,7 +237,7 @@ int lmpc_reserve(lmpc_handle* h, int32_t max_batch) {
 
 int lmpc_query_launch(const lmpc_handle* h, int32_t* lds_bytes_per_problem, int32_t* threads_per_problem) {
   if (!h) return LMPC_ERR_ARGUMENT;
-  if (lds_bytes_per_problem) *lds_bytes_per_problem = lmpc_lds_doubles(h->P.N) * (int)sizeof(double);
+  if (lds_bytes_per_problem) *lds_bytes_per_problem = lmpc_lds_doubles(h->P.N, h->P.learning) * (int)sizeof(double);
   if (threads_per_problem) *threads_per_problem = 64;
   return LMPC_OK;
 }
@@ -199,16 +245,10 @@ int lmpc_query_launch(const lmpc_handle* h, int32_t* lds_bytes_per_problem, int3
 int lmpc_query_residency(lmpc_handle* h, int32_t* problems_per_cu) {
   if (!h || !problems_per_cu) return LMPC_ERR_ARGUMENT;
   HIP_TRY(h, hipSetDevice(h->device));
-  const size_t lds = (size_t)lmpc_lds_doubles(h->P.N) * sizeof(double);
+  const size_t lds = (size_t)lmpc_lds_doubles(h->P.N, h->P.learning) * sizeof(double);
   int n = 0;
-  const void* fn = nullptr;
-  switch (kq_for(h->P.N)) {
-    case 2: fn = reinterpret_cast<const void*>(&lmpc_solve_kernel<2>); break;
-    case 4: fn = reinterpret_cast<const void*>(&lmpc_solve_kernel<4>); break;
-    case 7: fn = reinterpret_cast<const void*>(&lmpc_solve_kernel<7>); break;
-    case 11: fn = reinterpret_cast<const void*>(&lmpc_solve_kernel<11>); break;
-    default: fn = reinterpret_cast<const void*>(&lmpc_solve_kernel<14>); break;
-  }
+  const void* fn = pick_solve_fn(kq_for(h->P.N), ks_for(h->P.S));
+  if (!fn) return fail(h, LMPC_ERR_UNSUPPORTED, "no kernel for this (N, num_ss_pts)");
   HIP_TRY(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, 64, lds));
   *problems_per_cu = n;
@@ -254,14 +294,10 @@ int lmpc_solve_batch(lmpc_handle* h, int32_t batch, const double* x_ic, const do
                      int32_t* status, int32_t* iters, double* kkt) {
   if (!h) return LMPC_ERR_ARGUMENT;
   (void)total_length;  // abscissa alignment (racing_mpc.cpp:219-223) shifts s only; the QP is invariant to it
-  (void)convex_combi_optm;
   if (batch < 0 || !x_ic || !u_ic || !X_ref || !U_ref || !T_ref || !bound_left || !bound_right || !curvatures ||
       !vel_ref || !X_optm || !U_optm || !dU_optm || !status || !iters)
     return fail(h, LMPC_ERR_ARGUMENT, "lmpc_solve_batch: null pointer or negative batch");
-  if (h->P.learning) {
-    if (!ss_x || !ss_j) return fail(h, LMPC_ERR_ARGUMENT, "learning=1 needs ss_x and ss_j");
-    return fail(h, LMPC_ERR_UNSUPPORTED, "LMPC terminal block (racing_mpc.cpp:479-522) not built in this round");
-  }
+  if (h->P.learning && (!ss_x || !ss_j)) return fail(h, LMPC_ERR_ARGUMENT, "learning=1 needs ss_x and ss_j");
   if (batch == 0) return LMPC_OK;
   HIP_TRY(h, hipSetDevice(h->device));
   if ((size_t)batch > h->ws_cap) {
@@ -275,16 +311,16 @@ int lmpc_solve_batch(lmpc_handle* h, int32_t batch, const double* x_ic, const do
                      curvatures, h->ws, (double*)nullptr, (double*)nullptr);
   HIP_TRY(h, hipGetLastError());
   if (h->timing) HIP_TRY(h, hipEventRecord(h->ev[1], h->stream));
-  const size_t lds_bytes = (size_t)lmpc_lds_doubles(N) * sizeof(double);
-  int rc = LMPC_ERR_ARGUMENT;
-  switch (kq_for(N)) {
-    case 2: rc = launch_solve<2>(h, batch, lds_bytes, x_ic, u_ic, T_ref, bound_left, bound_right, vel_ref, X_optm, U_optm, dU_optm, status, iters, kkt); break;
-    case 4: rc = launch_solve<4>(h, batch, lds_bytes, x_ic, u_ic, T_ref, bound_left, bound_right, vel_ref, X_optm, U_optm, dU_optm, status, iters, kkt); break;
-    case 7: rc = launch_solve<7>(h, batch, lds_bytes, x_ic, u_ic, T_ref, bound_left, bound_right, vel_ref, X_optm, U_optm, dU_optm, status, iters, kkt); break;
-    case 11: rc = launch_solve<11>(h, batch, lds_bytes, x_ic, u_ic, T_ref, bound_left, bound_right, vel_ref, X_optm, U_optm, dU_optm, status, iters, kkt); break;
-    case 14: rc = launch_solve<14>(h, batch, lds_bytes, x_ic, u_ic, T_ref, bound_left, bound_right, vel_ref, X_optm, U_optm, dU_optm, status, iters, kkt); break;
-    default: return fail(h, LMPC_ERR_ARGUMENT, "unsupported N");
-  }
+  const void* fn = pick_solve_fn(kq_for(N), ks_for(h->P.S));
+  if (!fn) return fail(h, LMPC_ERR_UNSUPPORTED, "no kernel for this (N, num_ss_pts)");
+  solve_args a{};
+  a.B = batch;
+  a.lds_bytes = (size_t)lmpc_lds_doubles(N, h->P.learning) * sizeof(double);
+  a.x_ic = x_ic; a.u_ic = u_ic; a.T_ref = T_ref; a.bl = bound_left; a.br = bound_right; a.vref = vel_ref;
+  a.ss_x = h->P.learning ? ss_x : nullptr; a.ss_j = h->P.learning ? ss_j : nullptr;
+  a.lam = h->P.learning ? convex_combi_optm : nullptr;
+  a.X = X_optm; a.U = U_optm; a.dU = dU_optm; a.status = status; a.iters = iters; a.kkt = kkt;
+  const int rc = launch_solve(h, fn, a);
   if (rc != LMPC_OK) return rc;
   if (h->timing) HIP_TRY(h, hipEventRecord(h->ev[2], h->stream));
   return LMPC_OK;

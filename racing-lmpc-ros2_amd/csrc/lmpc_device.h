@@ -34,10 +34,11 @@ struct lmpc_params {
 #define LMPC_STAGE_STRIDE 78
 #define LMPC_KNOT_STRIDE 34
 #define LMPC_TAIL_DOUBLES 320
+#define LMPC_TAIL_DOUBLES_LMPC 464  // + terminal-block scratch (PT, T, F^-1, a, ...)
 #define LMPC_LIN_RECORD 54  // per stage in the linearisation workspace: ABt[8][6] | g[6]
 
-static inline int lmpc_lds_doubles(int N) {
-  return (N - 1) * LMPC_STAGE_STRIDE + N * LMPC_KNOT_STRIDE + LMPC_TAIL_DOUBLES;
+static inline int lmpc_lds_doubles(int N, int learning) {
+  return (N - 1) * LMPC_STAGE_STRIDE + N * LMPC_KNOT_STRIDE + (learning ? LMPC_TAIL_DOUBLES_LMPC : LMPC_TAIL_DOUBLES);
 }
 
 #endif

@@ -70,6 +70,17 @@
 #define CT_HI 20
 #define CT_LO 30
 #define CT_ZERO 40  // a 0.0 entry: coefficient slot for "no term"
+#define CT_E 41     // 2 * convex_hull_slack (LMPC)
+// LMPC extension of the tail (only allocated when learning): terminal-block quantities
+#define TL_PT 320   // PT[6][6]: terminal cost-to-go contributed by the safe-set block
+#define TL_TG 356   // terminal gradient contribution  E eps + pT
+#define TL_EPS 362  // eps = (x_T - ss0) - (SS - ss0 1') lambda
+#define TL_T 368    // T = U Th^-1 U' (6x6)
+#define TL_FI 404   // F^-1, F = E^-1 + T
+#define TL_A 440    // a = U Th^-1 1
+#define TL_FIA 446  // F^-1 a
+#define TL_S11 452  // s11 = 1'M^-1 1
+#define TH_L_MIN 1e-3  // floor of the simplex rows' weight inside the Newton matrix (see oracle/c/lmpc_oracle.c)
 #define F_UP 1
 #define F_LO 2
 #define F_SIG 4
@@ -100,6 +111,86 @@ __device__ __forceinline__ double frcp(double x) {
   return __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
 }
 
+// NV independent wave sums in lock-step: the six shuffle steps of all values overlap, so the cost is
+// ~NV * 12 ds_bpermute issues + one latency chain instead of NV chains.
+template <int NV>
+__device__ __forceinline__ void wave_sum_n(double (&v)[NV]) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) v[k] += __shfl_xor(v[k], m);
+  }
+}
+
+// Inverse of a symmetric positive definite 6x6 (row-major, full storage) by Cholesky; every index is
+// a compile-time constant after unrolling, so the factor lives in registers.  Executed redundantly by
+// all lanes on wave-uniform data.
+__device__ __forceinline__ void spd_inv6(const double (&F)[36], double (&Fi)[36]) {
+  double Lc[36];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    double d = F[j * 6 + j];
+#pragma unroll
+    for (int k = 0; k < j; ++k) d -= Lc[j * 6 + k] * Lc[j * 6 + k];
+    d = sqrt(d);
+    const double id = 1.0 / d;
+    Lc[j * 6 + j] = id;  // store the reciprocal of the pivot
+#pragma unroll
+    for (int i = j + 1; i < 6; ++i) {
+      double t = F[i * 6 + j];
+#pragma unroll
+      for (int k = 0; k < j; ++k) t -= Lc[i * 6 + k] * Lc[j * 6 + k];
+      Lc[i * 6 + j] = t * id;
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 6; ++c) {
+    double y[6], x[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      double t = (i == c) ? 1.0 : 0.0;
+#pragma unroll
+      for (int k = 0; k < i; ++k) t -= Lc[i * 6 + k] * y[k];
+      y[i] = t * Lc[i * 6 + i];
+    }
+#pragma unroll
+    for (int i = 5; i >= 0; --i) {
+      double t = y[i];
+#pragma unroll
+      for (int k = i + 1; k < 6; ++k) t -= Lc[k * 6 + i] * x[k];
+      x[i] = t * Lc[i * 6 + i];
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) Fi[i * 6 + c] = x[i];
+  }
+}
+
+// LMPC simplex row j: gradient of the (eps-eliminated) terminal cost wrt lambda_j including the row's
+// barrier coefficient, bl_j = ss_j - cf_j - u_j'E eps; also returns 1/max(theta_j, floor).
+__device__ __forceinline__ double simplex_bl(double lm, double t, double l, double pprod, double ssj, const double (&u)[6],
+                                             double smu, double pm, const double* ct, const double* T, double& itf) {
+  const double it_ = frcp(t);
+  const double th = l * it_;
+  itf = frcp(fmax(th, TH_L_MIN));
+  const double cf = th * (-lm + t) + (smu - pm * pprod) * it_;
+  double ue = 0.0;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) ue += u[k] * ct[CT_E + k] * T[TL_EPS + k];
+  return ssj - cf - ue;
+}
+
+// Register-resident state of the LMPC simplex rows lambda_j >= 0 (KS safe-set points per lane); empty for
+// the tracking kernel so that it costs it nothing.
+template <int KS>
+struct SimplexRows {
+  bool on[KS];
+  double lm[KS], t[KS], l[KS], p[KS], j[KS], u[KS][6], dl[KS];
+  double ss0[6];
+  double r1;  // 1 - 1'lambda
+};
+template <>
+struct SimplexRows<0> {};
+
 struct Lds {
   double* base;
   int N;
@@ -116,7 +207,8 @@ __device__ __forceinline__ double qz_entry(const double* ct, int N, int i, int r
 
 // Backward Riccati sweep for the barrier weights currently in the knots' rhs0 region
 // (Thz @ +10..17, Thv @ +18,19, boundary weight @ KN_EY).  Leaves K, Hinv in the stage records.
-__device__ void riccati_factor(const Lds& L, int lane) {
+template <bool HAS_PT>
+__device__ void riccati_factor(const Lds& L, int lane, const double* PT) {
   const int N = L.N, r = lane >> 3, c = lane & 7;
   double* T = L.tail();
   double* MP = T + TL_P;
@@ -127,6 +219,7 @@ __device__ void riccati_factor(const Lds& L, int lane) {
     const double* kn = L.kn(N - 1);
     double e = qz_entry(ct, N, N - 1, r, c);
     if (r == c) e += kn[KN_R0 + r] + (r == 1 ? kn[KN_EY] : 0.0);
+    if (HAS_PT && r < 6 && c < 6) e += PT[r * 6 + c];  // LMPC: safe-set block condensed onto x_T
     MP[r * MROW + c] = e;
   }
   __syncthreads();
@@ -314,11 +407,12 @@ __device__ void feedback_rollout(const Lds& L, int lane) {
   }
 }
 
-template <int KQ>
-__global__ __launch_bounds__(64, (KQ <= 4 ? 2 : 1)) void lmpc_solve_kernel(
+template <int KQ, int KS>
+__global__ __launch_bounds__(64, ((KQ <= 4 && KS == 0) ? 2 : 1)) void lmpc_solve_kernel(
     lmpc_params P, int B, const double* __restrict__ ws_lin, const double* __restrict__ x_ic,
     const double* __restrict__ u_ic, const double* __restrict__ T_ref, const double* __restrict__ bl,
-    const double* __restrict__ br, const double* __restrict__ vref, double* __restrict__ X_out,
+    const double* __restrict__ br, const double* __restrict__ vref, const double* __restrict__ ss_x,
+    const double* __restrict__ ss_j, double* __restrict__ lam_out, double* __restrict__ X_out,
     double* __restrict__ U_out, double* __restrict__ dU_out, int* __restrict__ status_out,
     int* __restrict__ iters_out, double* __restrict__ kkt_out) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -364,6 +458,8 @@ __global__ __launch_bounds__(64, (KQ <= 4 ? 2 : 1)) void lmpc_solve_kernel(
       ct[CT_SV + lane - 14] = P.Sv[lane - 14];
     } else if (lane == 18) {
       ct[CT_ZERO] = 0.0;
+    } else if (lane < 25) {
+      ct[CT_E + lane - 19] = P.chs2[lane - 19];
     }
   }
   __syncthreads();
@@ -438,6 +534,29 @@ __global__ __launch_bounds__(64, (KQ <= 4 ? 2 : 1)) void lmpc_solve_kernel(
     s_lu[q] = s_ll[q] = 0.0;
     s_pu[q] = s_pl[q] = 0.0;
   }
+  // ---------------- LMPC: simplex rows lambda_j >= 0, one safe-set point per lane and k < KS ----------------
+  // (racing_mpc.cpp:484-504).  The points are centred on the first one (valid because 1'lambda = 1):
+  // all sums below then run over O(1) offsets instead of absolute abscissae.
+  const int S = P.S;
+  SimplexRows<KS> sx;
+  if constexpr (KS > 0) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) sx.ss0[k] = ss_x[((size_t)k * S) * B + b];
+#pragma unroll
+    for (int q = 0; q < KS; ++q) {
+      const int j = lane + 64 * q;
+      sx.on[q] = j < S;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) sx.u[q][k] = sx.on[q] ? ss_x[((size_t)k * S + j) * B + b] - sx.ss0[k] : 0.0;
+      sx.j[q] = sx.on[q] ? ss_j[(size_t)j * B + b] : 0.0;
+      sx.lm[q] = sx.on[q] ? 1.0 / S : 0.0;
+      sx.t[q] = sx.on[q] ? 1.0 / S : 1.0;
+      sx.l[q] = 0.0;
+      sx.p[q] = 0.0;
+      sx.dl[q] = 0.0;
+      m_rows += sx.on[q] ? 1.0 : 0.0;
+    }
+  }
   const double m_tot = wave_sum(m_rows) + (has_sigma ? 1.0 : 0.0);
   const double inv_m = 1.0 / m_tot;
 
@@ -466,9 +585,29 @@ __global__ __launch_bounds__(64, (KQ <= 4 ? 2 : 1)) void lmpc_solve_kernel(
     kn[s_wo[q]] = 0.0;
     if (s_wo[q] == KN_EY) kn[KN_CSIG] = 0.0;
   }
+  if constexpr (KS > 0) {  // lambda frozen at 1/S: terminal cost eps'D eps only
+    if (lane < 36) T[TL_PT + lane] = (lane % 7 == 0) ? ct[CT_E + lane / 7] : 0.0;
+  }
   __syncthreads();
-  riccati_factor(L, lane);
+  riccati_factor<(KS > 0)>(L, lane, T + TL_PT);
   feedback_rollout(L, lane);
+  if constexpr (KS > 0) {
+    double ul[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < KS; ++q)
+#pragma unroll
+      for (int k = 0; k < 6; ++k) ul[k] += sx.u[q][k] * sx.lm[q];
+    wave_sum_n<6>(ul);
+    if (lane < 6) {
+      double e = 0.0;
+#pragma unroll
+      for (int k = 0; k < 6; ++k)
+        if (k == lane) e = (L.kn(N - 1)[k] - sx.ss0[k]) - ul[k];
+      T[TL_EPS + lane] = e;
+      T[TL_TG + lane] = ct[CT_E + lane] * e;
+    }
+    __syncthreads();
+  }
   PT_MARK(1)
 
   const double tau = 0.995, mu0 = 1.0;
@@ -497,6 +636,76 @@ __global__ __launch_bounds__(64, (KQ <= 4 ? 2 : 1)) void lmpc_solve_kernel(
         kn[s_wo[q]] = thu + thd;
         if (s_wo[q] == KN_EY) kn[KN_CSIG] = (f & F_SIG) ? (thd - thu) : 0.0;
         eysum += (f & F_SIG) ? (thu + thd) : 0.0;
+      }
+      if constexpr (KS > 0) {
+        double tt[21], av[14];  // T (upper triangle) | a[6], sum 1/theta, U lambda [6], sum lambda
+#pragma unroll
+        for (int k = 0; k < 21; ++k) tt[k] = 0.0;
+#pragma unroll
+        for (int k = 0; k < 14; ++k) av[k] = 0.0;
+#pragma unroll
+        for (int q = 0; q < KS; ++q) {
+          const double on = sx.on[q] ? 1.0 : 0.0;
+          const double itf = on * frcp(fmax(sx.l[q] * frcp(sx.t[q]), TH_L_MIN));
+          musum += on * sx.l[q] * sx.t[q];
+          rdl = fmax(rdl, on * fabs(-sx.lm[q] + sx.t[q]));
+          int n = 0;
+#pragma unroll
+          for (int r = 0; r < 6; ++r) {
+#pragma unroll
+            for (int c = r; c < 6; ++c) tt[n++] += sx.u[q][r] * sx.u[q][c] * itf;
+            av[r] += sx.u[q][r] * itf;
+            av[7 + r] += sx.u[q][r] * sx.lm[q];
+          }
+          av[6] += itf;
+          av[13] += sx.lm[q];
+        }
+        wave_sum_n<21>(tt);
+        wave_sum_n<14>(av);
+        sx.r1 = 1.0 - av[13];
+        double F[36], Fi[36], Fia[6];
+        {
+          int n = 0;
+#pragma unroll
+          for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int c = r; c < 6; ++c) {
+              F[r * 6 + c] = tt[n];
+              F[c * 6 + r] = tt[n];
+              ++n;
+            }
+        }
+        if (lane == 0) {
+#pragma unroll
+          for (int k = 0; k < 36; ++k) T[TL_T + k] = F[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) F[k * 6 + k] += 1.0 / ct[CT_E + k];
+        spd_inv6(F, Fi);
+        double s11 = av[6];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+          double t = 0.0;
+#pragma unroll
+          for (int c = 0; c < 6; ++c) t += Fi[r * 6 + c] * av[c];
+          Fia[r] = t;
+          s11 -= av[r] * t;
+        }
+        const double is11 = 1.0 / s11;
+        if (lane == 0) {
+#pragma unroll
+          for (int r = 0; r < 6; ++r) {
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+              T[TL_FI + r * 6 + c] = Fi[r * 6 + c];
+              T[TL_PT + r * 6 + c] = Fi[r * 6 + c] + Fia[r] * Fia[c] * is11;  // PT = F^-1 + (F^-1 a)(F^-1 a)'/s11
+            }
+            T[TL_A + r] = av[r];
+            T[TL_FIA + r] = Fia[r];
+            T[TL_EPS + r] = (L.kn(N - 1)[r] - sx.ss0[r]) - av[7 + r];
+          }
+          T[TL_S11] = s11;
+        }
       }
       musum = wave_sum(musum);
       rdmax = wave_max(rdl);
@@ -528,7 +737,7 @@ __global__ __launch_bounds__(64, (KQ <= 4 ? 2 : 1)) void lmpc_solve_kernel(
       if (it == max_iter) break;
       __syncthreads();
       PT_MARK(2)
-      riccati_factor(L, lane);
+      riccati_factor<(KS > 0)>(L, lane, T + TL_PT);
       PT_MARK(3)
     }
 
@@ -539,6 +748,39 @@ __global__ __launch_bounds__(64, (KQ <= 4 ? 2 : 1)) void lmpc_solve_kernel(
       const double smu = (pass == 1) ? sigc * mu : 0.0, pm = (pass == 1) ? 1.0 : 0.0;
       // ======== gradient: cost gradient + row coefficients, written by the component owner ========
       double sgsum = 0.0;  // sum of boundary-row coefficients entering the sigma gradient
+      if constexpr (KS > 0) {
+        if (ipm) {
+          double sbl = 0.0;
+          double bs[7] = {0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+          for (int q = 0; q < KS; ++q) {
+            double itf;
+            const double w = sx.on[q] ? simplex_bl(sx.lm[q], sx.t[q], sx.l[q], sx.p[q], sx.j[q], sx.u[q], smu, pm, ct, T, itf) * itf : 0.0;
+            bs[6] += w;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) bs[k] += sx.u[q][k] * w;
+          }
+          wave_sum_n<7>(bs);
+          sbl = bs[6];
+          double Fib[6], aFib = 0.0;
+#pragma unroll
+          for (int r = 0; r < 6; ++r) {
+            double t = 0.0;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) t += T[TL_FI + r * 6 + c] * bs[c];
+            Fib[r] = t;
+            aFib += T[TL_A + r] * t;
+          }
+          const double coef = (sbl - aFib + sx.r1) / T[TL_S11];
+          if (lane < 6) {
+            double tg = 0.0;
+#pragma unroll
+            for (int k = 0; k < 6; ++k)
+              if (k == lane) tg = ct[CT_E + k] * T[TL_EPS + k] + Fib[k] - T[TL_FIA + k] * coef;
+            T[TL_TG + lane] = tg;
+          }
+        }
+      }
 #pragma unroll
       for (int q = 0; q < KQ; ++q) {
         if (s_ko[q] < 0) continue;
@@ -563,6 +805,10 @@ __global__ __launch_bounds__(64, (KQ <= 4 ? 2 : 1)) void lmpc_solve_kernel(
         double* kn = L.kn(i);
         kn[KN_R0 + 1] += kn[KN_EY];
         if (pass == 0) kn[KN_R1 + 1] = (i >= 1) ? kn[KN_CSIG] : 0.0;
+      }
+      if constexpr (KS > 0) {  // terminal gradient of the safe-set block onto x_T (lanes 0..5 != EY lanes' cells)
+        __syncthreads();
+        if (lane < 6) L.kn(N - 1)[KN_R0 + lane] += T[TL_TG + lane];
       }
       __syncthreads();
       // ======== Newton step: predictor together with the Schur vector, then the corrector ========
@@ -595,6 +841,48 @@ __global__ __launch_bounds__(64, (KQ <= 4 ? 2 : 1)) void lmpc_solve_kernel(
         for (int q = 0; q < KQ; ++q) d_val[q] = (s_ko[q] < 0) ? 0.0 : (KN0 + s_ko[q])[KN_R0 + s_vo[q]];
         break;
       }
+      if constexpr (KS > 0) {
+        // d lambda_j = (r_j - u_j'F^-1 gamma)/theta_j - Mi1_j (sr - a'F^-1 gamma - sx.r1)/s11,  r_j = u_j'E dx_T - bl_j
+        const double* knT = L.kn(N - 1);
+        double e[6], gs[7] = {0, 0, 0, 0, 0, 0, 0}, rj[KS], itfq[KS];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) e[k] = ct[CT_E + k] * (knT[KN_R0 + k] + dsigma * knT[KN_R1 + k]);
+#pragma unroll
+        for (int q = 0; q < KS; ++q) {
+          double itf;
+          double r = -simplex_bl(sx.lm[q], sx.t[q], sx.l[q], sx.p[q], sx.j[q], sx.u[q], smu, pm, ct, T, itf);
+#pragma unroll
+          for (int k = 0; k < 6; ++k) r += sx.u[q][k] * e[k];
+          r = sx.on[q] ? r : 0.0;
+          rj[q] = r;
+          itfq[q] = itf;
+          const double w = r * itf;
+          gs[6] += w;
+#pragma unroll
+          for (int k = 0; k < 6; ++k) gs[k] += sx.u[q][k] * w;
+        }
+        wave_sum_n<7>(gs);
+        double Fig[6], aFig = 0.0;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+          double t = 0.0;
+#pragma unroll
+          for (int c = 0; c < 6; ++c) t += T[TL_FI + r * 6 + c] * gs[c];
+          Fig[r] = t;
+          aFig += T[TL_A + r] * t;
+        }
+        const double coef = (gs[6] - aFig - sx.r1) / T[TL_S11];
+#pragma unroll
+        for (int q = 0; q < KS; ++q) {
+          double ug = 0.0, ua = 0.0;
+#pragma unroll
+          for (int k = 0; k < 6; ++k) {
+            ug += sx.u[q][k] * Fig[k];
+            ua += sx.u[q][k] * T[TL_FIA + k];
+          }
+          sx.dl[q] = sx.on[q] ? (rj[q] - ug) * itfq[q] - (1.0 - ua) * itfq[q] * coef : 0.0;
+        }
+      }
       // ======== row steps; largest feasible step as 1 / max(1, max -dt/t, max -dlam/lam) ========
       // (dt, dlam) of a row from the step of the value it constrains; evaluated twice (ratio scan,
       // then use) rather than kept, to stay inside the register budget of two waves per SIMD.
@@ -620,6 +908,14 @@ __global__ __launch_bounds__(64, (KQ <= 4 ? 2 : 1)) void lmpc_solve_kernel(
         rmax = fmax(rmax, fmax(-dt_ * it_, -dl_ * frcp(fmax(s_lu[q], 1e-300))));
         row_step(f & F_LO, s_tl[q], s_ll[q], s_pl[q], -val - sg + s_tl[q] + s_lo[q], -dval - dsg, dt_, dl_, it_);
         rmax = fmax(rmax, fmax(-dt_ * it_, -dl_ * frcp(fmax(s_ll[q], 1e-300))));
+      }
+      if constexpr (KS > 0) {
+#pragma unroll
+        for (int q = 0; q < KS; ++q) {
+          double dt_, dl_, it_;
+          row_step(sx.on[q], sx.t[q], sx.l[q], sx.p[q], -sx.lm[q] + sx.t[q], -sx.dl[q], dt_, dl_, it_);
+          rmax = fmax(rmax, fmax(-dt_ * it_, -dl_ * frcp(fmax(sx.l[q], 1e-300))));
+        }
       }
       rmax = wave_max(rmax);
       if (has_sigma) {
@@ -651,6 +947,21 @@ __global__ __launch_bounds__(64, (KQ <= 4 ? 2 : 1)) void lmpc_solve_kernel(
           s_lu[q] += alpha * dlu;
           s_tl[q] += alpha * dtl;
           s_ll[q] += alpha * dll;
+        }
+      }
+      if constexpr (KS > 0) {
+#pragma unroll
+        for (int q = 0; q < KS; ++q) {
+          double dt_, dl_, it_;
+          row_step(sx.on[q], sx.t[q], sx.l[q], sx.p[q], -sx.lm[q] + sx.t[q], -sx.dl[q], dt_, dl_, it_);
+          if (pass == 0) {
+            sacc += sx.on[q] ? (sx.t[q] + amax * dt_) * (sx.l[q] + amax * dl_) : 0.0;
+            sx.p[q] = dt_ * dl_;
+          } else {
+            sx.t[q] += alpha * dt_;
+            sx.l[q] += alpha * dl_;
+            sx.lm[q] += alpha * sx.dl[q];
+          }
         }
       }
       if (pass == 0) {
@@ -701,6 +1012,10 @@ __global__ __launch_bounds__(64, (KQ <= 4 ? 2 : 1)) void lmpc_solve_kernel(
       sigma = 0.0;
       ts = 0.1;
       lams = has_sigma ? mu0 / ts : 0.0;
+      if constexpr (KS > 0) {
+#pragma unroll
+        for (int q = 0; q < KS; ++q) sx.l[q] = sx.on[q] ? mu0 / sx.t[q] : 0.0;
+      }
     }
   }
   PT_MARK(7)
@@ -717,6 +1032,13 @@ __global__ __launch_bounds__(64, (KQ <= 4 ? 2 : 1)) void lmpc_solve_kernel(
     const int k = e / NS, i = e - k * NS;
     U_out[(size_t)(k * NS + i) * B + b] = L.kn(i + 1)[6 + k];
     dU_out[(size_t)(k * NS + i) * B + b] = L.kn(i)[8 + k];
+  }
+  if constexpr (KS > 0) {
+    if (lam_out) {
+#pragma unroll
+      for (int q = 0; q < KS; ++q)
+        if (sx.on[q]) lam_out[(size_t)(lane + 64 * q) * B + b] = sx.lm[q];
+    }
   }
   if (lane == 0) {
     status_out[b] = status;
@@ -743,18 +1065,21 @@ __global__ __launch_bounds__(64, (KQ <= 4 ? 2 : 1)) void lmpc_solve_kernel(
   }
 }
 
-template __global__ void lmpc_solve_kernel<2>(lmpc_params, int, const double*, const double*, const double*,
-                                              const double*, const double*, const double*, const double*, double*,
-                                              double*, double*, int*, int*, double*);
-template __global__ void lmpc_solve_kernel<4>(lmpc_params, int, const double*, const double*, const double*,
-                                              const double*, const double*, const double*, const double*, double*,
-                                              double*, double*, int*, int*, double*);
-template __global__ void lmpc_solve_kernel<7>(lmpc_params, int, const double*, const double*, const double*,
-                                              const double*, const double*, const double*, const double*, double*,
-                                              double*, double*, int*, int*, double*);
-template __global__ void lmpc_solve_kernel<11>(lmpc_params, int, const double*, const double*, const double*,
-                                               const double*, const double*, const double*, const double*, double*,
-                                               double*, double*, int*, int*, double*);
-template __global__ void lmpc_solve_kernel<14>(lmpc_params, int, const double*, const double*, const double*,
-                                               const double*, const double*, const double*, const double*, double*,
-                                               double*, double*, int*, int*, double*);
+template __global__ void lmpc_solve_kernel<2, 0>(lmpc_params, int, const double*, const double*, const double*, const double*, const double*, const double*,
+    const double*, const double*, const double*, double*, double*, double*, double*, int*, int*, double*);
+template __global__ void lmpc_solve_kernel<4, 0>(lmpc_params, int, const double*, const double*, const double*, const double*, const double*, const double*,
+    const double*, const double*, const double*, double*, double*, double*, double*, int*, int*, double*);
+template __global__ void lmpc_solve_kernel<7, 0>(lmpc_params, int, const double*, const double*, const double*, const double*, const double*, const double*,
+    const double*, const double*, const double*, double*, double*, double*, double*, int*, int*, double*);
+template __global__ void lmpc_solve_kernel<11, 0>(lmpc_params, int, const double*, const double*, const double*, const double*, const double*, const double*,
+    const double*, const double*, const double*, double*, double*, double*, double*, int*, int*, double*);
+template __global__ void lmpc_solve_kernel<14, 0>(lmpc_params, int, const double*, const double*, const double*, const double*, const double*, const double*,
+    const double*, const double*, const double*, double*, double*, double*, double*, int*, int*, double*);
+template __global__ void lmpc_solve_kernel<4, 2>(lmpc_params, int, const double*, const double*, const double*, const double*, const double*, const double*,
+    const double*, const double*, const double*, double*, double*, double*, double*, int*, int*, double*);
+template __global__ void lmpc_solve_kernel<4, 3>(lmpc_params, int, const double*, const double*, const double*, const double*, const double*, const double*,
+    const double*, const double*, const double*, double*, double*, double*, double*, int*, int*, double*);
+template __global__ void lmpc_solve_kernel<7, 2>(lmpc_params, int, const double*, const double*, const double*, const double*, const double*, const double*,
+    const double*, const double*, const double*, double*, double*, double*, double*, int*, int*, double*);
+template __global__ void lmpc_solve_kernel<7, 3>(lmpc_params, int, const double*, const double*, const double*, const double*, const double*, const double*,
+    const double*, const double*, const double*, double*, double*, double*, double*, int*, int*, double*);

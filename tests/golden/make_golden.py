@@ -23,6 +23,29 @@ CASES = {
     "qp_iac_tracking_n40": (OP.iac_vehicle(), OP.iac_tracking_mpc(40), "putnam", 8, 9),
 }
 
+# ---- LMPC (safe set from the reference's recorded laps) ----
+sys.path.insert(0, str(ROOT / "tests"))
+import lmpc_scenario as LS  # noqa: E402
+
+veh, cfg, tr, laps, inp, q = LS.make(16, 5)
+ss_x, ss_j, nf = LS.oracle_safe_set(cfg, laps, q)
+N, B = cfg.N, 16
+X = np.zeros((6, N, B)); U = np.zeros((2, N - 1, B)); dU = np.zeros((2, N - 1, B)); obj = np.zeros(B); ok = np.zeros(B, bool)
+cert = np.zeros((4, B))
+for b in range(B):
+    qp = OQ.build_qp(cfg, veh, OS.problem(inp, b), ss_x=ss_x[:, :, b], ss_j=ss_j[:, b])
+    y, info = OQ.solve_dense(qp)
+    o = qp.split(y)
+    X[:, :, b], U[:, :, b], dU[:, :, b] = o["X_optm"], o["U_optm"], o["dU_optm"]
+    obj[b] = qp.objective(y)
+    c = OQ.kkt_certificate(qp, y)
+    cert[:, b] = [c["stat"], c["eq"], c["ineq"], c["comp"]]
+    ok[b] = info["status"] == 0
+    print("qp_barc_lmpc_n20", b, info["status"], info.get("polished"), c)
+np.savez_compressed(Path(__file__).parent / "qp_barc_lmpc_n20.npz", X_optm=X, U_optm=U, dU_optm=dU, objective=obj,
+                    kkt_cert=cert, certified=ok, ss_x=ss_x, ss_j=ss_j, query=q,
+                    **{k: np.asarray(v) for k, v in inp.items()})
+
 for name, (veh, cfg, kind, B, seed) in CASES.items():
     tr = wl.synthetic_track(kind)
     u_lo, u_hi, _, _ = OQ.effective_bounds(cfg, veh)

@@ -170,3 +170,46 @@ def test_ss_query_matches_oracle(pkg):
         assert np.array_equal(nf, rn)
         assert np.array_equal(ss_x, rx)  # gathered values: bit exact
         assert np.array_equal(ss_j, rj)
+
+
+def test_lmpc_solve_matches_golden_and_twin(pkg, golden):
+    """BASELINE config 3 path: safe-set query kernel -> LMPC QP kernel, against the certified optimum."""
+    import lmpc_scenario as LS
+    g = golden("qp_barc_lmpc_n20")
+    veh, cfg = P.barc_vehicle(), P.barc_lmpc(20, 3)
+    solver = pkg.Solver(pkg.presets.barc_lmpc(20, 3), pkg.presets.barc_vehicle(), device=0)
+    solver.set_safe_set(LS.load_laps(), LS.L_BARC_SS)
+    ss_x, ss_j, nf = solver.ss_query(g["query"])
+    assert np.array_equal(ss_x.cpu().numpy(), g["ss_x"]) and np.array_equal(ss_j.cpu().numpy(), g["ss_j"])
+    out = solver.alloc_outputs(g["x_ic"].shape[1])
+    import torch
+    out["convex_combi_optm"] = torch.zeros((96, g["x_ic"].shape[1]), dtype=torch.float64, device="cuda")
+    o = to_np(solver.solve(g, out, ss_x=ss_x, ss_j=ss_j))
+    assert (o["status"] == 0).all(), o["status"]
+    assert scaled_err(o["X_optm"], g["X_optm"], P.SCALE_X) < 1e-6
+    assert scaled_err(o["U_optm"], g["U_optm"], P.SCALE_U) < 1e-6
+    assert scaled_err(o["dU_optm"], g["dU_optm"], P.SCALE_U) < 1e-5
+    lam = o["convex_combi_optm"]
+    assert np.abs(lam.sum(0) - 1.0).max() < 1e-9 and lam.min() > -1e-12
+    twin = cbind.solve_batch(cfg, veh, g, ss_x=g["ss_x"], ss_j=g["ss_j"])
+    assert np.abs(o["iters"] - twin["iters"]).max() <= 1
+
+
+def test_lmpc_full_batch(pkg):
+    import lmpc_scenario as LS
+    veh, cfg, tr, laps, inp, q = LS.make(2048, 9)
+    solver = pkg.Solver(pkg.presets.barc_lmpc(20, 3), pkg.presets.barc_vehicle(), device=0)
+    solver.set_safe_set(laps, LS.L_BARC_SS)
+    ss_x, ss_j, nf = solver.ss_query(q)
+    import torch
+    out = solver.alloc_outputs(2048)
+    out["convex_combi_optm"] = torch.zeros((96, 2048), dtype=torch.float64, device="cuda")
+    o = to_np(solver.solve(inp, out, ss_x=ss_x, ss_j=ss_j))
+    assert (o["status"] == 0).mean() > 0.995, np.bincount(o["status"])
+    ok = o["status"] == 0
+    lam = o["convex_combi_optm"][:, ok]
+    assert np.abs(lam.sum(0) - 1.0).max() < 1e-8 and lam.min() > -1e-10
+    sub = {k: (v[..., :64] if isinstance(v, np.ndarray) else v) for k, v in inp.items()}
+    twin = cbind.solve_batch(cfg, veh, sub, ss_x=ss_x.cpu().numpy()[..., :64], ss_j=ss_j.cpu().numpy()[..., :64])
+    same = (twin["status"] == 0) & ok[:64]
+    assert np.abs((o["X_optm"][:, :, :64] - twin["X_optm"]) / P.SCALE_X[:, None, None])[:, :, same].max() < 1e-6

@@ -70,3 +70,17 @@ def test_infeasible_initial_state_is_reported():
     inp = S.cold_start_inputs(cfg, veh, tr, x, np.zeros((2, 2)), 0.025)
     out = cbind.solve_batch(cfg, veh, inp)
     assert out["status"][0] == 2 and out["status"][1] == 0
+
+
+def test_lmpc_golden_and_c_twin(golden):
+    """LMPC terminal block (racing_mpc.cpp:479-522): certified dense optimum vs the structured C twin."""
+    g = golden("qp_barc_lmpc_n20")
+    veh, cfg = P.barc_vehicle(), P.barc_lmpc(20, 3)
+    assert g["certified"].all() and g["kkt_cert"][0].max() < 1e-9
+    out = cbind.solve_batch(cfg, veh, g, ss_x=g["ss_x"], ss_j=g["ss_j"])
+    assert (out["status"] == 0).all() and out["iters"].max() <= 25
+    assert scaled_err(out["X_optm"], g["X_optm"], P.SCALE_X) < 1e-6
+    assert scaled_err(out["U_optm"], g["U_optm"], P.SCALE_U) < 1e-6
+    assert scaled_err(out["dU_optm"], g["dU_optm"], P.SCALE_U) < 1e-5
+    lam = out["convex_combi_optm"]
+    assert np.abs(lam.sum(0) - 1.0).max() < 1e-9 and lam.min() > -1e-12
