@@ -24,6 +24,19 @@ ALGO_BYTES_PER_SOLVE = (13 * 20 + 5) * 8 + (10 * 20 - 4) * 8 + 8  # 3696 B at N 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
 
 
+def measured_traffic_bytes():
+    """HBM bytes per launch of the QP kernel from the committed rocprofv3 PMC passes of this same command
+    (profiles/r01_pmc.json: FETCH_SIZE and WRITE_SIZE are reported in KiB, collected in separate --pmc runs).
+    The gfx950 FETCH_SIZE x2 correction of MI355X_MICROARCH.md applies to wide coalesced streams only; this
+    kernel's reads are 8-byte strided or L2/MALL-resident workspace lines, so the raw counter is reported."""
+    try:
+        pmc = json.load(open(ROOT / "profiles" / "r01_pmc.json"))
+        k = next(v for n, v in pmc.items() if n.startswith("lmpc_solve_kernel<4, 0>"))
+        return (k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0
+    except Exception:
+        return None
+
+
 def shard_bounds(total: int, world: int, rank: int):
     """Contiguous slice [lo, hi) of `total` problems owned by `rank` (sizes differ by at most one)."""
     base, rem = divmod(total, world)
@@ -96,6 +109,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--horizon", type=int, default=20)
+    ap.add_argument("--workload", choices=["tracking", "lmpc"], default="tracking",
+                    help="tracking = BASELINE configs[1] (the quoted metric); lmpc = configs[2] (5-lap safe set)")
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL result gather for N > 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -116,16 +131,32 @@ def main():
 
     pkg = load_package()
     N, B = args.horizon, args.batch
-    solver = pkg.Solver(pkg.presets.barc_tracking_mpc(N), pkg.presets.barc_vehicle(), device=local)
-    solver.reserve(B)
+    lmpc = args.workload == "lmpc"
     tr = pkg.workloads.synthetic_track("barc")
-    P = solver.config
-    u_lo = [max(P["u_min"][0], -0.015), max(P["u_min"][1], -0.314159)]
-    u_hi = [min(P["u_max"][0], 0.015), min(P["u_max"][1], 0.314159)]
-    x, u = pkg.workloads.sample_initial_states("barc", B, tr["L"], u_lo, u_hi, seed=rank)
+    if lmpc:
+        cfgd = pkg.presets.barc_lmpc(N, 5)  # 5 laps stored, 32 per lap -> 160 points
+        solver = pkg.Solver(cfgd, pkg.presets.barc_vehicle(), device=local)
+        laps = pkg.workloads.synthetic_laps(tr, 5)
+        solver.set_safe_set(laps, tr["L"])
+        x, u = pkg.workloads.sample_states_near_laps(laps, B, tr["L"], seed=rank)
+    else:
+        solver = pkg.Solver(pkg.presets.barc_tracking_mpc(N), pkg.presets.barc_vehicle(), device=local)
+        P = solver.config
+        u_lo = [max(P["u_min"][0], -0.015), max(P["u_min"][1], -0.314159)]
+        u_hi = [min(P["u_max"][0], 0.015), min(P["u_max"][1], 0.314159)]
+        x, u = pkg.workloads.sample_initial_states("barc", B, tr["L"], u_lo, u_hi, seed=rank)
+    solver.reserve(B)
     inp = solver.prepare(tr, x.T.copy(), 0.025)   # node cold start on the device (racing_mpc_node.cpp:210-292)
     inp["u_ic"] = torch.as_tensor(u.T.copy(), dtype=torch.float64, device=dev)
     outs = [solver.alloc_outputs(B), solver.alloc_outputs(B)]
+    query = None
+    if lmpc:
+        for o in outs:
+            o["convex_combi_optm"] = torch.zeros((cfgd["num_ss_pts"], B), dtype=torch.float64, device=dev)
+        # query = last knot of the abscissa-aligned reference (racing_mpc.cpp:219-223,249-254)
+        s_last, s0, L = inp["X_ref"][0, -1], inp["x_ic"][0], tr["L"]
+        kk = (s0 - s_last).abs() + L / 2
+        query = torch.stack([s_last + (kk - torch.fmod(kk, L)) * torch.sign(s0 - s_last), inp["X_ref"][1, -1]]).contiguous()
     gather = world > 1 and not args.no_gather
     if gather:
         import torch.distributed as dist
@@ -134,7 +165,11 @@ def main():
 
     def step(k, handle_prev):
         o = outs[k & 1]
-        solver.solve(inp, o)
+        if lmpc:
+            ss_x, ss_j, _ = solver.ss_query(query)
+            solver.solve(inp, o, ss_x=ss_x, ss_j=ss_j)
+        else:
+            solver.solve(inp, o)
         if gather:
             if handle_prev is not None:
                 handle_prev.wait()
@@ -175,7 +210,7 @@ def main():
         for k in range(n_lat):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            solver.solve(inp, outs[0])
+            step(0, None)
             e1.record()
             e1.synchronize()
             lat.append(e0.elapsed_time(e1))
@@ -191,13 +226,18 @@ def main():
     if rank == 0:
         value = world * B * args.steps / elapsed
         sol_avg = float(np.mean(sol_ms))
-        achieved = ALGO_BYTES_PER_SOLVE * B / (sol_avg * 1e-3) / 1e9
+        algo_bytes = ((13 * N + 5) + (10 * N - 4)) * 8 + 8
+        if lmpc:
+            algo_bytes += (7 + 1) * 160 * 8  # + ss_x, ss_j in and lambda out (13 936 B at S = 160)
+        achieved = algo_bytes * B / (sol_avg * 1e-3) / 1e9
         res = {
             "metric": "QP solves/sec (nx=6,nu=2,N=%d)" % N, "value": value, "unit": "solves/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "BARC tracking MPC, batch=%d random x0 per GPU, N=%d, fp64 (BASELINE configs[1])" % (B, N),
+            "config": {"workload": ("BARC LMPC with 5-lap safe set (160 points), batch=%d per GPU, N=%d, fp64: safe-set kNN kernel + "
+                                    "QP kernel per step (BASELINE configs[2])" if lmpc else
+                                    "BARC tracking MPC, batch=%d random x0 per GPU, N=%d, fp64 (BASELINE configs[1])") % (B, N),
                        "batch_per_gpu": B, "horizon": N, "result_gather": "rccl all_gather (async)" if gather else "none"},
             "p50_solve_ms": float(np.percentile(lat, 50)), "p99_solve_ms": float(np.percentile(lat, 99)),
             "latency_samples": len(lat),
@@ -205,11 +245,13 @@ def main():
             "kernels_ms": {"linearize": float(np.mean(lin_ms)), "qp_solve": sol_avg},
             "launch": solver.launch_info(),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "note": "algorithmic bytes 3696 B/solve x batch / lmpc_solve_kernel time; the kernel is "
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None if (lmpc or N != 20 or B != 4096) else measured_traffic_bytes(),
+                         "algorithmic_bytes_per_solve": algo_bytes,
+                         "note": "algorithmic bytes x batch / lmpc_solve_kernel time; the kernel is "
                                  "FP64-VALU/LDS-latency bound (DESIGN.md), HBM fraction is reported as required"},
         }
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and not lmpc:
             res["cpu_baseline"] = cpu_baseline(pkg, N, B)
         print(json.dumps(res))
     if world > 1:

@@ -54,3 +54,28 @@ def sample_initial_states(kind: str, batch: int, L: float, u_lo, u_hi, seed: int
         raise ValueError(kind)
     u = np.clip(u, np.asarray(u_lo), np.asarray(u_hi))
     return x, u
+
+
+def synthetic_laps(track: dict, n_laps: int = 5, n_pts: int = 440, v0: float = 1.4):
+    """Recorded-lap stand-ins for the LMPC safe set: n_pts samples per lap
+    along the track, a small lateral weave that differs per lap, speed rising from lap to lap
+    (statistics of the reference's barc_ss laps: ~440 samples, v ~ 1.5 m/s, |e_y| < 0.1)."""
+    L, M = float(track["L"]), int(track["M"])
+    laps = []
+    for l in range(n_laps):
+        s = (np.arange(n_pts) + 0.37) * L / n_pts
+        k = np.interp(s, np.arange(M) * L / M, track["curvature"], period=L)
+        vx = np.full(n_pts, v0 + 0.05 * l)
+        ey = 0.06 * np.sin(2 * np.pi * 3 * s / L + 0.9 * l)
+        epsi = 0.06 * (2 * np.pi * 3 / L) * np.cos(2 * np.pi * 3 * s / L + 0.9 * l)
+        laps.append(np.stack([s, ey, epsi, vx, np.zeros(n_pts), k * vx], axis=1))
+    return laps
+
+
+def sample_states_near_laps(laps, batch: int, L: float, seed: int = 0):
+    rng = np.random.default_rng(seed)
+    lap = laps[-1]
+    idx = rng.integers(0, lap.shape[0], batch)
+    x = lap[idx] + rng.normal(0, 1, (batch, 6)) * np.array([0.0, 0.03, 0.03, 0.1, 0.02, 0.1])
+    x[:, 0] = np.mod(x[:, 0], L)
+    return x, np.zeros((batch, 2))

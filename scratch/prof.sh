@@ -2,7 +2,8 @@
 # rocprofv3 kernel trace + counters for the bench command (run on the GPU box from the repo root)
 export TMPDIR=/tmp
 ROOT=$(pwd)
-OUT=$ROOT/gpurun_out/prof
+TAG=${1:-run}
+OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o run -- python $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $OUT/trace.log 2>&1
@@ -11,4 +12,5 @@ rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_V
 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc3 -o run -- python $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $OUT/pmc3.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc4 -o run -- python $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $OUT/pmc4.log 2>&1
 cd $ROOT
-find $OUT -name "*.csv" | head -30
+python scratch/prof_summary.py $OUT > $OUT/summary.md
+cat $OUT/summary.md
