@@ -109,8 +109,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--horizon", type=int, default=20)
-    ap.add_argument("--workload", choices=["tracking", "lmpc"], default="tracking",
-                    help="tracking = BASELINE configs[1] (the quoted metric); lmpc = configs[2] (5-lap safe set)")
+    ap.add_argument("--workload", choices=["tracking", "lmpc", "iac"], default="tracking",
+                    help="tracking = BASELINE configs[1] (the quoted metric); lmpc = configs[2] (5-lap safe set); "
+                         "iac = configs[3]'s problem (IAC/Putnam tracking, use --horizon 40 --batch 8192) in fp64")
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL result gather for N > 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -132,13 +133,17 @@ def main():
     pkg = load_package()
     N, B = args.horizon, args.batch
     lmpc = args.workload == "lmpc"
-    tr = pkg.workloads.synthetic_track("barc")
+    iac = args.workload == "iac"
+    tr = pkg.workloads.synthetic_track("putnam" if iac else "barc")
     if lmpc:
         cfgd = pkg.presets.barc_lmpc(N, 5)  # 5 laps stored, 32 per lap -> 160 points
         solver = pkg.Solver(cfgd, pkg.presets.barc_vehicle(), device=local)
         laps = pkg.workloads.synthetic_laps(tr, 5)
         solver.set_safe_set(laps, tr["L"])
         x, u = pkg.workloads.sample_states_near_laps(laps, B, tr["L"], seed=rank)
+    elif iac:
+        solver = pkg.Solver(pkg.presets.iac_tracking_mpc(N), pkg.presets.iac_vehicle(), device=local)
+        x, u = pkg.workloads.sample_initial_states("putnam", B, tr["L"], [-10.0, -0.314159], [5.0, 0.314159], seed=rank + 1)
     else:
         solver = pkg.Solver(pkg.presets.barc_tracking_mpc(N), pkg.presets.barc_vehicle(), device=local)
         P = solver.config
@@ -237,6 +242,7 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": ("BARC LMPC with 5-lap safe set (160 points), batch=%d per GPU, N=%d, fp64: safe-set kNN kernel + "
                                     "QP kernel per step (BASELINE configs[2])" if lmpc else
+                                    "IAC Putnam tracking MPC, batch=%d per GPU, N=%d, fp64 (problem of BASELINE configs[3]; fp32 not built)" if iac else
                                     "BARC tracking MPC, batch=%d random x0 per GPU, N=%d, fp64 (BASELINE configs[1])") % (B, N),
                        "batch_per_gpu": B, "horizon": N, "result_gather": "rccl all_gather (async)" if gather else "none"},
             "p50_solve_ms": float(np.percentile(lat, 50)), "p99_solve_ms": float(np.percentile(lat, 99)),
@@ -251,7 +257,7 @@ def main():
                          "note": "algorithmic bytes x batch / lmpc_solve_kernel time; the kernel is "
                                  "FP64-VALU/LDS-latency bound (DESIGN.md), HBM fraction is reported as required"},
         }
-        if not args.no_cpu_baseline and world == 1 and not lmpc:
+        if not args.no_cpu_baseline and world == 1 and not lmpc and not iac:
             res["cpu_baseline"] = cpu_baseline(pkg, N, B)
         print(json.dumps(res))
     if world > 1:

@@ -196,6 +196,23 @@ int lmpc_prepare_batch(lmpc_handle* h, int32_t batch, const lmpc_track* track, c
                        double* U_ref, double* T_ref, double* bound_left, double* bound_right,
                        double* curvatures, double* vel_ref);
 
+/* Warm-start shift of RacingMPCNode::on_step_timer (racing_mpc_node.cpp:245-254, 261-292): the previous
+ * solution moves one knot forward, the last input is repeated, the last state is rolled out with the model
+ * and the references are re-sampled at the shifted abscissa.  Per problem, `status` (may be NULL) selects the
+ * previous solution (X_sol, U_sol; status 0) or the previous reference (X_old, U_old) when the solve failed
+ * (racing_mpc_node.cpp:322-332).  Outputs must not alias inputs. */
+int lmpc_shift_batch(lmpc_handle* h, int32_t batch, const lmpc_track* track, const double* X_sol,
+                     const double* U_sol, const double* X_old, const double* U_old, const int32_t* status,
+                     double dt, double speed_scale, double speed_limit, double* X_ref, double* U_ref,
+                     double* T_ref, double* bound_left, double* bound_right, double* curvatures,
+                     double* vel_ref);
+
+/* Plant step of RacingSimulator::step (racing_simulator.cpp:46-69,97-112): x [6][B] advanced in place by
+ * `n_sub` RK4 sub-steps of dt_sim with u [2][B] held, curvature looked up at the current abscissa, abscissa
+ * wrapped into [0, L). */
+int lmpc_plant_step_batch(lmpc_handle* h, int32_t batch, const lmpc_track* track, double* x,
+                          const double* u, double dt_sim, int32_t n_sub);
+
 /* Grow the handle's device workspace (stage linearisations, 432 B per stage per problem) so
  * that no later *_batch call with batch <= max_batch allocates. */
 int lmpc_reserve(lmpc_handle* h, int32_t max_batch);

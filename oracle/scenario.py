@@ -69,3 +69,49 @@ def problem(inputs: dict, b: int) -> dict:
         "curvatures": inputs["curvatures"][:, b], "vel_ref": inputs["vel_ref"][:, b],
         "L": inputs["L"],
     }
+
+
+def _sample_refs(cfg, track, X, speed_scale, speed_limit):
+    L = float(track["L"])
+    s = X[:, :, 0]
+    bl = track_lookup(track["bound_left"], s, L)
+    br = track_lookup(track["bound_right"], s, L)
+    kap = track_lookup(track["curvature"], s, L)
+    vr = track_lookup(track["vel"], s, L) * speed_scale
+    cur = X[:, :, 3]
+    d = cfg.max_vel_ref_diff
+    lim = np.clip(speed_limit, cur - d, cur + d)
+    vref = np.where(vr > 0.0, np.minimum(np.clip(vr, cur - d, cur + d), lim), lim)
+    return bl, br, kap, vref
+
+
+def shift_inputs(cfg: MPCConfig, veh: Vehicle, track: dict, X_prev, U_prev, dt: float,
+                 speed_scale: float = 1.0, speed_limit: float | None = None) -> dict:
+    """racing_mpc_node.cpp:245-254: shift the previous plan one knot, repeat the last input, roll out the last
+    state, re-sample the references (:261-292).  X_prev [6][N][B], U_prev [2][N-1][B]."""
+    N, L = cfg.N, float(track["L"])
+    if speed_limit is None:
+        speed_limit = float(cfg.x_max[3])
+    X = np.empty_like(X_prev)
+    U = np.empty_like(U_prev)
+    X[:, :N - 1] = X_prev[:, 1:]
+    U[:, :N - 2] = U_prev[:, 1:]
+    U[:, N - 2] = U_prev[:, N - 2]
+    k_last = track_lookup(track["curvature"], X[0, N - 2], L)
+    X[:, N - 1] = dyn.rk4(X[:, N - 2].T, U[:, N - 2].T, k_last, dt, veh).T
+    bl, br, kap, vref = _sample_refs(cfg, track, X.transpose(1, 2, 0), speed_scale, speed_limit)
+    return {"X_ref": X, "U_ref": U, "T_ref": np.full((N - 1, X.shape[2]), dt), "bound_left": bl,
+            "bound_right": br, "curvatures": kap, "vel_ref": vref, "L": L}
+
+
+def plant_step(veh: Vehicle, track: dict, x, u, dt_sim: float, n_sub: int = 1):
+    """racing_simulator.cpp:97-112 with the abscissa wrap of :61-64.  x (B, 6), u (B, 2)."""
+    L = float(track["L"])
+    x = np.array(x, dtype=np.float64)
+    for _ in range(n_sub):
+        small = np.abs(x[:, 3]) < 1e-6
+        x[small, 3] = np.copysign(1e-6, x[small, 3])
+        k = track_lookup(track["curvature"], x[:, 0], L)
+        x = dyn.rk4(x, u, k, dt_sim, veh)
+        x[:, 0] = dyn.align_abscissa(x[:, 0], L / 2.0, L)
+    return x

@@ -18,7 +18,8 @@ SOLVE_OPTIMAL, SOLVE_MAX_ITER, SOLVE_INFEASIBLE = 0, 1, 2
 _ABI_SYMBOLS = ("lmpc_create", "lmpc_destroy", "lmpc_last_error", "lmpc_set_stream", "lmpc_synchronize",
                 "lmpc_linearize_batch", "lmpc_solve_batch", "lmpc_set_safe_set", "lmpc_ss_query_batch",
                 "lmpc_prepare_batch", "lmpc_reserve", "lmpc_query_launch", "lmpc_enable_timing",
-                "lmpc_last_kernel_ms", "lmpc_query_residency", "lmpc_solve_host")
+                "lmpc_last_kernel_ms", "lmpc_query_residency", "lmpc_solve_host", "lmpc_shift_batch",
+                "lmpc_plant_step_batch")
 
 
 class LmpcError(RuntimeError):
@@ -102,6 +103,7 @@ class Solver:
         self._torch = torch
         self.lib = load_library()
         self.config = dict(config)
+        self.vehicle = dict(vehicle)
         self.N = int(config["N"])
         self.device = torch.device("cuda", device)
         self._h = C.c_void_p(0)
@@ -189,6 +191,52 @@ class Solver:
         out["x_ic"] = x_ic
         out["L"] = float(track["L"])
         return out
+
+    def _ctrack(self, track: dict):
+        tabs = {k: self._t(track[k]) for k in ("curvature", "bound_left", "bound_right", "vel")}
+        ct = CTrack(float(track["L"]), int(tabs["curvature"].numel()), 0, tabs["curvature"].data_ptr(),
+                    tabs["bound_left"].data_ptr(), tabs["bound_right"].data_ptr(), tabs["vel"].data_ptr())
+        self._track_keepalive = tabs
+        return ct
+
+    def device_track(self, track: dict) -> dict:
+        """Upload the track tables once; the returned dict can be passed wherever `track` is expected."""
+        out = {k: self._t(track[k]) for k in ("curvature", "bound_left", "bound_right", "vel")}
+        out["L"] = float(track["L"])
+        out["M"] = int(track["M"])
+        return out
+
+    # ---- warm-start shift (racing_mpc_node.cpp:245-254,261-292) ----
+    def shift(self, track: dict, prev_inp: dict, sol: dict, dt: float, speed_scale: float = 1.0,
+              speed_limit: float | None = None):
+        torch = self._torch
+        self.use_current_stream()
+        ct = self._ctrack(track)
+        N = self.N
+        B = sol["X_optm"].shape[2]
+        if speed_limit is None:
+            speed_limit = float(self.config["x_max"][3])
+        kw = dict(dtype=torch.float64, device=self.device)
+        out = {"X_ref": torch.empty((6, N, B), **kw), "U_ref": torch.empty((2, N - 1, B), **kw),
+               "T_ref": torch.empty((N - 1, B), **kw), "bound_left": torch.empty((N, B), **kw),
+               "bound_right": torch.empty((N, B), **kw), "curvatures": torch.empty((N, B), **kw),
+               "vel_ref": torch.empty((N, B), **kw), "L": float(track["L"])}
+        rc = self.lib.lmpc_shift_batch(self._h, C.c_int32(B), C.byref(ct), _ptr(sol["X_optm"]), _ptr(sol["U_optm"]),
+                                       _ptr(prev_inp["X_ref"]), _ptr(prev_inp["U_ref"]), _ptr(sol["status"]),
+                                       C.c_double(dt), C.c_double(speed_scale), C.c_double(speed_limit),
+                                       *[_ptr(out[k]) for k in ("X_ref", "U_ref", "T_ref", "bound_left",
+                                                                "bound_right", "curvatures", "vel_ref")])
+        self._check(rc, "lmpc_shift_batch")
+        return out
+
+    # ---- plant (racing_simulator.cpp:97-112) ----
+    def plant_step(self, track: dict, x, u, dt_sim: float, n_sub: int = 1):
+        self.use_current_stream()
+        ct = self._ctrack(track)
+        rc = self.lib.lmpc_plant_step_batch(self._h, C.c_int32(x.shape[1]), C.byref(ct), _ptr(x), _ptr(u),
+                                            C.c_double(dt_sim), C.c_int32(n_sub))
+        self._check(rc, "lmpc_plant_step_batch")
+        return x
 
     # ---- discrete_dynamics_jacobian (single_track_planar_model.cpp:377-387) ----
     def linearize(self, inp: dict):

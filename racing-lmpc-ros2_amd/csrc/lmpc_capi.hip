@@ -20,6 +20,10 @@ __global__ void lmpc_linearize_kernel(lmpc_params, int, const double*, const dou
                                       double*, double*, double*);
 __global__ void lmpc_prepare_kernel(lmpc_params, int, lmpc_track, const double*, double, double, double, double*,
                                     double*, double*, double*, double*, double*, double*);
+__global__ void lmpc_shift_kernel(lmpc_params, int, lmpc_track, const double*, const double*, const double*,
+                                  const double*, const int*, double, double, double, double*, double*, double*, double*,
+                                  double*, double*, double*);
+__global__ void lmpc_plant_kernel(lmpc_params, int, lmpc_track, double*, const double*, double, int);
 template <int KQ, int KS>
 __global__ void lmpc_solve_kernel(lmpc_params, int, const double*, const double*, const double*, const double*,
                                   const double*, const double*, const double*, const double*, const double*, double*,
@@ -403,6 +407,42 @@ int lmpc_prepare_batch(lmpc_handle* h, int32_t batch, const lmpc_track* track, c
   HIP_TRY(h, hipSetDevice(h->device));
   hipLaunchKernelGGL(lmpc_prepare_kernel, dim3((batch + 255) / 256), dim3(256), 0, h->stream, h->P, batch, *track, x_ic,
                      dt, speed_scale, speed_limit, X_ref, U_ref, T_ref, bound_left, bound_right, curvatures, vel_ref);
+  HIP_TRY(h, hipGetLastError());
+  return LMPC_OK;
+}
+
+static bool track_ok(const lmpc_track* t) {
+  return t && t->curvature && t->bound_left && t->bound_right && t->vel && t->M >= 2 && t->L > 0.0;
+}
+
+int lmpc_shift_batch(lmpc_handle* h, int32_t batch, const lmpc_track* track, const double* X_sol, const double* U_sol,
+                     const double* X_old, const double* U_old, const int32_t* status, double dt, double speed_scale,
+                     double speed_limit, double* X_ref, double* U_ref, double* T_ref, double* bound_left,
+                     double* bound_right, double* curvatures, double* vel_ref) {
+  if (!h) return LMPC_ERR_ARGUMENT;
+  if (batch < 0 || !track_ok(track) || !X_sol || !U_sol || !X_ref || !U_ref || !T_ref || !bound_left || !bound_right ||
+      !curvatures || !vel_ref || !(dt > 0.0) || (status && (!X_old || !U_old)))
+    return fail(h, LMPC_ERR_ARGUMENT, "lmpc_shift_batch: bad argument");
+  if (X_ref == X_sol || X_ref == X_old || U_ref == U_sol || U_ref == U_old)
+    return fail(h, LMPC_ERR_ARGUMENT, "lmpc_shift_batch: outputs must not alias inputs");
+  if (batch == 0) return LMPC_OK;
+  HIP_TRY(h, hipSetDevice(h->device));
+  hipLaunchKernelGGL(lmpc_shift_kernel, dim3((batch + 255) / 256), dim3(256), 0, h->stream, h->P, batch, *track, X_sol,
+                     U_sol, X_old ? X_old : X_sol, U_old ? U_old : U_sol, status, dt, speed_scale, speed_limit, X_ref,
+                     U_ref, T_ref, bound_left, bound_right, curvatures, vel_ref);
+  HIP_TRY(h, hipGetLastError());
+  return LMPC_OK;
+}
+
+int lmpc_plant_step_batch(lmpc_handle* h, int32_t batch, const lmpc_track* track, double* x, const double* u,
+                          double dt_sim, int32_t n_sub) {
+  if (!h) return LMPC_ERR_ARGUMENT;
+  if (batch < 0 || !track_ok(track) || !x || !u || !(dt_sim > 0.0) || n_sub < 1)
+    return fail(h, LMPC_ERR_ARGUMENT, "lmpc_plant_step_batch: bad argument");
+  if (batch == 0) return LMPC_OK;
+  HIP_TRY(h, hipSetDevice(h->device));
+  hipLaunchKernelGGL(lmpc_plant_kernel, dim3((batch + 255) / 256), dim3(256), 0, h->stream, h->P, batch, *track, x, u,
+                     dt_sim, n_sub);
   HIP_TRY(h, hipGetLastError());
   return LMPC_OK;
 }

@@ -114,6 +114,95 @@ __device__ __forceinline__ double track_lookup(const double* __restrict__ tab, i
   return tab[i0] * (1.0 - fr) + tab[i1] * fr;
 }
 
+// Reference sampling at one knot (racing_mpc_node.cpp:261-292): bounds, curvature, clamped velocity reference.
+__device__ __forceinline__ void sample_refs(const lmpc_track& trk, double s, double cur, double d, double speed_scale,
+                                            double speed_limit, double& bl, double& br, double& kap, double& vr_out) {
+  kap = track_lookup(trk.curvature, trk.M, trk.L, s);
+  bl = track_lookup(trk.bound_left, trk.M, trk.L, s);
+  br = track_lookup(trk.bound_right, trk.M, trk.L, s);
+  const double vr = track_lookup(trk.vel, trk.M, trk.L, s) * speed_scale;
+  const double lim = fmin(fmax(speed_limit, cur - d), cur + d);       // :273-275
+  const double clipped = fmin(fmax(vr, cur - d), cur + d);
+  vr_out = (vr > 0.0) ? fmin(clipped, lim) : lim;                     // :276-285
+}
+
+// Warm-start shift of RacingMPCNode::on_step_timer (racing_mpc_node.cpp:245-254): the previous solution moves
+// one knot forward, the last input is repeated, the last state is rolled out with the model, and the references
+// are re-sampled along the shifted abscissa.  `status` (may be NULL) selects, per problem, the previous SOLUTION
+// (status 0) or the previous REFERENCE (solve failed: the node keeps driving on the shifted old plan, :322-332).
+// One thread per problem; inputs and outputs must not alias.
+__global__ __launch_bounds__(256) void lmpc_shift_kernel(lmpc_params P, int B, lmpc_track trk,
+                                                         const double* __restrict__ X_sol, const double* __restrict__ U_sol,
+                                                         const double* __restrict__ X_old, const double* __restrict__ U_old,
+                                                         const int* __restrict__ status, double dt, double speed_scale,
+                                                         double speed_limit, double* __restrict__ X_ref,
+                                                         double* __restrict__ U_ref, double* __restrict__ T_ref,
+                                                         double* __restrict__ bl, double* __restrict__ br,
+                                                         double* __restrict__ curv, double* __restrict__ vref) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int N = P.N, NS = N - 1;
+  const bool ok = !status || status[b] == 0;
+  const double* Xs = ok ? X_sol : X_old;
+  const double* Us = ok ? U_sol : U_old;
+  const double d = P.max_vel_ref_diff;
+  double x[6], u[2] = {0.0, 0.0}, xn[6];
+  for (int i = 0; i < N; ++i) {
+    if (i < NS) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) x[k] = Xs[(size_t)(k * N + i + 1) * B + b];
+    } else {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) x[k] = xn[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) X_ref[(size_t)(k * N + i) * B + b] = x[k];
+    double b_l, b_r, kap, vr;
+    sample_refs(trk, x[0], x[3], d, speed_scale, speed_limit, b_l, b_r, kap, vr);
+    bl[(size_t)i * B + b] = b_l;
+    br[(size_t)i * B + b] = b_r;
+    curv[(size_t)i * B + b] = kap;
+    vref[(size_t)i * B + b] = vr;
+    if (i < NS) {
+      const int src = (i < NS - 1) ? i + 1 : NS - 1;  // last input repeated (:247)
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        u[k] = Us[(size_t)(k * NS + src) * B + b];
+        U_ref[(size_t)(k * NS + i) * B + b] = u[k];
+      }
+      T_ref[(size_t)i * B + b] = dt;
+      if (i == NS - 1) lmpc_rk4(P.veh, x, u, kap, dt, xn);  // :248-249
+    }
+  }
+}
+
+// Plant step of RacingSimulator::step (racing_simulator.cpp:46-69,97-112): RK4 with the track curvature at the
+// current abscissa, abscissa wrapped into [0, L) by align_abscissa(s, L/2, L); nsub sub-steps of dt_sim with the
+// input held.  One thread per car; x is updated in place.
+__global__ __launch_bounds__(256) void lmpc_plant_kernel(lmpc_params P, int B, lmpc_track trk, double* __restrict__ x_io,
+                                                         const double* __restrict__ u_in, double dt_sim, int nsub) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  double x[6], xn[6];
+  const double u[2] = {u_in[b], u_in[(size_t)B + b]};
+#pragma unroll
+  for (int k = 0; k < 6; ++k) x[k] = x_io[(size_t)k * B + b];
+  for (int j = 0; j < nsub; ++j) {
+    if (fabs(x[3]) < 1e-6) x[3] = copysign(1e-6, x[3]);  // :99-102
+    const double kap = track_lookup(trk.curvature, trk.M, trk.L, x[0]);
+    lmpc_rk4(P.veh, x, u, kap, dt_sim, xn);
+    // align_abscissa(s, L/2, L): lmpc_utils/utils.hpp:35-41
+    const double s1 = xn[0], s2 = trk.L / 2.0;
+    const double kk = fabs(s2 - s1) + trk.L / 2.0;
+    const double ll = kk - fmod(kk, trk.L);
+    xn[0] = s1 + ll * ((s2 > s1) - (s2 < s1));
+#pragma unroll
+    for (int k = 0; k < 6; ++k) x[k] = xn[k];
+  }
+#pragma unroll
+  for (int k = 0; k < 6; ++k) x_io[(size_t)k * B + b] = x[k];
+}
+
 // One thread per problem: zero-input rollout of the reference, then reference sampling.
 __global__ __launch_bounds__(256) void lmpc_prepare_kernel(lmpc_params P, int B, lmpc_track trk,
                                                            const double* __restrict__ x_ic, double dt,
@@ -133,17 +222,12 @@ __global__ __launch_bounds__(256) void lmpc_prepare_kernel(lmpc_params P, int B,
   for (int i = 0; i < N; ++i) {
 #pragma unroll
     for (int k = 0; k < 6; ++k) X_ref[(size_t)(k * N + i) * B + b] = x[k];
-    const double s = x[0];
-    const double kap = track_lookup(trk.curvature, trk.M, trk.L, s);
-    bl[(size_t)i * B + b] = track_lookup(trk.bound_left, trk.M, trk.L, s);
-    br[(size_t)i * B + b] = track_lookup(trk.bound_right, trk.M, trk.L, s);
+    double b_l, b_r, kap, vr;
+    sample_refs(trk, x[0], x[3], d, speed_scale, speed_limit, b_l, b_r, kap, vr);
+    bl[(size_t)i * B + b] = b_l;
+    br[(size_t)i * B + b] = b_r;
     curv[(size_t)i * B + b] = kap;
-    // vel_ref clamp, racing_mpc_node.cpp:269-286
-    const double cur = x[3];
-    const double vr = track_lookup(trk.vel, trk.M, trk.L, s) * speed_scale;
-    const double lim = fmin(fmax(speed_limit, cur - d), cur + d);
-    const double clipped = fmin(fmax(vr, cur - d), cur + d);
-    vref[(size_t)i * B + b] = (vr > 0.0) ? fmin(clipped, lim) : lim;
+    vref[(size_t)i * B + b] = vr;
     if (i < NS) {
       U_ref[(size_t)(0 * NS + i) * B + b] = u[0];
       U_ref[(size_t)(1 * NS + i) * B + b] = u[1];

@@ -25,13 +25,15 @@ def synthetic_track(kind: str = "barc", M: int = 1024) -> dict:
         k = (2.0 * np.pi / L) * (1.0 + 0.9 * np.cos(2 * th + 0.3) + 0.45 * np.cos(3 * th - 1.1))
         half_l = 0.55 + 0.25 * np.sin(th + 0.5)
         half_r = 0.55 + 0.25 * np.cos(2 * th - 0.2)
-        vel = 3.9 - 1.2 * np.cos(2 * th + 0.3)
+        # speed profile consistent with the grip in the corners (lateral acceleration 0.45 g), as a raceline
+        # optimiser would produce; range 1.5 .. 4.5 m/s (the reference's BARC profile spans 2.7 .. 5.2)
+        vel = np.clip(np.sqrt(0.45 * 9.8 / np.maximum(np.abs(k), 1e-3)), 1.5, 4.5)
     elif kind == "putnam":
         L = 2849.0
         k = (2.0 * np.pi / L) * (1.0 + 8.0 * np.cos(3 * th + 0.4) ** 3 + 5.0 * np.cos(5 * th - 0.7))
         half_l = 4.5 + 2.5 * np.sin(th + 0.5)
         half_r = 4.5 + 2.5 * np.cos(2 * th - 0.2)
-        vel = 42.0 - 26.0 * np.abs(np.cos(3 * th + 0.4)) ** 1.5
+        vel = np.clip(np.sqrt(1.6 * 9.8 / np.maximum(np.abs(k), 1e-4)), 15.0, 65.0)  # 1.6 g with downforce
     else:
         raise ValueError(kind)
     return {"L": L, "M": M, "curvature": k, "bound_left": half_l, "bound_right": -half_r, "vel": vel}

@@ -213,3 +213,47 @@ def test_lmpc_full_batch(pkg):
     twin = cbind.solve_batch(cfg, veh, sub, ss_x=ss_x.cpu().numpy()[..., :64], ss_j=ss_j.cpu().numpy()[..., :64])
     same = (twin["status"] == 0) & ok[:64]
     assert np.abs((o["X_optm"][:, :, :64] - twin["X_optm"]) / P.SCALE_X[:, None, None])[:, :, same].max() < 1e-6
+
+
+def test_shift_and_plant_match_node_and_simulator(pkg):
+    """One warm-start shift and one plant step against the oracle's restatement of the node / simulator."""
+    import torch
+    veh, cfg, solver, tr, x, u = make(pkg, "barc20", 300, 31)
+    inp = solver.prepare(tr, x.T.copy(), 0.025)
+    inp["u_ic"] = u.T.copy()
+    out = solver.solve(inp)
+    o = to_np(out)
+    nxt = {k: (v.cpu().numpy() if hasattr(v, "cpu") else v) for k, v in solver.shift(tr, inp, out, 0.025, speed_scale=0.9).items()}
+    Xp = np.where((o["status"] == 0)[None, None, :], o["X_optm"], inp["X_ref"].cpu().numpy())
+    Up = np.where((o["status"] == 0)[None, None, :], o["U_optm"], inp["U_ref"].cpu().numpy())
+    ref = S.shift_inputs(cfg, veh, tr, Xp, Up, 0.025, speed_scale=0.9)
+    for k in ("X_ref", "U_ref", "T_ref", "bound_left", "bound_right", "curvatures", "vel_ref"):
+        assert np.abs(nxt[k] - ref[k]).max() <= 1e-11 * max(1.0, np.abs(ref[k]).max()), k
+    xs = torch.as_tensor(x.T.copy(), device="cuda")
+    ua = torch.as_tensor(o["U_optm"][:, 0, :].copy(), device="cuda")
+    solver.plant_step(tr, xs, ua, 0.0125, 2)
+    want = S.plant_step(veh, tr, x, o["U_optm"][:, 0, :].T, 0.0125, 2)
+    assert np.abs(xs.cpu().numpy().T - want).max() <= 1e-11 * max(1.0, np.abs(want).max())
+    assert (xs[0] >= 0).all() and (xs[0] < tr["L"]).all()
+
+
+def test_closed_loop_two_laps_inside_the_track(pkg):
+    """SURVEY.md 8d config 1 on the device, 512 cars at once: the tracking MPC drives the RK4 plant around the
+    synthetic BARC-scale track; pass = every car completes >= 2 laps and stays inside the boundaries."""
+    import torch
+    vname, cname, N, kind = PRESETS["barc20"]
+    solver = pkg.Solver(pkg.presets.barc_tracking_mpc(N), pkg.presets.barc_vehicle(), device=0)
+    tr = pkg.workloads.synthetic_track("barc")
+    rng = np.random.default_rng(2)
+    B = 512
+    x0 = np.stack([rng.uniform(0, tr["L"], B), rng.uniform(-0.1, 0.1, B), rng.normal(0, 0.03, B),
+                   rng.uniform(2.0, 2.5, B), np.zeros(B), np.zeros(B)])  # below ~1.5 m/s the reference's RK4 model is unstable
+    res = pkg.closed_loop.run(solver, tr, torch.as_tensor(x0, device="cuda"), torch.zeros((2, B), dtype=torch.float64, device="cuda"),
+                              steps=1100, dt=0.025, n_sub=2, speed_scale=0.9)
+    dist = res["distance"].cpu().numpy()
+    exc = res["worst_excess"].cpu().numpy()
+    nf = res["n_fail"].cpu().numpy()
+    assert np.isfinite(res["x"].cpu().numpy()).all()
+    assert dist.min() >= 2 * tr["L"], dist.min()
+    assert exc.max() <= 0.0, exc.max()          # body edge never leaves the track
+    assert nf.mean() < 0.01 * 1100, nf.mean()   # < 1 % failed solves per car
