@@ -30,12 +30,17 @@
 #define NSLOT 11
 
 // Optional per-phase cycle accounting (make prof -> -DLMPC_PHASE_TIMING): one s_memtime read per
-// phase boundary, per-wave totals written over kkt_out as [8][B] doubles (caller allocates 8 rows).
+// phase boundary, per-wave totals written over kkt_out as [16][B] doubles (caller allocates 20 rows).
 #ifdef LMPC_PHASE_TIMING
-#define PT_DECL long long pt_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long pt_t = __builtin_readcyclecounter(); const long long pt_w0 = wall_clock64();
-#define PT_MARK(k) { const long long pt_n = __builtin_readcyclecounter(); pt_acc[k] += pt_n - pt_t; pt_t = pt_n; }
+struct Prof {
+  long long acc[16];
+  long long t, w0;
+};
+#define PT_DECL Prof pf; { for (int k = 0; k < 16; ++k) pf.acc[k] = 0; pf.t = __builtin_readcyclecounter(); pf.w0 = wall_clock64(); }
+#define PT_MARK(k) { const long long pt_n = __builtin_readcyclecounter(); pf.acc[k] += pt_n - pf.t; pf.t = pt_n; }
 #else
-#define PT_DECL
+struct Prof {};
+#define PT_DECL Prof pf;
 #define PT_MARK(k)
 #endif
 #define SL_U 6
@@ -87,6 +92,11 @@
 #define F_QLIN 8
 #define F_MOVE 16
 #define MROW 10  // padded row stride of the 8x8 work matrices (conflict-free b128 row reads)
+
+// The workgroup is a single wavefront and the LDS executes one wave's DS instructions in issue order,
+// so cross-lane exchange through LDS needs no s_barrier and no wait for the write to retire: only the
+// compiler must not move memory operations across the exchange point.
+__device__ __forceinline__ void wave_sync() { __builtin_amdgcn_wave_barrier(); }
 
 __device__ __forceinline__ double wave_sum(double x) {
 #pragma unroll
@@ -222,7 +232,7 @@ __device__ void riccati_factor(const Lds& L, int lane, const double* PT) {
     if (HAS_PT && r < 6 && c < 6) e += PT[r * 6 + c];  // LMPC: safe-set block condensed onto x_T
     MP[r * MROW + c] = e;
   }
-  __syncthreads();
+  wave_sync();
   for (int i = N - 2; i >= 0; --i) {
     double* st = L.st(i);
     const double t = st[ST_DT];
@@ -233,13 +243,13 @@ __device__ void riccati_factor(const Lds& L, int lane, const double* PT) {
       for (int k = 0; k < 6; ++k) acc += st[r * 6 + k] * MP[c * MROW + k];
       MW[r * MROW + c] = acc;
     }
-    __syncthreads();
+    wave_sync();
     // Y = W Abar
     double y = (c >= 6) ? MW[r * MROW + c] : 0.0;
 #pragma unroll
     for (int k = 0; k < 6; ++k) y += MW[r * MROW + k] * st[c * 6 + k];
     MY[r * MROW + c] = y;
-    __syncthreads();
+    wave_sync();
     // H = Sv + Thv + t^2 Y_uu, K = H^-1 t Y[6:8,:], P <- Qz + Thz + Y - t^2 Y[6:8,r]' H^-1 Y[6:8,c]
     const double* kn = L.kn(i);
     const double y6r = MY[6 * MROW + r], y7r = MY[7 * MROW + r];
@@ -267,7 +277,7 @@ __device__ void riccati_factor(const Lds& L, int lane, const double* PT) {
       st[ST_HI + 2] = hi11;
     }
     if (i >= 1) MP[r * MROW + c] = pn;
-    __syncthreads();
+    wave_sync();
   }
 }
 
@@ -289,7 +299,7 @@ __device__ __forceinline__ double lane_bcast(double v, int k) {
 // no LDS round trip on the critical path; the stage matrices are plain loads whose addresses do
 // not depend on the chain, so they pipeline ahead of it.
 template <int NRHS>
-__device__ void riccati_solve(const Lds& L, int lane) {
+__device__ void riccati_solve(const Lds& L, int lane, Prof& pf) {
   const int N = L.N;
   const int r = lane & 7;  // lanes >= 8 mirror lanes 0..7 (their results are simply not stored)
   const bool store = lane < 8;
@@ -319,7 +329,8 @@ __device__ void riccati_solve(const Lds& L, int lane) {
       }
     }
   }
-  __syncthreads();
+  wave_sync();
+  PT_MARK(8 + NRHS - 1)
   double d[NRHS];
 #pragma unroll
   for (int s = 0; s < NRHS; ++s) {
@@ -365,7 +376,8 @@ __device__ void riccati_solve(const Lds& L, int lane) {
       }
     }
   }
-  __syncthreads();
+  wave_sync();
+  PT_MARK(10 + NRHS - 1)
 }
 
 // Closed-loop rollout z_{i+1} = Abar z_i + Bbar v_i + gbar, v_i = -K_i z_i (absolute variables).
@@ -403,7 +415,7 @@ __device__ void feedback_rollout(const Lds& L, int lane) {
         kn[9] = v1;
       }
     }
-    __syncthreads();
+    wave_sync();
   }
 }
 
@@ -462,7 +474,7 @@ __global__ __launch_bounds__(64, ((KQ <= 4 && KS == 0) ? 2 : 1)) void lmpc_solve
       ct[CT_E + lane - 19] = P.chs2[lane - 19];
     }
   }
-  __syncthreads();
+  wave_sync();
   PT_MARK(0)
 
   // ---------------- slot ownership ----------------
@@ -588,7 +600,7 @@ __global__ __launch_bounds__(64, ((KQ <= 4 && KS == 0) ? 2 : 1)) void lmpc_solve
   if constexpr (KS > 0) {  // lambda frozen at 1/S: terminal cost eps'D eps only
     if (lane < 36) T[TL_PT + lane] = (lane % 7 == 0) ? ct[CT_E + lane / 7] : 0.0;
   }
-  __syncthreads();
+  wave_sync();
   riccati_factor<(KS > 0)>(L, lane, T + TL_PT);
   feedback_rollout(L, lane);
   if constexpr (KS > 0) {
@@ -606,7 +618,7 @@ __global__ __launch_bounds__(64, ((KQ <= 4 && KS == 0) ? 2 : 1)) void lmpc_solve
       T[TL_EPS + lane] = e;
       T[TL_TG + lane] = ct[CT_E + lane] * e;
     }
-    __syncthreads();
+    wave_sync();
   }
   PT_MARK(1)
 
@@ -735,7 +747,7 @@ __global__ __launch_bounds__(64, ((KQ <= 4 && KS == 0) ? 2 : 1)) void lmpc_solve
         rd_check = rdmax;
       }
       if (it == max_iter) break;
-      __syncthreads();
+      wave_sync();
       PT_MARK(2)
       riccati_factor<(KS > 0)>(L, lane, T + TL_PT);
       PT_MARK(3)
@@ -800,23 +812,24 @@ __global__ __launch_bounds__(64, ((KQ <= 4 && KS == 0) ? 2 : 1)) void lmpc_solve
         if (pass == 0 && s_wo[q] != KN_EY) kn[s_wo[q] + 10] = 0.0;
         sgsum += (f & F_SIG) ? (cu + cd) : 0.0;
       }
-      __syncthreads();
+      wave_sync();
+      PT_MARK(12)
       for (int i = lane; i < N; i += 64) {
         double* kn = L.kn(i);
         kn[KN_R0 + 1] += kn[KN_EY];
         if (pass == 0) kn[KN_R1 + 1] = (i >= 1) ? kn[KN_CSIG] : 0.0;
       }
       if constexpr (KS > 0) {  // terminal gradient of the safe-set block onto x_T (lanes 0..5 != EY lanes' cells)
-        __syncthreads();
+        wave_sync();
         if (lane < 6) L.kn(N - 1)[KN_R0 + lane] += T[TL_TG + lane];
       }
-      __syncthreads();
+      wave_sync();
       // ======== Newton step: predictor together with the Schur vector, then the corrector ========
       PT_MARK(4)
       if (pass == 0 && ipm && has_sigma)
-        riccati_solve<2>(L, lane);
+        riccati_solve<2>(L, lane, pf);
       else
-        riccati_solve<1>(L, lane);
+        riccati_solve<1>(L, lane, pf);
       PT_MARK(5)
       // ======== boundary slack by Schur complement ========
       double cfs = 0.0;
@@ -969,7 +982,7 @@ __global__ __launch_bounds__(64, ((KQ <= 4 && KS == 0) ? 2 : 1)) void lmpc_solve
         if (has_sigma) sacc += (ts + amax * dts) * (lams + amax * dlams);
         const double ratio = (sacc * inv_m) / mu;
         sigc = ratio * ratio * ratio;
-        __syncthreads();
+        wave_sync();
       }
     }
 
@@ -983,7 +996,7 @@ __global__ __launch_bounds__(64, ((KQ <= 4 && KS == 0) ? 2 : 1)) void lmpc_solve
       if (s_f[q] & F_MOVE) (KN0 + s_ko[q])[s_vo[q]] += dz;
       stepmax = fmax(stepmax, fabs(dz));
     }
-    __syncthreads();
+    wave_sync();
     if (ipm) {
       last_step = wave_max(stepmax);
       if (has_sigma) {
@@ -1023,7 +1036,7 @@ __global__ __launch_bounds__(64, ((KQ <= 4 && KS == 0) ? 2 : 1)) void lmpc_solve
   if (!feasible) status = LMPC_SOLVE_INFEASIBLE;
 
   // ---------------- write back: X [6][N][B], U, dU [2][N-1][B] ----------------
-  __syncthreads();
+  wave_sync();
   for (int e = lane; e < 6 * N; e += 64) {
     const int k = e / N, i = e - k * N;
     X_out[(size_t)(k * N + i) * B + b] = L.kn(i)[k];
@@ -1045,14 +1058,14 @@ __global__ __launch_bounds__(64, ((KQ <= 4 && KS == 0) ? 2 : 1)) void lmpc_solve
     iters_out[b] = it;
 #ifdef LMPC_PHASE_TIMING
     if (kkt_out) {
-      for (int k = 0; k < 8; ++k) kkt_out[k * (size_t)B + b] = (double)pt_acc[k];
-      kkt_out[8 * (size_t)B + b] = (double)pt_w0;               // 100 MHz wall clock at start
-      kkt_out[9 * (size_t)B + b] = (double)wall_clock64();      // ... at end
+      for (int k = 0; k < 16; ++k) kkt_out[k * (size_t)B + b] = (double)pf.acc[k];
+      kkt_out[16 * (size_t)B + b] = (double)pf.w0;               // 100 MHz wall clock at start
+      kkt_out[17 * (size_t)B + b] = (double)wall_clock64();      // ... at end
       unsigned hwid, xcc;
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-      kkt_out[10 * (size_t)B + b] = (double)hwid;
-      kkt_out[11 * (size_t)B + b] = (double)(xcc & 0xf);
+      kkt_out[18 * (size_t)B + b] = (double)hwid;
+      kkt_out[19 * (size_t)B + b] = (double)(xcc & 0xf);
     }
 #else
     if (kkt_out) {

@@ -9,26 +9,27 @@ import importlib
 capi = importlib.import_module(pkg.__name__ + ".capi")
 capi.library_path = lambda: ROOT / "racing-lmpc-ros2_amd" / "lib" / "liblmpc_hip_prof.so"
 capi._LIB = None
-N, B = int(sys.argv[1]) if len(sys.argv) > 1 else 20, 4096
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 solver = pkg.Solver(pkg.presets.barc_tracking_mpc(N), pkg.presets.barc_vehicle(), 0)
 tr = pkg.workloads.synthetic_track("barc")
 x, u = pkg.workloads.sample_initial_states("barc", B, tr["L"], [-0.01, -0.314159], [0.01, 0.314159], 0)
 inp = solver.prepare(tr, x.T.copy(), 0.025)
 inp["u_ic"] = torch.as_tensor(u.T.copy(), dtype=torch.float64, device="cuda")
 out = solver.alloc_outputs(B)
-out["kkt"] = torch.zeros((12, B), dtype=torch.float64, device="cuda")
+out["kkt"] = torch.zeros((20, B), dtype=torch.float64, device="cuda")
 for _ in range(3):
     solver.solve(inp, out)
 torch.cuda.synchronize()
 k = out["kkt"].cpu().numpy()
 it = out["iters"].cpu().numpy()
-names = ["load", "init(factor+rollout)", "rows+reduce", "factor", "gradient", "solve", "schur+steps", "update/exit"]
-tot = k[:8].sum(0)
+names = ["load", "init(factor+rollout)", "rows+reduce", "factor", "gradient", "solve", "schur+steps", "update/exit"] + ["x%d" % i for i in range(8, 16)]
+tot = k[:16].sum(0)
 print("mean iters %.2f; mean cycles/wave %.0f" % (it.mean(), tot.mean()))
-for n, v in zip(names, k[:8]):
+for n, v in zip(names, k[:16]):
     print("%-22s %10.0f cycles  %5.1f %%   per-iter %8.0f" % (n, v.mean(), 100 * v.mean() / tot.mean(), v.mean() / it.mean()))
 
-w0, w1, hw, xcc = k[8], k[9], k[10].astype(np.int64), k[11].astype(np.int64)
+w0, w1, hw, xcc = k[16], k[17], k[18].astype(np.int64), k[19].astype(np.int64)
 span = (w1.max() - w0.min()) / 100e6
 dur = (w1 - w0) / 100e6
 print("kernel span %.3f ms; wave duration mean %.3f ms (min %.3f max %.3f); effective clock %.2f GHz" % (span * 1e3, dur.mean() * 1e3, dur.min() * 1e3, dur.max() * 1e3, tot.mean() / dur.mean() / 1e9))
