@@ -48,13 +48,13 @@ struct Prof {};
 #define SL_EY 10
 
 // ---- LDS layout (doubles) ---------------------------------------------------------------------
-// stage record i (stride 78): ABt[8][6] @0 (ABt[c][k] = [A B][k][c]) | g[6] @48 | K[2][8] @54
-//                             | Hinv (h00,h01,h11) @70 | dt @73 | kff[2 rhs][2] @74
+// stage record i (stride 78): M[8][8] @0: column c of the stage model with the feedback gain appended,
+//                               M[c][k] = [A B][k][c] (k < 6), M[c][6 + j] = K_j[c]
+//                             | g[6] @64 | Hinv (h00,h01,h11) @70 | dt @73 | kff[2 rhs][2] @74
 // knot record i (stride 34):  z[8] v[2] @0 | rhs0: Th / q / d [10] @10 | rhs1: q / e [10] @20
 //                             | csig @30 | eyT / eyD @31 | (free) @32 | qlin_vx @33
 // tail: P[8][10] @0 | W[8][10] @80 | Y[8][10] @160 | pvec[2 buf][2 rhs][8] @240 | consts @272 (48)
-#define ST_G 48
-#define ST_K 54
+#define ST_G 64
 #define ST_HI 70
 #define ST_DT 73
 #define ST_KFF 74
@@ -209,76 +209,12 @@ struct Lds {
   __device__ __forceinline__ double* tail() const { return base + (N - 1) * LMPC_STAGE_STRIDE + N * LMPC_KNOT_STRIDE; }
 };
 
-// true cost Hessian entry on z_i (no barrier terms), racing_mpc.cpp:459-476
-__device__ __forceinline__ double qz_entry(const double* ct, int N, int i, int r, int c) {
-  if (r < 6 || c < 6) return (r == c) ? (i == N - 1 ? ct[CT_QT + r] : ct[CT_QD + r]) : 0.0;
-  return (i >= 1) ? ct[CT_QU + (r - 6) * 2 + (c - 6)] : 0.0;
-}
-
-// Backward Riccati sweep for the barrier weights currently in the knots' rhs0 region
-// (Thz @ +10..17, Thv @ +18,19, boundary weight @ KN_EY).  Leaves K, Hinv in the stage records.
-template <bool HAS_PT>
-__device__ void riccati_factor(const Lds& L, int lane, const double* PT) {
-  const int N = L.N, r = lane >> 3, c = lane & 7;
-  double* T = L.tail();
-  double* MP = T + TL_P;
-  double* MW = T + TL_W;
-  double* MY = T + TL_Y;
-  const double* ct = T + TL_CT;
-  {
-    const double* kn = L.kn(N - 1);
-    double e = qz_entry(ct, N, N - 1, r, c);
-    if (r == c) e += kn[KN_R0 + r] + (r == 1 ? kn[KN_EY] : 0.0);
-    if (HAS_PT && r < 6 && c < 6) e += PT[r * 6 + c];  // LMPC: safe-set block condensed onto x_T
-    MP[r * MROW + c] = e;
-  }
-  wave_sync();
-  for (int i = N - 2; i >= 0; --i) {
-    double* st = L.st(i);
-    const double t = st[ST_DT];
-    // W = Abar' P : W[r][c] = sum_k Abar[k][r] P[k][c]  (+ P[r][c] for the u rows); P[k][c] read as P[c][k]
-    {
-      double acc = (r >= 6) ? MP[r * MROW + c] : 0.0;
-#pragma unroll
-      for (int k = 0; k < 6; ++k) acc += st[r * 6 + k] * MP[c * MROW + k];
-      MW[r * MROW + c] = acc;
-    }
-    wave_sync();
-    // Y = W Abar
-    double y = (c >= 6) ? MW[r * MROW + c] : 0.0;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) y += MW[r * MROW + k] * st[c * 6 + k];
-    MY[r * MROW + c] = y;
-    wave_sync();
-    // H = Sv + Thv + t^2 Y_uu, K = H^-1 t Y[6:8,:], P <- Qz + Thz + Y - t^2 Y[6:8,r]' H^-1 Y[6:8,c]
-    const double* kn = L.kn(i);
-    const double y6r = MY[6 * MROW + r], y7r = MY[7 * MROW + r];
-    const double y6c = MY[6 * MROW + c], y7c = MY[7 * MROW + c];
-    const double h00 = ct[CT_SV + 0] + kn[KN_R0 + 8] + t * t * MY[6 * MROW + 6];
-    const double h01 = ct[CT_SV + 1] + t * t * MY[6 * MROW + 7];
-    const double h11 = ct[CT_SV + 3] + kn[KN_R0 + 9] + t * t * MY[7 * MROW + 7];
-    const double idet = frcp(h00 * h11 - h01 * h01);
-    const double hi00 = h11 * idet, hi01 = -h01 * idet, hi11 = h00 * idet;
-    const double g0 = t * y6c, g1 = t * y7c;
-    const double k0c = hi00 * g0 + hi01 * g1;
-    const double k1c = hi01 * g0 + hi11 * g1;
-    double pn = 0.0;
-    if (i >= 1) {
-      pn = qz_entry(ct, N, i, r, c) + y - t * (y6r * k0c + y7r * k1c);
-      if (r == c) pn += kn[KN_R0 + r] + (r == 1 ? kn[KN_EY] : 0.0);
-    }
-    if (r == 0) {
-      st[ST_K + c] = k0c;
-      st[ST_K + 8 + c] = k1c;
-    }
-    if (lane == 8) {
-      st[ST_HI + 0] = hi00;
-      st[ST_HI + 1] = hi01;
-      st[ST_HI + 2] = hi11;
-    }
-    if (i >= 1) MP[r * MROW + c] = pn;
-    wave_sync();
-  }
+// true cost Hessian entry on z_i (no barrier terms), racing_mpc.cpp:459-476; terminal knot or a knot 1 <= i <= N-2
+__device__ __forceinline__ double qz_entry(const double* ct, bool terminal, int r, int c) {
+  const int rx = r < 6 ? r : 0, ru = r >= 6 ? r - 6 : 0, cu = c >= 6 ? c - 6 : 0;
+  const double dx = terminal ? ct[CT_QT + rx] : ct[CT_QD + rx];
+  const double uu = ct[CT_QU + ru * 2 + cu];
+  return (r < 6 || c < 6) ? ((r == c) ? dx : 0.0) : uu;
 }
 
 // Lane k's value of a wave-distributed double as a wave-uniform scalar (two v_readlane_b32; the
@@ -289,132 +225,272 @@ __device__ __forceinline__ double lane_bcast(double v, int k) {
   return __hiloint2double(hi, lo);
 }
 
-// Riccati vector solve for NRHS (1 or 2) right-hand sides held in the knots' rhs regions
-// (q_z @ +0..7, q_v @ +8,9 of region s); the step (dz, dv) overwrites them.  dz_0 = 0.
+// Pin the issue order of LDS traffic: one wave's DS instructions return in issue order, so the read a
+// serial chain waits for must be queued ahead of the operand prefetch of the following stage.
+#define ISSUE_ORDER() __builtin_amdgcn_sched_barrier(0)
+// ... and the other way round: value x is complete before any later memory operation is issued (an
+// empty asm that consumes x and clobbers memory), used to keep a prefetch behind the last use of the
+// registers it overwrites.
+#define AFTER_VALUE(x) asm volatile("" : "+v"(x) : : "memory")
+
+// Backward Riccati sweep for the barrier weights currently in the knots' rhs0 region
+// (Thz @ +10..17, Thv @ +18,19, boundary weight @ KN_EY).  Leaves K (columns 6,7 of M) and Hinv in
+// the stage records.
 //
-// The sweep is a strictly serial chain over the knots, so it is organised for latency, not for
-// lane occupancy: lane r (< 8) carries component r of the running vector of BOTH right-hand
-// sides in registers, the six components a matrix row needs are broadcast with v_readlane (SGPR
-// operands of the FMAs), and nothing is exchanged through LDS between stages -- no barrier and
-// no LDS round trip on the critical path; the stage matrices are plain loads whose addresses do
-// not depend on the chain, so they pipeline ahead of it.
-template <int NRHS>
-__device__ void riccati_solve(const Lds& L, int lane, Prof& pf) {
-  const int N = L.N;
-  const int r = lane & 7;  // lanes >= 8 mirror lanes 0..7 (their results are simply not stored)
-  const bool store = lane < 8;
-  double pv[NRHS];
+// The sweep is one dependent chain over the knots, so it is written for latency: lane (r, c) keeps its
+// own element of P / W in a register, everything that does not depend on the chain (model rows, barrier
+// weights) is fetched one stage ahead, and the three exchanges per stage (P, W, Y rows through LDS) are
+// the only waits; the 2x2 inverse starts from v_readlane copies of Y_uu while the Y rows are in flight.
+template <bool HAS_PT>
+__device__ void riccati_factor(const Lds& L, int lane, const double* PT) {
+  const int N = L.N, r = lane >> 3, c = lane & 7;
+  double* T = L.tail();
+  double* MP = T + TL_P;
+  double* MW = T + TL_W;
+  double* MY = T + TL_Y;
+  const double* ct = T + TL_CT;
+  const bool diag = r == c;
+  const double qmid = qz_entry(ct, false, r, c);
+  double pown;
+  {
+    const double* kn = L.kn(N - 1);
+    double e = qz_entry(ct, true, r, c);
+    const double th = kn[KN_R0 + r] + (r == 1 ? kn[KN_EY] : 0.0);
+    if (diag) e += th;
+    if (HAS_PT && r < 6 && c < 6) e += PT[r * 6 + c];  // LMPC: safe-set block condensed onto x_T
+    pown = e;
+    MP[r * MROW + c] = e;
+  }
+  // where this lane's share of the stage results goes: lanes 0..15 K_j[c] (j = r), 16..18 Hinv, the
+  // rest to their own (dead) W cell
+  const int res_off = lane < 16 ? c * 8 + 6 + r : ST_HI + (lane - 16);
+  const bool res_on = lane < 19;
+  double* const res_junk = MW + r * MROW + c;
+  // phase-1/2 operands of stage N-2 (later stages: fetched during phase 3 of the stage before)
+  double ar[6], ac[6];
+  {
+    const double* st = L.st(N - 2);
 #pragma unroll
-  for (int s = 0; s < NRHS; ++s) pv[s] = L.kn(N - 1)[KN_R0 + 10 * s + r];
+    for (int k = 0; k < 6; ++k) {
+      ar[k] = st[r * 8 + k];
+      ac[k] = st[c * 8 + k];
+    }
+  }
+  wave_sync();
   for (int i = N - 2; i >= 0; --i) {
     double* st = L.st(i);
     const double* kn = L.kn(i);
-    const double t = st[ST_DT];
-    double ab[6], k0r = st[ST_K + r], k1r = st[ST_K + 8 + r];
+    // W = Abar' P : W[r][c] = sum_k Abar[k][r] P[k][c]  (+ P[r][c] for the u rows); P[k][c] read as P[c][k]
+    double pr[6];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) ab[k] = st[r * 6 + k];
-    const double hi00 = st[ST_HI], hi01 = st[ST_HI + 1], hi11 = st[ST_HI + 2];
+    for (int k = 0; k < 6; ++k) pr[k] = MP[c * MROW + k];
+    ISSUE_ORDER();
+    // phase-3 operands of this stage, queued behind the P row
+    const double t = st[ST_DT], thr = kn[KN_R0 + r], ey = kn[KN_EY], thv0 = kn[KN_R0 + 8], thv1 = kn[KN_R0 + 9];
+    ISSUE_ORDER();
+    double w = (r >= 6) ? pown : 0.0;
 #pragma unroll
-    for (int s = 0; s < NRHS; ++s) {
-      const int reg = KN_R0 + 10 * s;
-      double w = (r >= 6) ? pv[s] : 0.0;  // w = Abar' p: rows 6,7 also take p_u
+    for (int k = 0; k < 6; ++k) w += ar[k] * pr[k];
+    MW[r * MROW + c] = w;
+    wave_sync();
+    // Y = W Abar
+    double wr[6];
 #pragma unroll
-      for (int k = 0; k < 6; ++k) w = __builtin_fma(ab[k], lane_bcast(pv[s], k), w);
-      const double hv0 = __builtin_fma(t, lane_bcast(w, 6), kn[reg + 8]);
-      const double hv1 = __builtin_fma(t, lane_bcast(w, 7), kn[reg + 9]);
-      if (i >= 1) pv[s] = kn[reg + r] + w - (k0r * hv0 + k1r * hv1);
-      if (lane == 0) {
-        st[ST_KFF + 2 * s + 0] = hi00 * hv0 + hi01 * hv1;
-        st[ST_KFF + 2 * s + 1] = hi01 * hv0 + hi11 * hv1;
+    for (int k = 0; k < 6; ++k) wr[k] = MW[r * MROW + k];
+    double y = (c >= 6) ? w : 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) y += wr[k] * ac[k];
+    MY[r * MROW + c] = y;
+    wave_sync();
+    // H = Sv + Thv + t^2 Y_uu, K = H^-1 t Y[6:8,:], P <- Qz + Thz + Y - t^2 Y[6:8,r]' H^-1 Y[6:8,c]
+    const double y6r = MY[6 * MROW + r], y7r = MY[7 * MROW + r];
+    const double y6c = MY[6 * MROW + c], y7c = MY[7 * MROW + c];
+    AFTER_VALUE(y);
+    {  // phase-1/2 operands of the next stage (their registers are dead by now), queued behind the Y rows
+      const double* stn = L.st(i > 0 ? i - 1 : 0);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        ar[k] = stn[r * 8 + k];
+        ac[k] = stn[c * 8 + k];
       }
     }
+    ISSUE_ORDER();
+    const double y66 = lane_bcast(y, 54), y67 = lane_bcast(y, 55), y77 = lane_bcast(y, 63);
+    const double tt = t * t;
+    const double h00 = ct[CT_SV + 0] + thv0 + tt * y66;
+    const double h01 = ct[CT_SV + 1] + tt * y67;
+    const double h11 = ct[CT_SV + 3] + thv1 + tt * y77;
+    const double idet = frcp(h00 * h11 - h01 * h01);
+    const double hi00 = h11 * idet, hi01 = -h01 * idet, hi11 = h00 * idet;
+    const double g0 = t * y6c, g1 = t * y7c;
+    const double k0c = hi00 * g0 + hi01 * g1;
+    const double k1c = hi01 * g0 + hi11 * g1;
+    double pn = qmid + y - t * (y6r * k0c + y7r * k1c);
+    const double th = thr + (r == 1 ? ey : 0.0);
+    if (diag) pn += th;
+    pown = pn;
+    MP[r * MROW + c] = pn;  // (not used after stage 0)
+    const double res = lane < 8 ? k0c : (lane < 16 ? k1c : (lane == 16 ? hi00 : (lane == 17 ? hi01 : hi11)));
+    *(res_on ? st + res_off : res_junk) = res;
+    wave_sync();
+  }
+}
+
+// Riccati vector solve for NRHS (1 or 2) right-hand sides held in the knots' rhs regions
+// (q_z @ +0..7, q_v @ +8,9 of region s); the step (dz, dv) overwrites them.  dz_0 = 0.
+//
+// Both sweeps are strictly serial over the knots and organised for latency and for few VALU issues:
+// lane (s, r) = ((lane >> 3) % NRHS, lane & 7) carries component r of right-hand side s, so the
+// predictor step and the boundary-slack Schur vector share one instruction stream.  Per stage the
+// running vector makes one trip through LDS (one write, broadcast b128 reads), the 2-vector a stage
+// condenses to (B'p, du) is spread with v_readlane, and the stage operands are fetched one stage ahead.
+// Lanes >= 8 NRHS mirror lanes below and write to dead cells of the factor work matrices.
+template <int NRHS>
+__device__ void riccati_solve(const Lds& L, int lane, Prof& pf) {
+  const int N = L.N;
+  const int r = lane & 7, s = (lane >> 3) & (NRHS - 1);
+  const bool own = lane < 8 * NRHS;
+  const int reg = KN_R0 + 10 * s;
+  double* T = L.tail();
+  double* const junk0 = T + TL_W + lane;  // 64 + 64 dead cells: W (80) and Y (80) are contiguous
+  double* const junk1 = T + TL_W + 80 + lane;
+  double* const pvec = T + TL_PV + 8 * s;
+  double* const pdst = own ? pvec + r : junk0;
+  auto spread2 = [&](double v, double& a, double& b) {  // values of lanes (s, 6) and (s, 7) to the whole group
+    if constexpr (NRHS == 2) {
+      // ds_swizzle bit mode: source lane = (lane & 0x18) | 6 (resp. 7), i.e. lane 6 / 7 of each group of 8
+      const int lo = __double2loint(v), hi = __double2hiint(v);
+      a = __hiloint2double(__builtin_amdgcn_ds_swizzle(hi, 0x00D8), __builtin_amdgcn_ds_swizzle(lo, 0x00D8));
+      b = __hiloint2double(__builtin_amdgcn_ds_swizzle(hi, 0x00F8), __builtin_amdgcn_ds_swizzle(lo, 0x00F8));
+    } else {
+      a = lane_bcast(v, 6);
+      b = lane_bcast(v, 7);
+    }
+  };
+  // ---- backward: p_i = q_i + Abar' p_{i+1} - K' (q_v + Bbar' p_{i+1});  kff_i = H^-1 (q_v + Bbar' p_{i+1})
+  double p = L.kn(N - 1)[reg + r];
+  *pdst = p;
+  double row[6];  // [A B](:, r), fetched one stage ahead
+  {
+    const double* st = L.st(N - 2);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) row[k] = st[r * 8 + k];
   }
   wave_sync();
-  PT_MARK(8 + NRHS - 1)
-  double d[NRHS];
+  for (int i = N - 2; i >= 0; --i) {
+    double* st = L.st(i);
+    const double* kn = L.kn(i);
+    double pb[6];
 #pragma unroll
-  for (int s = 0; s < NRHS; ++s) {
-    d[s] = 0.0;
-    if (store) L.kn(0)[KN_R0 + 10 * s + r] = 0.0;
+    for (int k = 0; k < 6; ++k) pb[k] = pvec[k];
+    ISSUE_ORDER();
+    // what the stage needs after the product, queued behind the costate
+    const double k0r = st[r * 8 + 6], k1r = st[r * 8 + 7], t = st[ST_DT];
+    const double qz = kn[reg + r], qv0 = kn[reg + 8], qv1 = kn[reg + 9];
+    const double hi00 = st[ST_HI], hi01 = st[ST_HI + 1], hi11 = st[ST_HI + 2];
+    ISSUE_ORDER();
+    double w = (r >= 6) ? p : 0.0;  // w = Abar' p: rows 6,7 also take p_u
+#pragma unroll
+    for (int k = 0; k < 6; ++k) w = __builtin_fma(row[k], pb[k], w);
+    AFTER_VALUE(w);
+    double w6, w7;
+    spread2(w, w6, w7);
+    ISSUE_ORDER();
+    {
+      const double* stn = L.st(i > 0 ? i - 1 : 0);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) row[k] = stn[r * 8 + k];
+    }
+    ISSUE_ORDER();
+    const double hv0 = __builtin_fma(t, w6, qv0);
+    const double hv1 = __builtin_fma(t, w7, qv1);
+    p = qz + w - (k0r * hv0 + k1r * hv1);  // (not used after stage 0)
+    *pdst = p;
+    const double kff = (r == 0) ? hi00 * hv0 + hi01 * hv1 : hi01 * hv0 + hi11 * hv1;
+    *((own && r < 2) ? st + ST_KFF + 2 * s + r : junk1) = kff;
+    wave_sync();
   }
+  PT_MARK(8 + NRHS - 1)
+  // ---- forward: dv_i = -kff_i - K dz_i,  dz_{i+1} = Abar dz_i + Bbar dv_i
+  // lanes r < 6 take a state row, lanes 6, 7 the two rows of K: column k of M is [A B](:, k) | K(:, k)
+  *(own ? L.kn(0) + reg + r : junk0) = 0.0;
+  double col[8], a0;  // M(r, :) and the feed-forward term, fetched one stage ahead
+  {
+    const double* st = L.st(0);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) col[k] = st[k * 8 + r];
+    a0 = st[ST_KFF + 2 * s + (r & 1)];
+  }
+  wave_sync();
   for (int i = 0; i < N - 1; ++i) {
     const double* st = L.st(i);
     double* kn = L.kn(i);
-    double* kx = L.kn(i + 1);
-    const double t = st[ST_DT];
-    double k0[8], k1[8], arow[6];
+    double dz[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      k0[k] = st[ST_K + k];
-      k1[k] = st[ST_K + 8 + k];
+    for (int k = 0; k < 8; ++k) dz[k] = kn[reg + k];
+    ISSUE_ORDER();
+    const double b0 = st[6 * 8 + r], b1 = st[7 * 8 + r], t = st[ST_DT];
+    ISSUE_ORDER();
+    double acc = (r >= 6) ? a0 : 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) acc = __builtin_fma(col[k], dz[k], acc);
+    const double ax = acc;  // state rows: A dz_x
+    acc = __builtin_fma(col[6], dz[6], acc);
+    acc = __builtin_fma(col[7], dz[7], acc);
+    AFTER_VALUE(acc);
+    const double dv = -acc;  // lanes 6, 7
+    const double du = __builtin_fma(t, dv, (r == 6) ? dz[6] : dz[7]);
+    double du0, du1;
+    spread2(du, du0, du1);
+    ISSUE_ORDER();
+    {
+      const double* stn = L.st(i < N - 2 ? i + 1 : i);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) col[k] = stn[k * 8 + r];
+      a0 = stn[ST_KFF + 2 * s + (r & 1)];
     }
-    const int rr = r < 6 ? r : 0;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) arow[k] = st[k * 6 + rr];  // A[r][k]
-    const double b0 = st[36 + rr], b1 = st[42 + rr];      // B[r][0], B[r][1]
-#pragma unroll
-    for (int s = 0; s < NRHS; ++s) {
-      const int reg = KN_R0 + 10 * s;
-      double dz[8];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) dz[k] = lane_bcast(d[s], k);
-      double dv0 = -st[ST_KFF + 2 * s], dv1 = -st[ST_KFF + 2 * s + 1];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        dv0 = __builtin_fma(-k0[k], dz[k], dv0);
-        dv1 = __builtin_fma(-k1[k], dz[k], dv1);
-      }
-      const double du0 = __builtin_fma(t, dv0, dz[6]), du1 = __builtin_fma(t, dv1, dz[7]);
-      double nx = b0 * du0 + b1 * du1;
-#pragma unroll
-      for (int k = 0; k < 6; ++k) nx = __builtin_fma(arow[k], dz[k], nx);
-      d[s] = (r < 6) ? nx : (r == 6 ? du0 : du1);
-      if (store) kx[reg + r] = d[s];
-      if (lane == 0) {
-        kn[reg + 8] = dv0;
-        kn[reg + 9] = dv1;
-      }
-    }
+    ISSUE_ORDER();
+    const double nx = __builtin_fma(b1, du1, __builtin_fma(b0, du0, ax));
+    const double d = (r < 6) ? nx : du;
+    *(own ? kn + LMPC_KNOT_STRIDE + reg + r : junk0) = d;
+    *((own && r >= 6) ? kn + reg + 2 + r : junk1) = dv;
+    wave_sync();
   }
-  wave_sync();
   PT_MARK(10 + NRHS - 1)
 }
 
 // Closed-loop rollout z_{i+1} = Abar z_i + Bbar v_i + gbar, v_i = -K_i z_i (absolute variables).
 // The linearised model can be open-loop unstable (|eig A| > 1 at low speed with dt = 25 ms), so
-// the start trajectory is generated under the stabilising Riccati feedback.
+// the start trajectory is generated under the stabilising Riccati feedback.  Same lane roles as the
+// forward sweep of riccati_solve.
 __device__ void feedback_rollout(const Lds& L, int lane) {
   const int N = L.N, r = lane & 7;
-  const bool on = lane < 8;
+  const bool own = lane < 8;
+  double* T = L.tail();
+  double* const junk0 = T + TL_W + lane;
+  double* const junk1 = T + TL_W + 80 + lane;
   for (int i = 0; i < N - 1; ++i) {
-    if (on) {
-      const double* st = L.st(i);
-      double* kn = L.kn(i);
-      const double t = st[ST_DT];
-      double d[8];
+    const double* st = L.st(i);
+    double* kn = L.kn(i);
+    double dz[8], col[8];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) d[k] = kn[k];
-      double v0 = 0.0, v1 = 0.0;
+    for (int k = 0; k < 8; ++k) dz[k] = kn[k];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        v0 -= st[ST_K + k] * d[k];
-        v1 -= st[ST_K + 8 + k] * d[k];
-      }
-      const double u0 = d[6] + t * v0, u1 = d[7] + t * v1;
-      double nx;
-      if (r < 6) {
-        nx = st[ST_G + r] + st[36 + r] * u0 + st[42 + r] * u1;
+    for (int k = 0; k < 8; ++k) col[k] = st[k * 8 + r];
+    const double t = st[ST_DT];
+    const double g = st[ST_G + (r < 6 ? r : 0)];
+    double acc = 0.0;
 #pragma unroll
-        for (int k = 0; k < 6; ++k) nx += st[k * 6 + r] * d[k];
-      } else {
-        nx = (r == 6) ? u0 : u1;
-      }
-      L.kn(i + 1)[r] = nx;
-      if (r == 0) {
-        kn[8] = v0;
-        kn[9] = v1;
-      }
-    }
+    for (int k = 0; k < 6; ++k) acc = __builtin_fma(col[k], dz[k], acc);
+    const double ax = acc;
+    acc = __builtin_fma(col[6], dz[6], acc);
+    acc = __builtin_fma(col[7], dz[7], acc);
+    const double v = -acc;
+    const double u = __builtin_fma(t, v, (r == 6) ? dz[6] : dz[7]);
+    const double u0 = lane_bcast(u, 6), u1 = lane_bcast(u, 7);
+    const double nx = g + __builtin_fma(col[7], u1, __builtin_fma(col[6], u0, ax));
+    *(own ? kn + LMPC_KNOT_STRIDE + r : junk0) = (r < 6) ? nx : u;
+    *((own && r >= 6) ? kn + 2 + r : junk1) = v;
     wave_sync();
   }
 }
@@ -442,7 +518,8 @@ __global__ __launch_bounds__(64, ((KQ <= 4 && KS == 0) ? 2 : 1)) void lmpc_solve
     const double* wsb = ws_lin + (size_t)b * NS * LMPC_LIN_RECORD;
     for (int e = lane; e < NS * LMPC_LIN_RECORD; e += 64) {
       const int i = e / LMPC_LIN_RECORD, o = e - i * LMPC_LIN_RECORD;
-      L.st(i)[o] = wsb[e];
+      const int c = o / 6;
+      L.st(i)[o < 48 ? c * 8 + (o - c * 6) : ST_G + (o - 48)] = wsb[e];
     }
     for (int i = lane; i < NS; i += 64) L.st(i)[ST_DT] = T_ref[(size_t)i * B + b];
     for (int i = lane; i < N; i += 64) {
