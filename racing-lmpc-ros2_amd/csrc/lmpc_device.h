@@ -32,7 +32,7 @@ struct lmpc_params {
 
 // LDS record sizes (in doubles) of the solve kernel; see DESIGN.md "data layout".
 #define LMPC_STAGE_STRIDE 78
-#define LMPC_KNOT_STRIDE 34
+#define LMPC_KNOT_STRIDE 36
 #define LMPC_TAIL_DOUBLES 320
 #define LMPC_TAIL_DOUBLES_LMPC 464  // + terminal-block scratch (PT, T, F^-1, a, ...)
 #define LMPC_LIN_RECORD 54  // per stage in the linearisation workspace: ABt[8][6] | g[6]

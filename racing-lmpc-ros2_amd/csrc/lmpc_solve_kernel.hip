@@ -51,8 +51,8 @@ struct Prof {};
 // stage record i (stride 78): M[8][8] @0: column c of the stage model with the feedback gain appended,
 //                               M[c][k] = [A B][k][c] (k < 6), M[c][6 + j] = K_j[c]
 //                             | g[6] @64 | Hinv (h00,h01,h11) @70 | dt @73 | kff[2 rhs][2] @74
-// knot record i (stride 34):  z[8] v[2] @0 | rhs0: Th / q / d [10] @10 | rhs1: q / e [10] @20
-//                             | csig @30 | eyT / eyD @31 | (free) @32 | qlin_vx @33
+// knot record i (stride 36):  z[8] v[2] @0 | rhs0: Th / q / d [10] @10 | rhs1: q / e [10] @20
+//                             | csig @30 | eyT / eyD @31 | boundary row bounds (hi, lo) @32 | qlin_vx @34
 // tail: P[8][10] @0 | W[8][10] @80 | Y[8][10] @160 | pvec[2 buf][2 rhs][8] @240 | consts @272 (48)
 #define ST_G 64
 #define ST_HI 70
@@ -62,7 +62,8 @@ struct Prof {};
 #define KN_R1 20
 #define KN_CSIG 30
 #define KN_EY 31
-#define KN_QLIN 33
+#define KN_BHL 32
+#define KN_QLIN 34
 #define TL_P 0
 #define TL_W 80
 #define TL_Y 160
@@ -72,8 +73,7 @@ struct Prof {};
 #define CT_QT 6
 #define CT_QU 12
 #define CT_SV 16
-#define CT_HI 20
-#define CT_LO 30
+#define CT_HL 20    // box bounds of the ten primal components, (hi, lo) interleaved
 #define CT_ZERO 40  // a 0.0 entry: coefficient slot for "no term"
 #define CT_E 41     // 2 * convex_hull_slack (LMPC)
 // LMPC extension of the tail (only allocated when learning): terminal-block quantities
@@ -91,6 +91,8 @@ struct Prof {};
 #define F_SIG 4
 #define F_QLIN 8
 #define F_MOVE 16
+#define F_EY 32
+#define F_SCH 64
 #define MROW 10  // padded row stride of the 8x8 work matrices (conflict-free b128 row reads)
 
 // The workgroup is a single wavefront and the LDS executes one wave's DS instructions in issue order,
@@ -98,20 +100,26 @@ struct Prof {};
 // compiler must not move memory operations across the exchange point.
 __device__ __forceinline__ void wave_sync() { __builtin_amdgcn_wave_barrier(); }
 
+// A value that is the same in every lane, moved to scalar registers (two v_readfirstlane): the solver's
+// wave-wide scalars (mu, step lengths, sigma, ...) then cost no vector registers while they are carried
+// across the Riccati sweeps, and feed the FP64 VALU as scalar operands.
+__device__ __forceinline__ double uni(double x) {
+  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)), __builtin_amdgcn_readfirstlane(__double2loint(x)));
+}
 __device__ __forceinline__ double wave_sum(double x) {
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) x += __shfl_xor(x, m);
-  return x;
+  return uni(x);
 }
 __device__ __forceinline__ double wave_max(double x) {
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) x = fmax(x, __shfl_xor(x, m));
-  return x;
+  return uni(x);
 }
 __device__ __forceinline__ double wave_min(double x) {
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) x = fmin(x, __shfl_xor(x, m));
-  return x;
+  return uni(x);
 }
 
 // 1/x: hardware v_rcp_f64 seed + one Newton step (full fp64 accuracy for normal x); replaces the
@@ -130,6 +138,8 @@ __device__ __forceinline__ void wave_sum_n(double (&v)[NV]) {
 #pragma unroll
     for (int k = 0; k < NV; ++k) v[k] += __shfl_xor(v[k], m);
   }
+#pragma unroll
+  for (int k = 0; k < NV; ++k) v[k] = uni(v[k]);
 }
 
 // Inverse of a symmetric positive definite 6x6 (row-major, full storage) by Cholesky; every index is
@@ -527,20 +537,22 @@ __global__ __launch_bounds__(64, ((KQ <= 4 && KS == 0) ? 2 : 1)) void lmpc_solve
       kn[KN_QLIN] = P.learning ? 0.0 : (i == N - 1 ? P.qv_term : P.qv_stage) * vref[(size_t)i * B + b];
       kn[8] = 0.0;
       kn[9] = 0.0;
+      kn[KN_BHL] = bl[(size_t)i * B + b] - P.marg;
+      kn[KN_BHL + 1] = br[(size_t)i * B + b] + P.marg;
     }
     if (lane < 6) {
       KN0[lane] = x_ic[(size_t)lane * B + b];
       ct[CT_QD + lane] = P.learning ? 0.0 : P.Qd[lane];
       ct[CT_QT + lane] = P.learning ? 0.0 : P.Qt[lane];
-      ct[CT_HI + lane] = P.x_max[lane];
-      ct[CT_LO + lane] = P.x_min[lane];
+      ct[CT_HL + 2 * lane] = P.x_max[lane];
+      ct[CT_HL + 2 * lane + 1] = P.x_min[lane];
     } else if (lane < 8) {
       KN0[lane] = u_ic[(size_t)(lane - 6) * B + b];
-      ct[CT_HI + lane] = P.u_hi[lane - 6];
-      ct[CT_LO + lane] = P.u_lo[lane - 6];
+      ct[CT_HL + 2 * lane] = P.u_hi[lane - 6];
+      ct[CT_HL + 2 * lane + 1] = P.u_lo[lane - 6];
     } else if (lane < 10) {
-      ct[CT_HI + lane] = P.v_hi[lane - 8];
-      ct[CT_LO + lane] = P.v_lo[lane - 8];
+      ct[CT_HL + 2 * lane] = P.v_hi[lane - 8];
+      ct[CT_HL + 2 * lane + 1] = P.v_lo[lane - 8];
     } else if (lane < 14) {
       ct[CT_QU + lane - 10] = P.Qu[lane - 10];
     } else if (lane < 18) {
@@ -555,19 +567,23 @@ __global__ __launch_bounds__(64, ((KQ <= 4 && KS == 0) ? 2 : 1)) void lmpc_solve
   PT_MARK(0)
 
   // ---------------- slot ownership ----------------
-  // slot j = lane + 64 q  ->  knot i = j / 11, kind sl = j % 11.  Kinds 0..9 address the primal
+  // slot j = lane + 64 q  ->  knot i = j / 11, kind sl = j % 11.  Kinds 0..9 constrain the primal
   // component (z[0..7], v[0..1]) at offset sl of the knot record; kind 10 is the track boundary
   // row pair on e_y (offset 1) which also carries the shared slack sigma.  Everything a slot needs
-  // is reduced to offsets and 0/1 masks here so that the per-iteration row code is branch-free:
-  // an absent row keeps t = 1, lam = 0 and a zero mask.
+  // is reduced to LDS offsets and flag bits here so that the per-iteration row code is branch-free
+  // (its loads batch and the slots of a lane interleave): an absent row keeps t = 1, lam = 0 and a
+  // clear flag; a lane's surplus slots (j >= 11 N) point at a dead record inside the factor's work
+  // matrices, so their loads and stores are harmless.
   const bool has_sigma = P.has_sigma != 0;
-  int s_ko[KQ];           // offset of the slot's knot record from knot 0 (doubles); -1: no slot
-  int s_vo[KQ];           // offset of the constrained value inside the knot record
-  int s_wo[KQ];           // where the slot writes its barrier weight / gradient entry
-  int s_g[KQ];            // packed gradient recipe: ct index c0 | o0 << 8 | ct index c1 << 16 | o1 << 24
-  int s_f[KQ];            // flags: F_UP / F_LO row exists, F_SIG boundary slot carrying sigma,
-                          // F_QLIN component takes the linear vx cost term, F_MOVE owns a moving primal component
-  double s_hi[KQ], s_lo[KQ], s_tu[KQ], s_tl[KQ], s_lu[KQ], s_ll[KQ], s_pu[KQ], s_pl[KQ];
+  const int KNB = NS * LMPC_STAGE_STRIDE;            // knot 0, offset from the LDS base (doubles)
+  const int JB = KNB + N * LMPC_KNOT_STRIDE + TL_W;  // dead record (34 cells of W)
+  const int CTB = KNB + N * LMPC_KNOT_STRIDE + TL_CT;
+  int o_val[KQ];  // the constrained value; its Newton step sits at +10 (rhs0) and +20 (rhs1)
+  int o_hl[KQ];   // the row pair's bounds (hi, lo): box table for kinds 0..9, knot record for the boundary
+  int s_gf[KQ];   // gradient recipe: ct index of the coefficient on the value | on its partner << 8 | (partner offset + 1) << 16,
+                  // and flags << 20: F_UP / F_LO row exists, F_SIG boundary slot carrying sigma, F_QLIN takes the linear
+                  // vx cost, F_MOVE owns a moving primal component, F_EY boundary slot, F_SCH boundary slot of a knot >= 1
+  double s_tu[KQ], s_tl[KQ], s_lu[KQ], s_ll[KQ], s_pu[KQ], s_pl[KQ];
   double m_rows = 0.0;
 #pragma unroll
   for (int q = 0; q < KQ; ++q) {
@@ -575,36 +591,28 @@ __global__ __launch_bounds__(64, ((KQ <= 4 && KS == 0) ? 2 : 1)) void lmpc_solve
     const bool valid = j < NSLOT * N;
     const int i = valid ? j / NSLOT : 0;
     const int sl = valid ? j - i * NSLOT : 0;
-    s_ko[q] = valid ? i * LMPC_KNOT_STRIDE : -1;
-    s_vo[q] = sl < SL_EY ? sl : 1;
-    s_wo[q] = sl < SL_EY ? KN_R0 + sl : KN_EY;
+    const int kb = valid ? KNB + i * LMPC_KNOT_STRIDE : JB;
+    o_val[q] = kb + (sl < SL_EY ? sl : 1);
+    o_hl[q] = (valid && sl < SL_EY) ? CTB + CT_HL + 2 * sl : kb + KN_BHL;
     double hi = INFINITY, lo = -INFINITY;
     bool on = false;
-    int c0 = CT_ZERO, o0 = 0, c1 = CT_ZERO, o1 = 0;
+    int ca = CT_ZERO, cb = CT_ZERO, pd = 0;
     if (valid) {
       if (sl < SL_EY) {
-        hi = ct[CT_HI + sl];
-        lo = ct[CT_LO + sl];
+        hi = ct[CT_HL + 2 * sl];
+        lo = ct[CT_HL + 2 * sl + 1];
         if (sl < SL_U) {
           on = i >= 1 && i <= N - 2;
-          c0 = (i == N - 1 ? CT_QT : CT_QD) + sl;
-          o0 = sl;
-        } else if (sl < SL_V) {
-          on = i >= 1;
-          if (i >= 1) {
-            c0 = CT_QU + (sl - SL_U) * 2;
-            c1 = c0 + 1;
-          }
-          o0 = 6;
-          o1 = 7;
+          ca = (i == N - 1 ? CT_QT : CT_QD) + sl;
         } else {
-          on = i <= N - 2;
-          if (i <= N - 2) {
-            c0 = CT_SV + (sl - SL_V) * 2;
-            c1 = c0 + 1;
+          const bool uslot = sl < SL_V;
+          const int k = uslot ? sl - SL_U : sl - SL_V;  // row of the 2x2 block (Qu on u, Sv on v)
+          on = uslot ? i >= 1 : i <= N - 2;
+          if (on) {
+            ca = (uslot ? CT_QU : CT_SV) + 3 * k;        // diagonal entry
+            cb = (uslot ? CT_QU : CT_SV) + 2 * k + 1 - k;  // [k][1-k]
           }
-          o0 = 8;
-          o1 = 9;
+          pd = k == 0 ? 1 : -1;
         }
       } else {
         hi = bl[(size_t)i * B + b] - P.marg;
@@ -612,17 +620,22 @@ __global__ __launch_bounds__(64, ((KQ <= 4 && KS == 0) ? 2 : 1)) void lmpc_solve
         on = has_sigma || i >= 1;
       }
     }
-    s_g[q] = c0 | (o0 << 8) | (c1 << 16) | (o1 << 24);
     const bool au = on && (hi < INFINITY), al = on && (lo > -INFINITY);
-    s_f[q] = (au ? F_UP : 0) | (al ? F_LO : 0) | ((valid && sl == SL_EY && has_sigma) ? F_SIG : 0) |
-             ((valid && sl == 3) ? F_QLIN : 0) | ((valid && sl < SL_EY && (i >= 1 || sl >= SL_V)) ? F_MOVE : 0);
-    s_hi[q] = au ? hi : 0.0;
-    s_lo[q] = al ? lo : 0.0;
+    const bool eys = valid && sl == SL_EY;
+    const int fl = (au ? F_UP : 0) | (al ? F_LO : 0) | ((eys && has_sigma) ? F_SIG : 0) | ((valid && sl == 3) ? F_QLIN : 0) |
+             ((valid && sl < SL_EY && (i >= 1 || sl >= SL_V)) ? F_MOVE : 0) | (eys ? F_EY : 0) | ((eys && i >= 1) ? F_SCH : 0);
+    s_gf[q] = ca | (cb << 8) | ((pd + 1) << 16) | (fl << 20);
     m_rows += (au ? 1.0 : 0.0) + (al ? 1.0 : 0.0);
     s_tu[q] = s_tl[q] = 1.0;
     s_lu[q] = s_ll[q] = 0.0;
     s_pu[q] = s_pl[q] = 0.0;
   }
+  // cell next to a boundary slot's weight that takes the sigma coupling coefficient (dead cell otherwise)
+  auto flags = [&](int q) { return s_gf[q] >> 20; };
+  // where the slot writes its barrier weight / gradient entry: the rhs0 cell of its component, or the boundary cell
+  auto o_w = [&](int q) { return o_val[q] + ((flags(q) & F_EY) ? KN_EY - 1 : KN_R0); };
+  auto o_csig = [&](int q) { return (flags(q) & F_EY) ? o_val[q] + (KN_CSIG - 1) : JB + KN_CSIG; };
+  auto bounds = [&](int q) { return *reinterpret_cast<const double2*>(&lds[o_hl[q]]); };
   // ---------------- LMPC: simplex rows lambda_j >= 0, one safe-set point per lane and k < KS ----------------
   // (racing_mpc.cpp:484-504).  The points are centred on the first one (valid because 1'lambda = 1):
   // all sums below then run over O(1) offsets instead of absolute abscissae.
@@ -647,7 +660,7 @@ __global__ __launch_bounds__(64, ((KQ <= 4 && KS == 0) ? 2 : 1)) void lmpc_solve
     }
   }
   const double m_tot = wave_sum(m_rows) + (has_sigma ? 1.0 : 0.0);
-  const double inv_m = 1.0 / m_tot;
+  const double inv_m = uni(1.0 / m_tot);
 
   // knot-0 feasibility: the state box applies to x_0 = x_ic (racing_mpc.cpp:147,201)
   bool feasible = true;
@@ -655,7 +668,7 @@ __global__ __launch_bounds__(64, ((KQ <= 4 && KS == 0) ? 2 : 1)) void lmpc_solve
     bool ok = true;
     if (lane < 6) {
       const double v = KN0[lane];
-      ok = (v <= ct[CT_HI + lane]) && (v >= ct[CT_LO + lane]);
+      ok = (v <= ct[CT_HL + 2 * lane]) && (v >= ct[CT_HL + 2 * lane + 1]);
     }
     if (lane == 6 && !has_sigma) {
       const double ey = KN0[1];
@@ -669,10 +682,8 @@ __global__ __launch_bounds__(64, ((KQ <= 4 && KS == 0) ? 2 : 1)) void lmpc_solve
   // ---------------- start point: minimiser of the cost over the dynamics alone ----------------
 #pragma unroll
   for (int q = 0; q < KQ; ++q) {
-    if (s_ko[q] < 0) continue;
-    double* kn = KN0 + s_ko[q];
-    kn[s_wo[q]] = 0.0;
-    if (s_wo[q] == KN_EY) kn[KN_CSIG] = 0.0;
+    lds[o_w(q)] = 0.0;
+    lds[o_csig(q)] = 0.0;
   }
   if constexpr (KS > 0) {  // lambda frozen at 1/S: terminal cost eps'D eps only
     if (lane < 36) T[TL_PT + lane] = (lane % 7 == 0) ? ct[CT_E + lane / 7] : 0.0;
@@ -711,20 +722,26 @@ __global__ __launch_bounds__(64, ((KQ <= 4 && KS == 0) ? 2 : 1)) void lmpc_solve
     // ======== rows: complementarity, residual, barrier weights ========
     if (ipm) {
       double musum = 0.0, rdl = 0.0, eysum = 0.0;
+      {
+        double val[KQ];
+        double2 hl[KQ];
 #pragma unroll
-      for (int q = 0; q < KQ; ++q) {
-        if (s_ko[q] < 0) continue;
-        double* kn = KN0 + s_ko[q];
-        const double val = kn[s_vo[q]];
-        const int f = s_f[q];
-        const double sg = (f & F_SIG) ? sigma : 0.0;
-        const double thu = s_lu[q] * frcp(s_tu[q]), thd = s_ll[q] * frcp(s_tl[q]);
-        musum += s_lu[q] * s_tu[q] + s_ll[q] * s_tl[q];
-        rdl = fmax(rdl, (f & F_UP) ? fabs(val - sg + s_tu[q] - s_hi[q]) : 0.0);
-        rdl = fmax(rdl, (f & F_LO) ? fabs(-val - sg + s_tl[q] + s_lo[q]) : 0.0);
-        kn[s_wo[q]] = thu + thd;
-        if (s_wo[q] == KN_EY) kn[KN_CSIG] = (f & F_SIG) ? (thd - thu) : 0.0;
-        eysum += (f & F_SIG) ? (thu + thd) : 0.0;
+        for (int q = 0; q < KQ; ++q) {
+          val[q] = lds[o_val[q]];
+          hl[q] = bounds(q);
+        }
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) {
+          const int f = flags(q);
+          const double sg = (f & F_SIG) ? sigma : 0.0;
+          const double thu = s_lu[q] * frcp(s_tu[q]), thd = s_ll[q] * frcp(s_tl[q]);
+          musum += s_lu[q] * s_tu[q] + s_ll[q] * s_tl[q];
+          rdl = fmax(rdl, (f & F_UP) ? fabs(val[q] - sg + s_tu[q] - hl[q].x) : 0.0);
+          rdl = fmax(rdl, (f & F_LO) ? fabs(-val[q] - sg + s_tl[q] + hl[q].y) : 0.0);
+          lds[o_w(q)] = thu + thd;
+          lds[o_csig(q)] = (f & F_SIG) ? (thd - thu) : 0.0;
+          eysum += (f & F_SIG) ? (thu + thd) : 0.0;
+        }
       }
       if constexpr (KS > 0) {
         double tt[21], av[14];  // T (upper triangle) | a[6], sum 1/theta, U lambda [6], sum lambda
@@ -796,15 +813,19 @@ __global__ __launch_bounds__(64, ((KQ <= 4 && KS == 0) ? 2 : 1)) void lmpc_solve
           T[TL_S11] = s11;
         }
       }
-      musum = wave_sum(musum);
+      {
+        double red[2] = {musum, eysum};
+        wave_sum_n<2>(red);
+        musum = red[0];
+        hsig = P.qsig + red[1];
+      }
       rdmax = wave_max(rdl);
-      hsig = P.qsig + wave_sum(eysum);
       if (has_sigma) {
         musum += ts * lams;
         rdmax = fmax(rdmax, fabs(-sigma + ts));
-        hsig += lams / ts;
+        hsig = uni(hsig + lams / ts);
       }
-      mu = musum * inv_m;
+      mu = uni(musum * inv_m);
       if (!(mu == mu) || !(rdmax == rdmax)) {
         status = LMPC_SOLVE_INFEASIBLE;
         break;
@@ -870,24 +891,33 @@ __global__ __launch_bounds__(64, ((KQ <= 4 && KS == 0) ? 2 : 1)) void lmpc_solve
           }
         }
       }
+      {
+        double val[KQ], par[KQ], ca[KQ], cb[KQ], ql[KQ];
+        double2 hl[KQ];
 #pragma unroll
-      for (int q = 0; q < KQ; ++q) {
-        if (s_ko[q] < 0) continue;
-        double* kn = KN0 + s_ko[q];
-        const double val = kn[s_vo[q]];
-        const int f = s_f[q];
-        const double sg = (f & F_SIG) ? sigma : 0.0;
-        const double itu = frcp(s_tu[q]), itl = frcp(s_tl[q]);
-        double cu = s_lu[q] * itu * (val - sg + s_tu[q] - s_hi[q]) + (smu - pm * s_pu[q]) * itu;
-        double cd = s_ll[q] * itl * (-val - sg + s_tl[q] + s_lo[q]) + (smu - pm * s_pl[q]) * itl;
-        cu = (ipm && (f & F_UP)) ? cu : 0.0;
-        cd = (ipm && (f & F_LO)) ? cd : 0.0;
-        const int gr = s_g[q];
-        const double g = ct[gr & 0xff] * kn[(gr >> 8) & 0xff] + ct[(gr >> 16) & 0xff] * kn[(gr >> 24) & 0xff] +
-                         ((f & F_QLIN) ? kn[KN_QLIN] : 0.0);
-        kn[s_wo[q]] = (s_wo[q] == KN_EY) ? (cu - cd) : (g + cu - cd);
-        if (pass == 0 && s_wo[q] != KN_EY) kn[s_wo[q] + 10] = 0.0;
-        sgsum += (f & F_SIG) ? (cu + cd) : 0.0;
+        for (int q = 0; q < KQ; ++q) {
+          const int gr = s_gf[q];
+          val[q] = lds[o_val[q]];
+          hl[q] = bounds(q);
+          par[q] = lds[o_val[q] + ((gr >> 16) & 3) - 1];
+          ca[q] = lds[CTB + (gr & 0xff)];
+          cb[q] = lds[CTB + ((gr >> 8) & 0xff)];
+          ql[q] = lds[o_val[q] + (KN_QLIN - 3)];
+        }
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) {
+          const int f = flags(q);
+          const double sg = (f & F_SIG) ? sigma : 0.0;
+          const double itu = frcp(s_tu[q]), itl = frcp(s_tl[q]);
+          double cu = s_lu[q] * itu * (val[q] - sg + s_tu[q] - hl[q].x) + (smu - pm * s_pu[q]) * itu;
+          double cd = s_ll[q] * itl * (-val[q] - sg + s_tl[q] + hl[q].y) + (smu - pm * s_pl[q]) * itl;
+          cu = (ipm && (f & F_UP)) ? cu : 0.0;
+          cd = (ipm && (f & F_LO)) ? cd : 0.0;
+          const double g = ca[q] * val[q] + cb[q] * par[q] + ((f & F_QLIN) ? ql[q] : 0.0);  // (zero coefficients on a boundary slot)
+          lds[o_w(q)] = g + cu - cd;
+          if (pass == 0) lds[(f & F_EY) ? JB + KN_EY : o_w(q) + 10] = 0.0;
+          sgsum += (f & F_SIG) ? (cu + cd) : 0.0;
+        }
       }
       wave_sync();
       PT_MARK(12)
@@ -908,28 +938,41 @@ __global__ __launch_bounds__(64, ((KQ <= 4 && KS == 0) ? 2 : 1)) void lmpc_solve
       else
         riccati_solve<1>(L, lane, pf);
       PT_MARK(5)
-      // ======== boundary slack by Schur complement ========
-      double cfs = 0.0;
-      if (ipm && has_sigma) {
-        double cep = 0.0, cap = 0.0;
+      // ======== step of every constrained value; boundary slack by Schur complement ========
+      double dz0[KQ], dz1[KQ], val[KQ];
+      double2 hl[KQ];
 #pragma unroll
-        for (int q = 0; q < KQ; ++q)
-          if (s_ko[q] > 0 && s_wo[q] == KN_EY) {  // boundary slots of knots >= 1
-            const double* kn = KN0 + s_ko[q];
-            cap += kn[KN_CSIG] * kn[KN_R0 + 1];
-            cep += kn[KN_CSIG] * kn[KN_R1 + 1];
-          }
-        const double ca = wave_sum(cap);
-        if (pass == 0) ce = wave_sum(cep);
-        const double its = frcp(ts);
-        cfs = lams * its * (-sigma + ts) + (smu - pm * dts * dlams) * its;
-        const double qsg = P.qsig * sigma - wave_sum(sgsum) - cfs;
-        dsigma = -(qsg + ca) / (hsig + ce);
+      for (int q = 0; q < KQ; ++q) {
+        dz0[q] = lds[o_val[q] + 10];
+        dz1[q] = lds[o_val[q] + 20];
+        val[q] = lds[o_val[q]];
+        hl[q] = bounds(q);
       }
       if (!ipm) {
 #pragma unroll
-        for (int q = 0; q < KQ; ++q) d_val[q] = (s_ko[q] < 0) ? 0.0 : (KN0 + s_ko[q])[KN_R0 + s_vo[q]];
+        for (int q = 0; q < KQ; ++q) d_val[q] = dz0[q];
         break;
+      }
+      double cfs = 0.0;
+      if (has_sigma) {
+        double red[3] = {0.0, 0.0, sgsum};  // c'dz (this rhs), c'e (Schur vector), sum of boundary coefficients
+        {
+          double cs[KQ];
+#pragma unroll
+          for (int q = 0; q < KQ; ++q) cs[q] = lds[o_csig(q)];
+#pragma unroll
+          for (int q = 0; q < KQ; ++q) {
+            const bool sch = (flags(q) & F_SCH) != 0;
+            red[0] += sch ? cs[q] * dz0[q] : 0.0;
+            red[1] += sch ? cs[q] * dz1[q] : 0.0;
+          }
+        }
+        wave_sum_n<3>(red);
+        if (pass == 0) ce = red[1];
+        const double its = frcp(ts);
+        cfs = lams * its * (-sigma + ts) + (smu - pm * dts * dlams) * its;
+        const double qsg = P.qsig * sigma - red[2] - cfs;
+        dsigma = uni(-(qsg + red[0]) / (hsig + ce));
       }
       if constexpr (KS > 0) {
         // d lambda_j = (r_j - u_j'F^-1 gamma)/theta_j - Mi1_j (sr - a'F^-1 gamma - sx.r1)/s11,  r_j = u_j'E dx_T - bl_j
@@ -974,30 +1017,31 @@ __global__ __launch_bounds__(64, ((KQ <= 4 && KS == 0) ? 2 : 1)) void lmpc_solve
         }
       }
       // ======== row steps; largest feasible step as 1 / max(1, max -dt/t, max -dlam/lam) ========
-      // (dt, dlam) of a row from the step of the value it constrains; evaluated twice (ratio scan,
-      // then use) rather than kept, to stay inside the register budget of two waves per SIMD.
       auto row_step = [&](bool on, double t, double lam, double pprod, double rd, double cdy, double& dt_, double& dl_,
                           double& it_) {
         it_ = frcp(t);
         dt_ = on ? (-rd - cdy) : 0.0;
         dl_ = on ? (-lam + (smu - pm * pprod) * it_ - lam * it_ * dt_) : 0.0;
       };
+      double dtu[KQ], dlu[KQ], dtl[KQ], dll[KQ];
       double rmax = 1.0;
 #pragma unroll
       for (int q = 0; q < KQ; ++q) {
-        d_val[q] = 0.0;
-        if (s_ko[q] < 0) continue;
-        const double* kn = KN0 + s_ko[q];
-        const int off = s_vo[q], f = s_f[q];
-        const double dval = kn[KN_R0 + off] + dsigma * kn[KN_R1 + off];
+        const int f = flags(q);
+        const double dval = dz0[q] + dsigma * dz1[q];
         d_val[q] = dval;
-        const double val = kn[off];
         const double sg = (f & F_SIG) ? sigma : 0.0, dsg = (f & F_SIG) ? dsigma : 0.0;
-        double dt_, dl_, it_;
-        row_step(f & F_UP, s_tu[q], s_lu[q], s_pu[q], val - sg + s_tu[q] - s_hi[q], dval - dsg, dt_, dl_, it_);
-        rmax = fmax(rmax, fmax(-dt_ * it_, -dl_ * frcp(fmax(s_lu[q], 1e-300))));
-        row_step(f & F_LO, s_tl[q], s_ll[q], s_pl[q], -val - sg + s_tl[q] + s_lo[q], -dval - dsg, dt_, dl_, it_);
-        rmax = fmax(rmax, fmax(-dt_ * it_, -dl_ * frcp(fmax(s_ll[q], 1e-300))));
+        const double itu = frcp(s_tu[q]), itl = frcp(s_tl[q]);
+        const double a = (f & F_UP) ? -(val[q] - sg + s_tu[q] - hl[q].x) - (dval - dsg) : 0.0;
+        const double bq = (f & F_UP) ? -s_lu[q] + (smu - pm * s_pu[q]) * itu - s_lu[q] * itu * a : 0.0;
+        const double c = (f & F_LO) ? -(-val[q] - sg + s_tl[q] + hl[q].y) - (-dval - dsg) : 0.0;
+        const double d = (f & F_LO) ? -s_ll[q] + (smu - pm * s_pl[q]) * itl - s_ll[q] * itl * c : 0.0;
+        dtu[q] = a;
+        dlu[q] = bq;
+        dtl[q] = c;
+        dll[q] = d;
+        rmax = fmax(rmax, fmax(-a * itu, -bq * frcp(fmax(s_lu[q], 1e-300))));
+        rmax = fmax(rmax, fmax(-c * itl, -d * frcp(fmax(s_ll[q], 1e-300))));
       }
       if constexpr (KS > 0) {
 #pragma unroll
@@ -1010,33 +1054,24 @@ __global__ __launch_bounds__(64, ((KQ <= 4 && KS == 0) ? 2 : 1)) void lmpc_solve
       rmax = wave_max(rmax);
       if (has_sigma) {
         const double th = lams / ts, rds = -sigma + ts;
-        dts = -rds + dsigma;
-        dlams = -lams + cfs - th * rds - th * dts;
+        dts = uni(-rds + dsigma);
+        dlams = uni(-lams + cfs - th * rds - th * dts);
         rmax = fmax(rmax, fmax(-dts / ts, -dlams / lams));
       }
-      const double amax = 1.0 / rmax;
-      if (pass == 1) alpha = fmin(1.0, tau * amax);
+      const double amax = uni(1.0 / rmax);
+      if (pass == 1) alpha = uni(fmin(1.0, tau * amax));
       double sacc = 0.0;
 #pragma unroll
       for (int q = 0; q < KQ; ++q) {
-        if (s_ko[q] < 0) continue;
-        const double* kn = KN0 + s_ko[q];
-        const int f = s_f[q];
-        const double dval = d_val[q];
-        const double val = kn[s_vo[q]];
-        const double sg = (f & F_SIG) ? sigma : 0.0, dsg = (f & F_SIG) ? dsigma : 0.0;
-        double dtu, dlu, dtl, dll, it_;
-        row_step(f & F_UP, s_tu[q], s_lu[q], s_pu[q], val - sg + s_tu[q] - s_hi[q], dval - dsg, dtu, dlu, it_);
-        row_step(f & F_LO, s_tl[q], s_ll[q], s_pl[q], -val - sg + s_tl[q] + s_lo[q], -dval - dsg, dtl, dll, it_);
         if (pass == 0) {
-          sacc += (s_tu[q] + amax * dtu) * (s_lu[q] + amax * dlu) + (s_tl[q] + amax * dtl) * (s_ll[q] + amax * dll);
-          s_pu[q] = dtu * dlu;
-          s_pl[q] = dtl * dll;
+          sacc += (s_tu[q] + amax * dtu[q]) * (s_lu[q] + amax * dlu[q]) + (s_tl[q] + amax * dtl[q]) * (s_ll[q] + amax * dll[q]);
+          s_pu[q] = dtu[q] * dlu[q];
+          s_pl[q] = dtl[q] * dll[q];
         } else {
-          s_tu[q] += alpha * dtu;
-          s_lu[q] += alpha * dlu;
-          s_tl[q] += alpha * dtl;
-          s_ll[q] += alpha * dll;
+          s_tu[q] += alpha * dtu[q];
+          s_lu[q] += alpha * dlu[q];
+          s_tl[q] += alpha * dtl[q];
+          s_ll[q] += alpha * dll[q];
         }
       }
       if constexpr (KS > 0) {
@@ -1058,7 +1093,7 @@ __global__ __launch_bounds__(64, ((KQ <= 4 && KS == 0) ? 2 : 1)) void lmpc_solve
         sacc = wave_sum(sacc);
         if (has_sigma) sacc += (ts + amax * dts) * (lams + amax * dlams);
         const double ratio = (sacc * inv_m) / mu;
-        sigc = ratio * ratio * ratio;
+        sigc = uni(ratio * ratio * ratio);
         wave_sync();
       }
     }
@@ -1068,34 +1103,39 @@ __global__ __launch_bounds__(64, ((KQ <= 4 && KS == 0) ? 2 : 1)) void lmpc_solve
     double stepmax = 0.0;
 #pragma unroll
     for (int q = 0; q < KQ; ++q) {
-      if (s_ko[q] < 0) continue;
-      const double dz = (s_f[q] & F_MOVE) ? alpha * d_val[q] : 0.0;
-      if (s_f[q] & F_MOVE) (KN0 + s_ko[q])[s_vo[q]] += dz;
+      const bool mv = (flags(q) & F_MOVE) != 0;
+      const double dz = mv ? alpha * d_val[q] : 0.0;
+      lds[mv ? o_val[q] : JB + q] += dz;
       stepmax = fmax(stepmax, fabs(dz));
     }
     wave_sync();
     if (ipm) {
       last_step = wave_max(stepmax);
       if (has_sigma) {
-        sigma += alpha * dsigma;
-        ts += alpha * dts;
-        lams += alpha * dlams;
+        sigma = uni(sigma + alpha * dsigma);
+        ts = uni(ts + alpha * dts);
+        lams = uni(lams + alpha * dlams);
       }
     } else {
       // ---- slacks and multipliers at the start point: t = max(slack, 0.1 range), lam = mu0 / t ----
+      double val[KQ];
+      double2 hl[KQ];
 #pragma unroll
       for (int q = 0; q < KQ; ++q) {
-        if (s_ko[q] < 0) continue;
-        const double val = (KN0 + s_ko[q])[s_vo[q]];
-        double range = ((s_f[q] & (F_UP | F_LO)) == (F_UP | F_LO)) ? (s_hi[q] - s_lo[q]) : 1.0;
+        val[q] = lds[o_val[q]];
+        hl[q] = bounds(q);
+      }
+#pragma unroll
+      for (int q = 0; q < KQ; ++q) {
+        double range = ((flags(q) & (F_UP | F_LO)) == (F_UP | F_LO)) ? (hl[q].x - hl[q].y) : 1.0;
         if (!(range > 1e-3)) range = 1e-3;
         const double thr = 0.1 * range;
-        if (s_f[q] & F_UP) {
-          s_tu[q] = fmax(s_hi[q] - val, thr);
+        if (flags(q) & F_UP) {
+          s_tu[q] = fmax(hl[q].x - val[q], thr);
           s_lu[q] = mu0 / s_tu[q];
         }
-        if (s_f[q] & F_LO) {
-          s_tl[q] = fmax(val - s_lo[q], thr);
+        if (flags(q) & F_LO) {
+          s_tl[q] = fmax(val[q] - hl[q].y, thr);
           s_ll[q] = mu0 / s_tl[q];
         }
       }
