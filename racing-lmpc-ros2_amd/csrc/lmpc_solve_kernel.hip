@@ -48,16 +48,22 @@ struct Prof {};
 #define SL_EY 10
 
 // ---- LDS layout (doubles) ---------------------------------------------------------------------
-// stage record i (stride 78): M[8][8] @0: column c of the stage model with the feedback gain appended,
-//                               M[c][k] = [A B][k][c] (k < 6), M[c][6 + j] = K_j[c]
-//                             | g[6] @64 | Hinv (h00,h01,h11) @70 | dt @73 | kff[2 rhs][2] @74
+// stage record i (stride 78): M[8][8]: column c of the stage model with the feedback gain appended,
+//                               M[c][k] = [A B][k][c] (k < 6), M[c][6 + j] = K_j[c].  Row c starts at
+//                               ST_ROW(c) = 8 c + 2 (c >> 1): the two-cell skew after every second row puts
+//                               the eight rows on eight different 4-bank groups, so the per-lane row reads
+//                               (b128, lane = row) are conflict-free; column reads (lane = column) stay
+//                               contiguous.  The six skew cells and the tail of the record hold
+//                               Hinv (h00,h01) @16 | (h11, dt) @34 | kff rhs0 [2] @52 | kff rhs1 [2] @70 | g[6] @72
 // knot record i (stride 36):  z[8] v[2] @0 | rhs0: Th / q / d [10] @10 | rhs1: q / e [10] @20
 //                             | csig @30 | eyT / eyD @31 | boundary row bounds (hi, lo) @32 | qlin_vx @34
 // tail: P[8][10] @0 | W[8][10] @80 | Y[8][10] @160 | pvec[2 buf][2 rhs][8] @240 | consts @272 (48)
-#define ST_G 64
-#define ST_HI 70
-#define ST_DT 73
-#define ST_KFF 74
+#define ST_ROW(c) (8 * (c) + 2 * ((c) >> 1))
+#define ST_HI 16     // h00, h01
+#define ST_HI11 34   // h11
+#define ST_DT 35
+#define ST_KFF(s) ((s) ? 70 : 52)
+#define ST_G 72
 #define KN_R0 10
 #define KN_R1 20
 #define KN_CSIG 30
@@ -273,7 +279,7 @@ __device__ void riccati_factor(const Lds& L, int lane, const double* PT) {
   }
   // where this lane's share of the stage results goes: lanes 0..15 K_j[c] (j = r), 16..18 Hinv, the
   // rest to their own (dead) W cell
-  const int res_off = lane < 16 ? c * 8 + 6 + r : ST_HI + (lane - 16);
+  const int res_off = lane < 16 ? ST_ROW(c) + 6 + r : (lane == 18 ? ST_HI11 : ST_HI + (lane - 16));
   const bool res_on = lane < 19;
   double* const res_junk = MW + r * MROW + c;
   // phase-1/2 operands of stage N-2 (later stages: fetched during phase 3 of the stage before)
@@ -282,8 +288,8 @@ __device__ void riccati_factor(const Lds& L, int lane, const double* PT) {
     const double* st = L.st(N - 2);
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
-      ar[k] = st[r * 8 + k];
-      ac[k] = st[c * 8 + k];
+      ar[k] = st[ST_ROW(r) + k];
+      ac[k] = st[ST_ROW(c) + k];
     }
   }
   wave_sync();
@@ -297,6 +303,7 @@ __device__ void riccati_factor(const Lds& L, int lane, const double* PT) {
     ISSUE_ORDER();
     // phase-3 operands of this stage, queued behind the P row
     const double t = st[ST_DT], thr = kn[KN_R0 + r], ey = kn[KN_EY], thv0 = kn[KN_R0 + 8], thv1 = kn[KN_R0 + 9];
+    const double sv00 = ct[CT_SV + 0], sv01 = ct[CT_SV + 1], sv11 = ct[CT_SV + 3];
     ISSUE_ORDER();
     double w = (r >= 6) ? pown : 0.0;
 #pragma unroll
@@ -320,16 +327,16 @@ __device__ void riccati_factor(const Lds& L, int lane, const double* PT) {
       const double* stn = L.st(i > 0 ? i - 1 : 0);
 #pragma unroll
       for (int k = 0; k < 6; ++k) {
-        ar[k] = stn[r * 8 + k];
-        ac[k] = stn[c * 8 + k];
+        ar[k] = stn[ST_ROW(r) + k];
+        ac[k] = stn[ST_ROW(c) + k];
       }
     }
     ISSUE_ORDER();
     const double y66 = lane_bcast(y, 54), y67 = lane_bcast(y, 55), y77 = lane_bcast(y, 63);
     const double tt = t * t;
-    const double h00 = ct[CT_SV + 0] + thv0 + tt * y66;
-    const double h01 = ct[CT_SV + 1] + tt * y67;
-    const double h11 = ct[CT_SV + 3] + thv1 + tt * y77;
+    const double h00 = sv00 + thv0 + tt * y66;
+    const double h01 = sv01 + tt * y67;
+    const double h11 = sv11 + thv1 + tt * y77;
     const double idet = frcp(h00 * h11 - h01 * h01);
     const double hi00 = h11 * idet, hi01 = -h01 * idet, hi11 = h00 * idet;
     const double g0 = t * y6c, g1 = t * y7c;
@@ -384,7 +391,7 @@ __device__ void riccati_solve(const Lds& L, int lane, Prof& pf) {
   {
     const double* st = L.st(N - 2);
 #pragma unroll
-    for (int k = 0; k < 6; ++k) row[k] = st[r * 8 + k];
+    for (int k = 0; k < 6; ++k) row[k] = st[ST_ROW(r) + k];
   }
   wave_sync();
   for (int i = N - 2; i >= 0; --i) {
@@ -395,9 +402,9 @@ __device__ void riccati_solve(const Lds& L, int lane, Prof& pf) {
     for (int k = 0; k < 6; ++k) pb[k] = pvec[k];
     ISSUE_ORDER();
     // what the stage needs after the product, queued behind the costate
-    const double k0r = st[r * 8 + 6], k1r = st[r * 8 + 7], t = st[ST_DT];
+    const double k0r = st[ST_ROW(r) + 6], k1r = st[ST_ROW(r) + 7], t = st[ST_DT];
     const double qz = kn[reg + r], qv0 = kn[reg + 8], qv1 = kn[reg + 9];
-    const double hi00 = st[ST_HI], hi01 = st[ST_HI + 1], hi11 = st[ST_HI + 2];
+    const double hi00 = st[ST_HI], hi01 = st[ST_HI + 1], hi11 = st[ST_HI11];
     ISSUE_ORDER();
     double w = (r >= 6) ? p : 0.0;  // w = Abar' p: rows 6,7 also take p_u
 #pragma unroll
@@ -409,7 +416,7 @@ __device__ void riccati_solve(const Lds& L, int lane, Prof& pf) {
     {
       const double* stn = L.st(i > 0 ? i - 1 : 0);
 #pragma unroll
-      for (int k = 0; k < 6; ++k) row[k] = stn[r * 8 + k];
+      for (int k = 0; k < 6; ++k) row[k] = stn[ST_ROW(r) + k];
     }
     ISSUE_ORDER();
     const double hv0 = __builtin_fma(t, w6, qv0);
@@ -417,7 +424,7 @@ __device__ void riccati_solve(const Lds& L, int lane, Prof& pf) {
     p = qz + w - (k0r * hv0 + k1r * hv1);  // (not used after stage 0)
     *pdst = p;
     const double kff = (r == 0) ? hi00 * hv0 + hi01 * hv1 : hi01 * hv0 + hi11 * hv1;
-    *((own && r < 2) ? st + ST_KFF + 2 * s + r : junk1) = kff;
+    *((own && r < 2) ? st + ST_KFF(s) + r : junk1) = kff;
     wave_sync();
   }
   PT_MARK(8 + NRHS - 1)
@@ -428,8 +435,8 @@ __device__ void riccati_solve(const Lds& L, int lane, Prof& pf) {
   {
     const double* st = L.st(0);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) col[k] = st[k * 8 + r];
-    a0 = st[ST_KFF + 2 * s + (r & 1)];
+    for (int k = 0; k < 8; ++k) col[k] = st[ST_ROW(k) + r];
+    a0 = st[ST_KFF(s) + (r & 1)];
   }
   wave_sync();
   for (int i = 0; i < N - 1; ++i) {
@@ -439,7 +446,7 @@ __device__ void riccati_solve(const Lds& L, int lane, Prof& pf) {
 #pragma unroll
     for (int k = 0; k < 8; ++k) dz[k] = kn[reg + k];
     ISSUE_ORDER();
-    const double b0 = st[6 * 8 + r], b1 = st[7 * 8 + r], t = st[ST_DT];
+    const double b0 = st[ST_ROW(6) + r], b1 = st[ST_ROW(7) + r], t = st[ST_DT];
     ISSUE_ORDER();
     double acc = (r >= 6) ? a0 : 0.0;
 #pragma unroll
@@ -456,8 +463,8 @@ __device__ void riccati_solve(const Lds& L, int lane, Prof& pf) {
     {
       const double* stn = L.st(i < N - 2 ? i + 1 : i);
 #pragma unroll
-      for (int k = 0; k < 8; ++k) col[k] = stn[k * 8 + r];
-      a0 = stn[ST_KFF + 2 * s + (r & 1)];
+      for (int k = 0; k < 8; ++k) col[k] = stn[ST_ROW(k) + r];
+      a0 = stn[ST_KFF(s) + (r & 1)];
     }
     ISSUE_ORDER();
     const double nx = __builtin_fma(b1, du1, __builtin_fma(b0, du0, ax));
@@ -486,7 +493,7 @@ __device__ void feedback_rollout(const Lds& L, int lane) {
 #pragma unroll
     for (int k = 0; k < 8; ++k) dz[k] = kn[k];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) col[k] = st[k * 8 + r];
+    for (int k = 0; k < 8; ++k) col[k] = st[ST_ROW(k) + r];
     const double t = st[ST_DT];
     const double g = st[ST_G + (r < 6 ? r : 0)];
     double acc = 0.0;
@@ -529,7 +536,7 @@ __global__ __launch_bounds__(64, ((KQ <= 4 && KS == 0) ? 2 : 1)) void lmpc_solve
     for (int e = lane; e < NS * LMPC_LIN_RECORD; e += 64) {
       const int i = e / LMPC_LIN_RECORD, o = e - i * LMPC_LIN_RECORD;
       const int c = o / 6;
-      L.st(i)[o < 48 ? c * 8 + (o - c * 6) : ST_G + (o - 48)] = wsb[e];
+      L.st(i)[o < 48 ? ST_ROW(c) + (o - c * 6) : ST_G + (o - 48)] = wsb[e];
     }
     for (int i = lane; i < NS; i += 64) L.st(i)[ST_DT] = T_ref[(size_t)i * B + b];
     for (int i = lane; i < N; i += 64) {
