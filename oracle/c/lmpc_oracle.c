@@ -702,7 +702,7 @@ static void primal_update(prob_t* p, double alpha) {
  * and within 1e-3 in the worst case, the same order as OSQP's eps = 1e-3 in the reference.    */
 static int ipm_solve(prob_t* p, int* iters_out, double* kkt_out) {
   const int N = p->N, S = p->S;
-  const double tau = 0.995, mu0 = 1.0, thr_frac = 0.1;
+  const double tau = 0.995, mu0 = 0.1, thr_frac = 0.5;
   work_t* w = calloc(1, sizeof(work_t));
   /* ---- initial point: the minimiser of the cost over the dynamics alone (no inequality
    * rows, sigma = 0).  The linearised model can be open-loop unstable (|eig A| > 1 at low speed
@@ -767,7 +767,7 @@ static int ipm_solve(prob_t* p, int* iters_out, double* kkt_out) {
     ++m;
   }
   int status = LMPC_SOLVE_MAX_ITER, it = 0;
-  double mu = 0.0, rdmax = 0.0, rd_check = 0.0;
+  double mu = 0.0, rdmax = 0.0, rd_check = 0.0, mu_prev = INFINITY;
 
   /* ================= phase 1: interior point ================= */
   for (it = 0; it <= p->max_iter; ++it) {
@@ -804,6 +804,13 @@ static int ipm_solve(prob_t* p, int* iters_out, double* kkt_out) {
       status = LMPC_SOLVE_OPTIMAL;
       break;
     }
+    /* accuracy floor: with the rows feasible, a complementarity that has stopped halving within two decades of
+     * the tolerance is as small as the Riccati recursion can make it (weights lam/t ~ 1e12 cancel in P) */
+    if (rdmax <= 1e-9 && mu <= 100.0 * p->tol && mu > 0.5 * mu_prev) {
+      status = LMPC_SOLVE_OPTIMAL;
+      break;
+    }
+    mu_prev = mu;
     /* primal infeasibility: the row residual contracts by (1 - alpha) per iteration on a feasible
      * problem; if it has not halved over five iterations while still large, give up */
     if (it % 5 == 0) {

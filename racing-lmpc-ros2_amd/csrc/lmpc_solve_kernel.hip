@@ -717,9 +717,9 @@ __global__ __launch_bounds__(64, ((KQ <= 4 && KS == 0) ? 2 : 1)) void lmpc_solve
   }
   PT_MARK(1)
 
-  const double tau = 0.995, mu0 = 1.0;
+  const double tau = 0.995, mu0 = 0.1, thr_frac = 0.5;
   int status = LMPC_SOLVE_MAX_ITER, it = 0;
-  double mu = 0.0, rdmax = 0.0, rd_check = 0.0, last_step = 0.0, hsig = 0.0, ce = 0.0;
+  double mu = 0.0, mu_prev = INFINITY, rdmax = 0.0, rd_check = 0.0, last_step = 0.0, hsig = 0.0, ce = 0.0;
   const int max_iter = feasible ? P.max_iter : 0;
 
   // it == -1 is the start-point Newton step (all row weights zero, full step); it >= 0 the
@@ -841,6 +841,13 @@ __global__ __launch_bounds__(64, ((KQ <= 4 && KS == 0) ? 2 : 1)) void lmpc_solve
         status = LMPC_SOLVE_OPTIMAL;
         break;
       }
+      // accuracy floor: with the rows feasible, a complementarity that has stopped halving within two decades
+      // of the tolerance is as small as the Riccati recursion can make it (weights lam/t ~ 1e12 cancel in P)
+      if (rdmax <= 1e-9 && mu <= 100.0 * P.tol && mu > 0.5 * mu_prev) {
+        status = LMPC_SOLVE_OPTIMAL;
+        break;
+      }
+      mu_prev = mu;
       // primal infeasibility: on a feasible problem the row residual contracts by (1 - alpha) per
       // iteration; not halving over five iterations while still large ends the solve (this also
       // bounds the straggler that would otherwise hold its CU slot for max_iter iterations)
@@ -1124,7 +1131,7 @@ __global__ __launch_bounds__(64, ((KQ <= 4 && KS == 0) ? 2 : 1)) void lmpc_solve
         lams = uni(lams + alpha * dlams);
       }
     } else {
-      // ---- slacks and multipliers at the start point: t = max(slack, 0.1 range), lam = mu0 / t ----
+      // ---- slacks and multipliers at the start point: t = max(slack, 0.5 range), lam = mu0 / t ----
       double val[KQ];
       double2 hl[KQ];
 #pragma unroll
@@ -1136,7 +1143,7 @@ __global__ __launch_bounds__(64, ((KQ <= 4 && KS == 0) ? 2 : 1)) void lmpc_solve
       for (int q = 0; q < KQ; ++q) {
         double range = ((flags(q) & (F_UP | F_LO)) == (F_UP | F_LO)) ? (hl[q].x - hl[q].y) : 1.0;
         if (!(range > 1e-3)) range = 1e-3;
-        const double thr = 0.1 * range;
+        const double thr = thr_frac * range;
         if (flags(q) & F_UP) {
           s_tu[q] = fmax(hl[q].x - val[q], thr);
           s_lu[q] = mu0 / s_tu[q];

@@ -48,3 +48,11 @@ for u in uniq[:64]:
     mx.append(best)
 print("max concurrent waves per CU (first 64 CUs):", np.bincount(mx))
 print("xcc histogram", np.bincount(xcc))
+# timeline: when do waves start / end (ms from kernel start)
+t0 = w0.min()
+st_ms = (w0 - t0) / 100e6 * 1e3; en_ms = (w1 - t0) / 100e6 * 1e3
+print("start times: pct 50/90/99/max", np.percentile(st_ms, [50, 90, 99, 100]).round(3))
+print("end times:   pct 1/10/50/90/99/max", np.percentile(en_ms, [1, 10, 50, 90, 99, 100]).round(3))
+order = np.argsort(en_ms)[-8:]
+print("last finishers: idx", order, "start", st_ms[order].round(3), "dur", dur[order].round(3) * 1e3, "iters", it[order])
+print("dur by iters:", {int(k): round(float(dur[it == k].mean() * 1e3), 3) for k in np.unique(it)})
