@@ -37,6 +37,24 @@ def measured_traffic_bytes():
         return None
 
 
+def engine_utilisation(kernel_ms):
+    """What actually bounds the QP kernel: busy fractions of the FP64 VALU and of the LDS pipeline from the same
+    committed PMC passes (SQ_ACTIVE_INST_VALU is in 4-cycle units summed over waves, one VALU per SIMD, 4 SIMDs x
+    256 CUs; SQ_LDS_IDX_ACTIVE in cycles summed over the 256 CU-local LDS pipelines), against the kernel duration of
+    that profile run.  Reported next to the HBM figure because the path is not HBM-bound."""
+    try:
+        pmc = json.load(open(ROOT / "profiles" / "r01_pmc.json"))
+        k = next(v for n, v in pmc.items() if n.startswith("lmpc_solve_kernel<4, 0>"))
+        prof_ms = pmc.get("_meta", {}).get("qp_kernel_ms", kernel_ms)
+        cyc = prof_ms * 1e-3 * pmc.get("_meta", {}).get("clock_ghz", 2.3) * 1e9
+        return {"valu_busy_frac": k["SQ_ACTIVE_INST_VALU"] * 4.0 / (cyc * 256 * 4),
+                "lds_busy_frac": k["SQ_LDS_IDX_ACTIVE"] / (cyc * 256),
+                "valu_insts_per_solve": k["SQ_INSTS_VALU"] / k["SQ_WAVES"], "lds_insts_per_solve": k["SQ_INSTS_LDS"] / k["SQ_WAVES"],
+                "source": "profiles/r01_pmc.json (rocprofv3 --pmc, batch 4096, N 20)"}
+    except Exception:
+        return None
+
+
 def shard_bounds(total: int, world: int, rank: int):
     """Contiguous slice [lo, hi) of `total` problems owned by `rank` (sizes differ by at most one)."""
     base, rem = divmod(total, world)
@@ -114,6 +132,8 @@ def main():
                          "iac = configs[3]'s problem (IAC/Putnam tracking, use --horizon 40 --batch 8192) in fp64")
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL result gather for N > 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-batch1", action="store_true", help="skip the single-car latency probe (profiling runs: keeps every "
+                                                             "launch of the QP kernel at the bench batch size)")
     args = ap.parse_args()
 
     import torch
@@ -211,7 +231,8 @@ def main():
     lat, lin_ms, sol_ms = [], [], []
     if rank == 0:
         solver.enable_timing(True)
-        n_lat = max(100, min(1000, args.steps * 4))
+        # p99 over >= 1000 timed calls (bounded to ~3 s of GPU time for the big batches)
+        n_lat = int(max(100, min(1000, 3.0 / max(elapsed / args.steps, 1e-4))))
         for k in range(n_lat):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -223,6 +244,19 @@ def main():
             lin_ms.append(a)
             sol_ms.append(b)
         solver.enable_timing(False)
+        # one car: the latency a single controller sees against its 25 ms period
+        lat1 = []
+        if not lmpc and not args.no_batch1:
+            inp1 = {k: (v[..., :1].contiguous() if hasattr(v, "dim") and v.dim() >= 1 else v) for k, v in inp.items()}
+            out1 = solver.alloc_outputs(1)
+            for k in range(250):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                solver.solve(inp1, out1)
+                e1.record()
+                e1.synchronize()
+                if k >= 50:
+                    lat1.append(e0.elapsed_time(e1))
         st = outs[0]["status"].cpu().numpy()
         iters = outs[0]["iters"].cpu().numpy()
     if world > 1:
@@ -247,6 +281,7 @@ def main():
                        "batch_per_gpu": B, "horizon": N, "result_gather": "rccl all_gather (async)" if gather else "none"},
             "p50_solve_ms": float(np.percentile(lat, 50)), "p99_solve_ms": float(np.percentile(lat, 99)),
             "latency_samples": len(lat),
+            "batch1_solve_ms": {"p50": float(np.percentile(lat1, 50)), "p99": float(np.percentile(lat1, 99)), "control_period_ms": 25.0} if lat1 else None,
             "solved_fraction": float((st == 0).mean()), "mean_ipm_iters": float(iters.mean()),
             "kernels_ms": {"linearize": float(np.mean(lin_ms)), "qp_solve": sol_avg},
             "launch": solver.launch_info(),
@@ -255,7 +290,8 @@ def main():
                          "traffic": None if (lmpc or N != 20 or B != 4096) else measured_traffic_bytes(),
                          "algorithmic_bytes_per_solve": algo_bytes,
                          "note": "algorithmic bytes x batch / lmpc_solve_kernel time; the kernel is "
-                                 "FP64-VALU/LDS-latency bound (DESIGN.md), HBM fraction is reported as required"},
+                                 "FP64-VALU issue / LDS-pipeline bound (DESIGN.md), HBM fraction is reported as required",
+                         "engines": None if (lmpc or N != 20 or B != 4096) else engine_utilisation(sol_avg)},
         }
         if not args.no_cpu_baseline and world == 1 and not lmpc and not iac:
             res["cpu_baseline"] = cpu_baseline(pkg, N, B)
