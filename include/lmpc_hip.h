@@ -177,6 +177,38 @@ int lmpc_solve_host(lmpc_handle* h, const double* x_ic, const double* u_ic, cons
 int lmpc_set_safe_set(lmpc_handle* h, int32_t n_laps, const int32_t* n_pts, const double* x,
                       double total_length);
 
+/* Error-dynamics regression on the recorded laps: RegQuery / RegResult (safe_set.hpp:57-88),
+ * SSTrajectory::query(RegQuery) (safe_set.cpp:56-114), SafeSetManager::query(RegQuery) (:182-245) -- BASELINE
+ * config 5.  For every linearisation point a kernel-weighted ridge regression of the nominal model's one-step error
+ * over the lap samples within dist_max of [X_ref[in_state]; U_ref[in_ctrl]] is added onto (A, B, g):
+ *   K_j = 0.75/h (1 - (d_j/h)^2)^2,  M = [z_j' 1],  R_r = (M'KM + 1e-3 I)^-1 (-M'K y_r)   (minus sign as written),
+ *   A[r, in_state] += R_r[0:ns],  B[r, in_ctrl] += R_r[ns:ns+nc],  g[r] += R_r[-1].
+ * The reference never calls this query and two of its expressions do not type-check as written; the reading taken
+ * (same index lists for every regressed row, nominal step evaluated on the full recorded state, residual of the
+ * regressed row, dt_j = t_j - t_{j+1} as process_lap_data writes it) is documented in oracle/regression.py.
+ * Built for (n_in_state + n_in_ctrl, n_out) = (5, 3) -- rows vx, vy, yaw rate on (vx, vy, yaw rate; u) -- and (8, 6). */
+typedef struct lmpc_regression_spec {
+  int32_t n_out;       /* reg_out_state_idxs: one state index per regressed row */
+  int32_t out[6];
+  int32_t n_in_state;  /* reg_in_state_idxs */
+  int32_t in_state[6];
+  int32_t n_in_ctrl;   /* reg_in_control_idxs */
+  int32_t in_ctrl[2];
+  int32_t reserved;
+  double dist_max;     /* RegQuery::dist_max, the kernel bandwidth h */
+} lmpc_regression_spec;
+
+/* HOST pointers, laps concatenated as in lmpc_set_safe_set: x [n][6], u [n][2], k [n] (curvature), t [n] (time
+ * stamps) -- the lap_.x/u/k/t of SSTrajectory.  n_laps = 0 or spec = NULL switches the regression off.  While it is
+ * on, lmpc_solve_batch applies it between its linearisation and its QP kernel. */
+int lmpc_set_regression_laps(lmpc_handle* h, int32_t n_laps, const int32_t* n_pts, const double* x, const double* u,
+                             const double* k, const double* t, const lmpc_regression_spec* spec);
+
+/* RegResult{A, B, C} for a batch: adds the regression onto A [6][6][N-1][B], Bm [6][2][N-1][B], g [6][N-1][B]
+ * (the arrays of lmpc_linearize_batch; DEVICE pointers), linearisation points X_ref [6][N][B], U_ref [2][N-1][B]. */
+int lmpc_regress_batch(lmpc_handle* h, int32_t batch, const double* X_ref, const double* U_ref, double* A, double* Bm,
+                       double* g);
+
 /* SafeSetManager::query(SSQuery) + the pad/truncate and J - J[0] of RacingMPC::solve
  * (safe_set.cpp:153-180, trajectory_kd_tree.cpp:53-63, racing_mpc.cpp:249-280):
  *   query [2][B] = (s, e_y) of X_ref[:, N-1] after abscissa alignment  ->

@@ -19,7 +19,7 @@ _ABI_SYMBOLS = ("lmpc_create", "lmpc_destroy", "lmpc_last_error", "lmpc_set_stre
                 "lmpc_linearize_batch", "lmpc_solve_batch", "lmpc_set_safe_set", "lmpc_ss_query_batch",
                 "lmpc_prepare_batch", "lmpc_reserve", "lmpc_query_launch", "lmpc_enable_timing",
                 "lmpc_last_kernel_ms", "lmpc_query_residency", "lmpc_solve_host", "lmpc_shift_batch",
-                "lmpc_plant_step_batch")
+                "lmpc_plant_step_batch", "lmpc_set_regression_laps", "lmpc_regress_batch")
 
 
 class LmpcError(RuntimeError):
@@ -43,6 +43,12 @@ class CConfig(C.Structure):
                 ("x_max", C.c_double * 6), ("x_min", C.c_double * 6),
                 ("u_max", C.c_double * 2), ("u_min", C.c_double * 2),
                 ("convex_hull_slack", C.c_double * 6), ("max_vel_ref_diff", C.c_double)]
+
+
+class CRegressionSpec(C.Structure):
+    """lmpc_regression_spec: RegQuery's index lists and bandwidth (safe_set.hpp:57-75)."""
+    _fields_ = [("n_out", C.c_int32), ("out", C.c_int32 * 6), ("n_in_state", C.c_int32), ("in_state", C.c_int32 * 6),
+                ("n_in_ctrl", C.c_int32), ("in_ctrl", C.c_int32 * 2), ("reserved", C.c_int32), ("dist_max", C.c_double)]
 
 
 class CTrack(C.Structure):
@@ -291,6 +297,35 @@ class Solver:
         rc = self.lib.lmpc_set_safe_set(self._h, C.c_int32(len(laps_x)), n_pts.ctypes.data_as(C.c_void_p),
                                         x.ctypes.data_as(C.c_void_p), C.c_double(total_length))
         self._check(rc, "lmpc_set_safe_set")
+
+    # ---- error-dynamics regression (safe_set.cpp:56-114, 182-245) ----
+    def set_regression_laps(self, laps, in_state=(3, 4, 5), in_ctrl=(0, 1), out_rows=(3, 4, 5), dist_max: float = 1.0):
+        """laps: list of (x [n,6], u [n,2], k [n], t [n]) host arrays; an empty list switches the regression off."""
+        import numpy as np
+
+        if not laps:
+            self._check(self.lib.lmpc_set_regression_laps(self._h, C.c_int32(0), None, None, None, None, None, None),
+                        "lmpc_set_regression_laps")
+            return
+        n_pts = np.array([np.asarray(l[0]).shape[0] for l in laps], dtype=np.int32)
+        cat = [np.ascontiguousarray(np.concatenate([np.asarray(l[i], dtype=np.float64).reshape(n, -1) for l, n in zip(laps, n_pts)], 0))
+               for i in range(4)]
+        spec = CRegressionSpec()
+        spec.n_out, spec.n_in_state, spec.n_in_ctrl, spec.dist_max = len(out_rows), len(in_state), len(in_ctrl), float(dist_max)
+        spec.out[:len(out_rows)] = list(out_rows)
+        spec.in_state[:len(in_state)] = list(in_state)
+        spec.in_ctrl[:len(in_ctrl)] = list(in_ctrl)
+        rc = self.lib.lmpc_set_regression_laps(self._h, C.c_int32(len(laps)), n_pts.ctypes.data_as(C.c_void_p),
+                                               *[a.ctypes.data_as(C.c_void_p) for a in cat], C.byref(spec))
+        self._check(rc, "lmpc_set_regression_laps")
+
+    def regress(self, inp: dict, A, Bm, g):
+        """Adds RegResult onto A [6,6,N-1,B], Bm [6,2,N-1,B], g [6,N-1,B] (device tensors, in place)."""
+        self.use_current_stream()
+        X, U = self._t(inp["X_ref"]), self._t(inp["U_ref"])
+        rc = self.lib.lmpc_regress_batch(self._h, C.c_int32(X.shape[2]), _ptr(X), _ptr(U), _ptr(A), _ptr(Bm), _ptr(g))
+        self._check(rc, "lmpc_regress_batch")
+        return A, Bm, g
 
     def ss_query(self, query):
         torch = self._torch

@@ -30,6 +30,11 @@ __global__ void lmpc_solve_kernel(lmpc_params, int, const double*, const double*
                                   double*, double*, double*, int*, int*, double*);
 __global__ void lmpc_ss_query_kernel(int, int, int, int, const int*, const int*, const double*, double, const double*,
                                      double*, double*, int*);
+__global__ void lmpc_reg_residual_kernel(lmpc_vehicle, int, const int*, const double*, const double*, const double*,
+                                         const double*, double*);
+template <int NF, int NOUT, bool WS_LAYOUT>
+__global__ void lmpc_regress_kernel(int, int, lmpc_regression_spec, int, const int*, const double*, const double*,
+                                    const double*, const double*, const double*, double*, double*, double*);
 
 struct lmpc_handle {
   lmpc_params P;
@@ -46,6 +51,14 @@ struct lmpc_handle {
   double* ss_x = nullptr;  // [total][6]
   double ss_L = 0.0;
   int ss_nmax = 0;
+  // regression store (device): lap samples, one-step residuals of the nominal model, end-of-lap flags
+  bool reg_on = false;
+  int reg_total = 0;
+  int* reg_end = nullptr;
+  double* reg_x = nullptr;  // [total][6]
+  double* reg_u = nullptr;  // [total][2]
+  double* reg_y = nullptr;  // [total][6]
+  lmpc_regression_spec reg_spec{};
   // staging for lmpc_solve_host (device + pinned-free host mirror)
   double* stage_dev = nullptr;
   size_t stage_doubles = 0;
@@ -128,6 +141,24 @@ int launch_solve(lmpc_handle* h, const void* fn, const solve_args& a) {
 
 }  // namespace
 
+
+namespace {
+// one wavefront per (problem, stage); WS: the handle's workspace, otherwise the caller's A/B/g arrays
+template <bool WS>
+int launch_regress(lmpc_handle* h, int batch, const double* X_ref, const double* U_ref, double* A, double* Bm, double* g) {
+  const int nf = h->reg_spec.n_in_state + h->reg_spec.n_in_ctrl;
+  const dim3 grid((unsigned)batch * (h->P.N - 1)), block(64);
+  if (nf == 5 && h->reg_spec.n_out == 3)
+    hipLaunchKernelGGL((lmpc_regress_kernel<5, 3, WS>), grid, block, 0, h->stream, h->P.N, batch, h->reg_spec, h->reg_total,
+                       h->reg_end, h->reg_x, h->reg_u, h->reg_y, X_ref, U_ref, A, Bm, g);
+  else
+    hipLaunchKernelGGL((lmpc_regress_kernel<8, 6, WS>), grid, block, 0, h->stream, h->P.N, batch, h->reg_spec, h->reg_total,
+                       h->reg_end, h->reg_x, h->reg_u, h->reg_y, X_ref, U_ref, A, Bm, g);
+  HIP_TRY(h, hipGetLastError());
+  return LMPC_OK;
+}
+}  // namespace
+
 extern "C" {
 
 int lmpc_create(const lmpc_config* cfg, const lmpc_vehicle* veh, int device, lmpc_handle** out) {
@@ -204,6 +235,10 @@ void lmpc_destroy(lmpc_handle* h) {
   if (h->ss_npts) (void)hipFree(h->ss_npts);
   if (h->ss_off) (void)hipFree(h->ss_off);
   if (h->ss_x) (void)hipFree(h->ss_x);
+  if (h->reg_end) (void)hipFree(h->reg_end);
+  if (h->reg_x) (void)hipFree(h->reg_x);
+  if (h->reg_u) (void)hipFree(h->reg_u);
+  if (h->reg_y) (void)hipFree(h->reg_y);
   if (h->stage_dev) (void)hipFree(h->stage_dev);
   if (h->stage_int) (void)hipFree(h->stage_int);
   for (auto& e : h->ev)
@@ -314,6 +349,10 @@ int lmpc_solve_batch(lmpc_handle* h, int32_t batch, const double* x_ic, const do
   hipLaunchKernelGGL(lmpc_linearize_kernel<true>, grid, dim3(256), 0, h->stream, h->P, batch, X_ref, U_ref, T_ref,
                      curvatures, h->ws, (double*)nullptr, (double*)nullptr);
   HIP_TRY(h, hipGetLastError());
+  if (h->reg_on) {  // error-dynamics regression onto the workspace (safe_set.cpp:182-245)
+    const int rc = launch_regress<true>(h, batch, X_ref, U_ref, h->ws, nullptr, nullptr);
+    if (rc != LMPC_OK) return rc;
+  }
   if (h->timing) HIP_TRY(h, hipEventRecord(h->ev[1], h->stream));
   const void* fn = pick_solve_fn(kq_for(N), ks_for(h->P.S));
   if (!fn) return fail(h, LMPC_ERR_UNSUPPORTED, "no kernel for this (N, num_ss_pts)");
@@ -509,6 +548,73 @@ int lmpc_ss_query_batch(lmpc_handle* h, int32_t batch, const double* query, doub
                      h->cfg.num_ss_pts_per_lap, h->ss_npts, h->ss_off, h->ss_x, h->ss_L, query, ss_x, ss_j, n_found);
   HIP_TRY(h, hipGetLastError());
   return LMPC_OK;
+}
+
+int lmpc_set_regression_laps(lmpc_handle* h, int32_t n_laps, const int32_t* n_pts, const double* x, const double* u,
+                             const double* k, const double* t, const lmpc_regression_spec* spec) {
+  if (!h) return LMPC_ERR_ARGUMENT;
+  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  for (void* p : {(void*)h->reg_end, (void*)h->reg_x, (void*)h->reg_u, (void*)h->reg_y})
+    if (p) HIP_TRY(h, hipFree(p));
+  h->reg_end = nullptr;
+  h->reg_x = h->reg_u = h->reg_y = nullptr;
+  h->reg_on = false;
+  h->reg_total = 0;
+  if (n_laps == 0 || !spec) return LMPC_OK;
+  if (n_laps < 0 || !n_pts || !x || !u || !k || !t) return fail(h, LMPC_ERR_ARGUMENT, "lmpc_set_regression_laps: bad argument");
+  const int nf = spec->n_in_state + spec->n_in_ctrl;
+  if (!((nf == 5 && spec->n_out == 3) || (nf == 8 && spec->n_out == 6)) || spec->n_in_state < 1 || spec->n_in_state > 6 ||
+      spec->n_in_ctrl < 0 || spec->n_in_ctrl > 2)
+    return fail(h, LMPC_ERR_UNSUPPORTED, "regression built for (features, rows) = (5, 3) and (8, 6)");
+  if (!(spec->dist_max > 0.0)) return fail(h, LMPC_ERR_ARGUMENT, "dist_max must be positive");
+  for (int i = 0; i < spec->n_out; ++i)
+    if (spec->out[i] < 0 || spec->out[i] > 5) return fail(h, LMPC_ERR_ARGUMENT, "regressed row out of range");
+  for (int i = 0; i < spec->n_in_state; ++i)
+    if (spec->in_state[i] < 0 || spec->in_state[i] > 5) return fail(h, LMPC_ERR_ARGUMENT, "feature state out of range");
+  for (int i = 0; i < spec->n_in_ctrl; ++i)
+    if (spec->in_ctrl[i] < 0 || spec->in_ctrl[i] > 1) return fail(h, LMPC_ERR_ARGUMENT, "feature control out of range");
+  size_t total = 0;
+  std::vector<int> end;
+  for (int l = 0; l < n_laps; ++l) {
+    if (n_pts[l] < 2) return fail(h, LMPC_ERR_ARGUMENT, "lmpc_set_regression_laps: a lap needs two samples");
+    total += (size_t)n_pts[l];
+    end.resize(total, 0);
+    end[total - 1] = 1;
+  }
+  double *dk = nullptr, *dt = nullptr;
+  HIP_TRY(h, hipMalloc(&h->reg_end, total * sizeof(int)));
+  HIP_TRY(h, hipMalloc(&h->reg_x, total * 6 * sizeof(double)));
+  HIP_TRY(h, hipMalloc(&h->reg_u, total * 2 * sizeof(double)));
+  HIP_TRY(h, hipMalloc(&h->reg_y, total * 6 * sizeof(double)));
+  HIP_TRY(h, hipMalloc(&dk, total * sizeof(double)));
+  HIP_TRY(h, hipMalloc(&dt, total * sizeof(double)));
+  HIP_TRY(h, hipMemcpy(h->reg_end, end.data(), total * sizeof(int), hipMemcpyHostToDevice));
+  HIP_TRY(h, hipMemcpy(h->reg_x, x, total * 6 * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(h, hipMemcpy(h->reg_u, u, total * 2 * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(h, hipMemcpy(dk, k, total * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(h, hipMemcpy(dt, t, total * sizeof(double), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(lmpc_reg_residual_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, h->P.veh,
+                     (int)total, h->reg_end, h->reg_x, h->reg_u, dk, dt, h->reg_y);
+  HIP_TRY(h, hipGetLastError());
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  HIP_TRY(h, hipFree(dk));
+  HIP_TRY(h, hipFree(dt));
+  h->reg_total = (int)total;
+  h->reg_spec = *spec;
+  h->reg_on = true;
+  return LMPC_OK;
+}
+
+int lmpc_regress_batch(lmpc_handle* h, int32_t batch, const double* X_ref, const double* U_ref, double* A, double* Bm,
+                       double* g) {
+  if (!h) return LMPC_ERR_ARGUMENT;
+  if (batch < 0 || !X_ref || !U_ref || !A || !Bm || !g)
+    return fail(h, LMPC_ERR_ARGUMENT, "lmpc_regress_batch: null pointer or negative batch");
+  if (!h->reg_on) return fail(h, LMPC_ERR_ARGUMENT, "lmpc_regress_batch: no regression laps set");
+  if (batch == 0) return LMPC_OK;
+  HIP_TRY(h, hipSetDevice(h->device));
+  return launch_regress<false>(h, batch, X_ref, U_ref, A, Bm, g);
 }
 
 }  // extern "C"

@@ -3,4 +3,5 @@
 #include "lmpc_prep_kernels.hip"
 #include "lmpc_solve_kernel.hip"
 #include "lmpc_ss_kernel.hip"
+#include "lmpc_reg_kernel.hip"
 #include "lmpc_capi.hip"
