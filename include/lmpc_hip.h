@@ -177,6 +177,11 @@ int lmpc_solve_host(lmpc_handle* h, const double* x_ic, const double* u_ic, cons
 int lmpc_set_safe_set(lmpc_handle* h, int32_t n_laps, const int32_t* n_pts, const double* x,
                       double total_length);
 
+/* One query, HOST pointers, for the C++ facade's SafeSetManager::query: query[2] = (s, e_y); ss_x column-major
+ * 6 x S and ss_j [S] as lmpc_ss_query_batch produces them (padded, J - J[0]); *j0 (optional) = the J[0] that was
+ * subtracted, so that SSResult::J = ss_j + j0 on the first *n_found points.  Synchronises the handle's stream. */
+int lmpc_ss_query_host(lmpc_handle* h, const double* query, double* ss_x, double* ss_j, int32_t* n_found, double* j0);
+
 /* Error-dynamics regression on the recorded laps: RegQuery / RegResult (safe_set.hpp:57-88),
  * SSTrajectory::query(RegQuery) (safe_set.cpp:56-114), SafeSetManager::query(RegQuery) (:182-245) -- BASELINE
  * config 5.  For every linearisation point a kernel-weighted ridge regression of the nominal model's one-step error

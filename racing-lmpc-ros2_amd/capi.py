@@ -19,7 +19,7 @@ _ABI_SYMBOLS = ("lmpc_create", "lmpc_destroy", "lmpc_last_error", "lmpc_set_stre
                 "lmpc_linearize_batch", "lmpc_solve_batch", "lmpc_set_safe_set", "lmpc_ss_query_batch",
                 "lmpc_prepare_batch", "lmpc_reserve", "lmpc_query_launch", "lmpc_enable_timing",
                 "lmpc_last_kernel_ms", "lmpc_query_residency", "lmpc_solve_host", "lmpc_shift_batch",
-                "lmpc_plant_step_batch", "lmpc_set_regression_laps", "lmpc_regress_batch")
+                "lmpc_plant_step_batch", "lmpc_set_regression_laps", "lmpc_regress_batch", "lmpc_ss_query_host")
 
 
 class LmpcError(RuntimeError):

@@ -29,7 +29,7 @@ __global__ void lmpc_solve_kernel(lmpc_params, int, const double*, const double*
                                   const double*, const double*, const double*, const double*, const double*, double*,
                                   double*, double*, double*, int*, int*, double*);
 __global__ void lmpc_ss_query_kernel(int, int, int, int, const int*, const int*, const double*, double, const double*,
-                                     double*, double*, int*);
+                                     double*, double*, int*, double*);
 __global__ void lmpc_reg_residual_kernel(lmpc_vehicle, int, const int*, const double*, const double*, const double*,
                                          const double*, double*);
 template <int NF, int NOUT, bool WS_LAYOUT>
@@ -545,8 +545,46 @@ int lmpc_ss_query_batch(lmpc_handle* h, int32_t batch, const double* query, doub
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&lmpc_ss_query_kernel),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(lmpc_ss_query_kernel, dim3(batch), dim3(64), lds, h->stream, batch, h->ss_laps, h->cfg.num_ss_pts,
-                     h->cfg.num_ss_pts_per_lap, h->ss_npts, h->ss_off, h->ss_x, h->ss_L, query, ss_x, ss_j, n_found);
+                     h->cfg.num_ss_pts_per_lap, h->ss_npts, h->ss_off, h->ss_x, h->ss_L, query, ss_x, ss_j, n_found,
+                     (double*)nullptr);
   HIP_TRY(h, hipGetLastError());
+  return LMPC_OK;
+}
+
+int lmpc_ss_query_host(lmpc_handle* h, const double* query, double* ss_x, double* ss_j, int32_t* n_found, double* j0) {
+  if (!h) return LMPC_ERR_ARGUMENT;
+  if (!query || !ss_x || !ss_j || !n_found) return fail(h, LMPC_ERR_ARGUMENT, "lmpc_ss_query_host: null pointer");
+  const int S = h->cfg.num_ss_pts;
+  if (S < 1 || h->cfg.num_ss_pts_per_lap < 1) return fail(h, LMPC_ERR_ARGUMENT, "num_ss_pts / num_ss_pts_per_lap not configured");
+  if (h->cfg.num_ss_pts_per_lap > 64) return fail(h, LMPC_ERR_UNSUPPORTED, "num_ss_pts_per_lap > 64");
+  HIP_TRY(h, hipSetDevice(h->device));
+  const size_t nd = 2 + 7 * (size_t)S + 1;  // query | ss_x [6][S] | ss_j [S] | j0
+  double* d = nullptr;
+  int* di = nullptr;
+  HIP_TRY(h, hipMalloc(&d, nd * sizeof(double)));
+  HIP_TRY(h, hipMalloc(&di, sizeof(int)));
+  HIP_TRY(h, hipMemsetAsync(d, 0, nd * sizeof(double), h->stream));
+  HIP_TRY(h, hipMemcpyAsync(d, query, 2 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  const size_t lds = (size_t)3 * (h->ss_nmax > 0 ? h->ss_nmax : 1) * sizeof(double);
+  if (lds > 160 * 1024) return fail(h, LMPC_ERR_UNSUPPORTED, "lap longer than 6826 samples");
+  HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&lmpc_ss_query_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(lmpc_ss_query_kernel, dim3(1), dim3(64), lds, h->stream, 1, h->ss_laps, S, h->cfg.num_ss_pts_per_lap,
+                     h->ss_npts, h->ss_off, h->ss_x, h->ss_L, d, d + 2, d + 2 + 6 * (size_t)S, di, d + 2 + 7 * (size_t)S);
+  HIP_TRY(h, hipGetLastError());
+  std::vector<double> host(nd);
+  int nf = 0;
+  HIP_TRY(h, hipMemcpyAsync(host.data(), d, nd * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(&nf, di, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  HIP_TRY(h, hipFree(d));
+  HIP_TRY(h, hipFree(di));
+  for (int j = 0; j < S; ++j) {
+    for (int k = 0; k < 6; ++k) ss_x[(size_t)j * 6 + k] = host[2 + (size_t)k * S + j];  // -> column-major 6 x S
+    ss_j[j] = host[2 + 6 * (size_t)S + j];
+  }
+  *n_found = nf;
+  if (j0) *j0 = host[2 + 7 * (size_t)S];
   return LMPC_OK;
 }
 

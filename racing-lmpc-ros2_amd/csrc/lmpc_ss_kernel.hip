@@ -20,7 +20,7 @@ __global__ __launch_bounds__(64) void lmpc_ss_query_kernel(int B, int n_laps, in
                                                            const int* __restrict__ npts, const int* __restrict__ off,
                                                            const double* __restrict__ x, double Lt,
                                                            const double* __restrict__ query, double* __restrict__ ss_x,
-                                                           double* __restrict__ ss_j, int* __restrict__ n_found) {
+                                                           double* __restrict__ ss_j, int* __restrict__ n_found, double* __restrict__ j0_out) {
 #pragma clang fp contract(off)
   extern __shared__ __attribute__((aligned(16))) double dist[];
   const int b = blockIdx.x, lane = threadIdx.x;
@@ -85,7 +85,10 @@ __global__ __launch_bounds__(64) void lmpc_ss_query_kernel(int B, int n_laps, in
       }
     }
   }
-  if (lane == 0) n_found[b] = tot;
+  if (lane == 0) {
+    n_found[b] = tot;
+    if (j0_out) j0_out[b] = j0;  // cost-to-go of the first point, subtracted from ss_j (racing_mpc.cpp:280)
+  }
   if (tot > 0)  // pad with the last point (racing_mpc.cpp:263-272)
     for (int q = tot; q < S; ++q) {
       if (lane < 6)

@@ -33,6 +33,13 @@ RacingMPC::RacingMPC(RacingMPCConfig::SharedPtr mpc_config, VehicleModel::Shared
     h_ = nullptr;
     throw std::runtime_error("RacingMPC: lmpc_create failed: " + msg);
   }
+  if (config_->c.learning) {  // racing_mpc.cpp:57-66: manager sized by max_lap_stored, recorder writing under path_prefix
+    namespace rt = lmpc::vehicle_model::racing_trajectory;
+    ss_manager_.reset(new rt::SafeSetManager(h_, static_cast<std::size_t>(config_->c.max_lap_stored)));
+    ss_recorder_.reset(new rt::SafeSetRecorder(*ss_manager_, config_->record, config_->path_prefix));
+    ss_x_.assign(6 * static_cast<std::size_t>(config_->c.num_ss_pts), 0.0);
+    ss_j_.assign(static_cast<std::size_t>(config_->c.num_ss_pts), 0.0);
+  }
 }
 
 RacingMPC::~RacingMPC() { lmpc_destroy(h_); }
@@ -62,18 +69,42 @@ void RacingMPC::solve(const DMDict& in, DMDict& out, Dict& stats) {
       bound_left.data.size() != N || bound_right.data.size() != N || curvatures.data.size() != N ||
       vel_ref.data.size() != N || x_ic.data.size() != 6 || u_ic.data.size() != 2)
     throw std::length_error("RacingMPC::solve: input dimension does not match MPC dimension");
-  if (config_->c.learning) {
-    std::cerr << "RacingMPC::solve: LMPC terminal block not built in this round" << '\n';
-    return;
+  const std::size_t S = config_->c.learning ? static_cast<std::size_t>(config_->c.num_ss_pts) : 0;
+  if (config_->c.learning) {  // racing_mpc.cpp:240-281
+    namespace rt = lmpc::vehicle_model::racing_trajectory;
+    if (!ss_loaded_ && config_->load) {
+      ss_recorder_->load(config_->load_path, total_length);
+      ss_loaded_ = true;
+    }
+    DM k0(1, 1);
+    k0(0, 0) = curvatures.data[0];
+    ss_recorder_->step(x_ic, u_ic, k0, in.at("t_ic"), total_length);
+    rt::SSQuery q;
+    q.x = DM(6, 1);
+    for (int r = 0; r < 6; ++r) q.x(r, 0) = X_ref(r, N - 1);
+    q.max_num_total = S;
+    q.max_num_per_lap = static_cast<std::size_t>(config_->c.num_ss_pts_per_lap);
+    const rt::SSResult ss = ss_manager_->query(q);
+    out["ss_x"] = ss.x;
+    out["ss_j"] = ss.J;
+    if (ss.x.size2() > 0) {  // pad with the last point or truncate; costs relative to the first (racing_mpc.cpp:263-280)
+      const std::size_t n = ss.x.size2();
+      for (std::size_t j = 0; j < S; ++j) {
+        const std::size_t src = j < n ? j : n - 1;
+        for (int r = 0; r < 6; ++r) ss_x_[j * 6 + r] = ss.x(r, src);
+        ss_j_[j] = ss.J(0, src) - ss.J(0, 0);
+      }
+    }  // else: "No safe set found, using previous safe set." (racing_mpc.cpp:259-261)
   }
-  DM X(6, N), U(2, N - 1), dU(2, N - 1);
+  DM X(6, N), U(2, N - 1), dU(2, N - 1), lam(S, 1);
   int32_t status = 0, iters = 0, total_iters = 0;
   const int n_sqp = full_dynamics_ ? 8 : 1;
   for (int k = 0; k < n_sqp; ++k) {
     const int rc = lmpc_solve_host(h_, x_ic.data.data(), u_ic.data.data(), X_ref.data.data(), U_ref.data.data(),
                                    T.data.data(), bound_left.data.data(), bound_right.data.data(),
-                                   curvatures.data.data(), vel_ref.data.data(), total_length, nullptr, nullptr,
-                                   X.data.data(), U.data.data(), dU.data.data(), nullptr, &status, &iters);
+                                   curvatures.data.data(), vel_ref.data.data(), total_length, S ? ss_x_.data() : nullptr,
+                                   S ? ss_j_.data() : nullptr, X.data.data(), U.data.data(), dU.data.data(),
+                                   S ? lam.data.data() : nullptr, &status, &iters);
     if (rc != LMPC_OK) {
       std::cerr << "RacingMPC::solve: " << lmpc_last_error(h_) << '\n';
       return;
@@ -98,6 +129,7 @@ void RacingMPC::solve(const DMDict& in, DMDict& out, Dict& stats) {
   out["X_optm"] = X;
   out["U_optm"] = U;
   out["dU_optm"] = dU;
+  if (S) out["convex_combi_optm"] = lam;
 }
 
 void RacingMPC::create_warm_start(const DMDict& in, DMDict& out) {

@@ -7,7 +7,8 @@
 // for casadi::DM -- CasADi is not a dependency of this library) and the same keys as
 // RacingMPC::solve reads and writes (racing_mpc.cpp:215-228, 347-353).  A caller of the reference
 // (RacingMPCNode::on_step_timer, racing_mpc_node.cpp:301,320) switches by changing the include and
-// the DM type; see INTEGRATION.md.  No HIP types appear here: the facade talks to lmpc_solve_host.
+// the DM type; see INTEGRATION.md.  No HIP types appear here: the facade talks to lmpc_solve_host and, with
+// config.learning, keeps the safe set through SafeSetManager / SafeSetRecorder (safe_set.hpp).
 #ifndef LMPC_HOST_RACING_MPC_HPP_
 #define LMPC_HOST_RACING_MPC_HPP_
 
@@ -17,27 +18,17 @@
 #include <string>
 #include <vector>
 
+#include "dm.hpp"
 #include "lmpc_hip.h"
+#include "safe_set.hpp"
 
 namespace lmpc {
 namespace mpc {
 namespace racing_mpc {
 
-// Dense column-major matrix of doubles: element (r, c) at data[c * rows + r], as casadi::DM stores it.
-struct DM {
-  std::size_t rows = 0, cols = 0;
-  std::vector<double> data;
-  DM() = default;
-  DM(std::size_t r, std::size_t c, double fill = 0.0) : rows(r), cols(c), data(r * c, fill) {}
-  explicit DM(double scalar) : rows(1), cols(1), data(1, scalar) {}
-  double& operator()(std::size_t r, std::size_t c) { return data[c * rows + r]; }
-  double operator()(std::size_t r, std::size_t c) const { return data[c * rows + r]; }
-  std::size_t size1() const { return rows; }
-  std::size_t size2() const { return cols; }
-  explicit operator double() const { return data.at(0); }
-};
-typedef std::map<std::string, DM> DMDict;
-typedef std::map<std::string, double> Dict;  // the node reads only stats["iter_count"] (racing_mpc_node.cpp:355-357)
+using lmpc::DM;      // column-major dense matrix standing in for casadi::DM (dm.hpp)
+using lmpc::DMDict;
+using lmpc::Dict;
 
 // RacingMPCConfig (racing_mpc_config.hpp:37-82): the numeric fields live in the C struct.
 struct RacingMPCConfig {
@@ -89,6 +80,11 @@ class RacingMPC {
   bool full_dynamics_;
   bool solved_;
   lmpc_handle* h_;
+  // LMPC (config.learning): the safe set and its recorder, as racing_mpc.hpp:88-90 upstream
+  std::unique_ptr<lmpc::vehicle_model::racing_trajectory::SafeSetManager> ss_manager_;
+  std::unique_ptr<lmpc::vehicle_model::racing_trajectory::SafeSetRecorder> ss_recorder_;
+  bool ss_loaded_ = false;
+  std::vector<double> ss_x_, ss_j_;  // last non-empty query, padded (the parameter keeps its value upstream)
 };
 
 }  // namespace racing_mpc

@@ -35,3 +35,29 @@ def test_facade_solves_like_the_reference_class(golden, tmp_path):
             _dm(f, g["U_optm"][:, :, b])
         r = subprocess.run([str(exe), str(p)], capture_output=True, text=True, timeout=120)
         assert r.returncode == 0 and "PASS" in r.stdout, (r.stdout, r.stderr)
+
+
+def test_facade_lmpc_loads_laps_queries_and_records(golden, tmp_path):
+    """config.learning: SafeSetRecorder::load of the reference's lap files, SafeSetManager::query on the device,
+    the LMPC solve against the dense optimum, and the recorder's lap segmentation + file output."""
+    g = golden("qp_barc_lmpc_n20")
+    exe = LIB / "test_facade_lmpc"
+    assert exe.exists(), "run __graft_entry__.build() first"
+    b = 3
+    p = tmp_path / "lmpc_problem.txt"
+    nf = 96  # three laps x 32 points: no padding in this scenario
+    with open(p, "w") as f:
+        f.write("20 %r\n" % float(g["L"]))
+        _dm(f, g["x_ic"][:, b:b + 1])
+        _dm(f, g["u_ic"][:, b:b + 1])
+        _dm(f, g["X_ref"][:, :, b])
+        _dm(f, g["U_ref"][:, :, b])
+        for k in ("T_ref", "bound_left", "bound_right", "curvatures", "vel_ref"):
+            _dm(f, g[k][:, b][None, :])
+        _dm(f, g["X_optm"][:, :, b])
+        _dm(f, g["U_optm"][:, :, b])
+        _dm(f, g["ss_x"][:, :nf, b])
+        _dm(f, g["ss_j"][:nf, b][None, :])
+    laps = [str(ROOT / "tests" / "golden" / "barc_ss" / f"ss_lap_{i}") for i in (1, 2, 3)]
+    r = subprocess.run([str(exe), str(p), *laps, str(tmp_path) + "/rec_"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("PASS"), (r.stdout[-2000:], r.stderr[-2000:])
