@@ -811,10 +811,11 @@ static int ipm_solve(prob_t* p, int* iters_out, double* kkt_out) {
       break;
     }
     mu_prev = mu;
-    /* primal infeasibility: the row residual contracts by (1 - alpha) per iteration on a feasible
-     * problem; if it has not halved over five iterations while still large, give up */
-    if (it % 5 == 0) {
-      if (it >= 10 && rdmax > 1e-6 && rdmax > 0.5 * rd_check) {
+    /* primal infeasibility: the row residual contracts by (1 - alpha) per iteration on a feasible problem; if it
+     * has not lost a tenth over five iterations while still large (step lengths stuck below ~2 %), give up.  (A
+     * tighter test -- "not halved" -- rejects feasible problems with a slow start: IAC at 60 m/s into a corner
+     * needs 20-30 iterations and contracts by 0.6-0.8 per five early on.) */
+      if (it >= 10 && rdmax > 1e-6 && rdmax > 0.9 * rd_check) {
         status = LMPC_SOLVE_INFEASIBLE;
         break;
       }
@@ -937,7 +938,7 @@ static void setup_problem(prob_t* p, const lmpc_config* cfg, const lmpc_vehicle*
   p->N = N;
   p->has_sigma = cfg->q_boundary > 0.0;
   p->S = cfg->learning ? cfg->num_ss_pts : 0;
-  p->max_iter = cfg->max_iter > 0 ? cfg->max_iter : 30;
+  p->max_iter = cfg->max_iter > 0 ? cfg->max_iter : 40;
   p->tol = cfg->tol > 0 ? cfg->tol : 1e-11;
   for (int i = 0; i < N - 1; ++i) {
     double x[6], u[2], xp[6];
