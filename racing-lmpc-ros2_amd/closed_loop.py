@@ -47,3 +47,79 @@ def run(solver, track: dict, x0, u0, steps: int, dt: float = 0.025, n_sub: int =
         if record_every and k % record_every == 0:
             trace.append(x.clone())
     return {"x": x, "distance": dist, "worst_excess": worst_excess, "n_fail": n_fail, "trace": trace}
+
+
+def run_lmpc(tracker, learner, track: dict, x0, u0, warm_laps: int = 2, learn_laps: int = 4, dt: float = 0.025,
+             n_sub: int = 2, warm_speed_scale: float = 0.7, max_steps: int = 20000, debug: bool = False):
+    """The LMPC experiment of the reference (sim_barc_lmpc): `warm_laps` laps under the tracking MPC fill the safe
+    set, then the learning MPC drives and every completed lap of car 0 is added to the set (SafeSetRecorder ->
+    SafeSetManager -> device store).  All B cars share car 0's safe set.  Returns car 0's lap times (tracking laps
+    first) and per-car statistics.  x0 [6][B], u0 [2][B] on the device."""
+    import numpy as np
+    import torch
+
+    from . import safe_set as SS
+
+    trk = tracker.device_track(track)
+    L = float(track["L"])
+    B = x0.shape[1]
+    man = SS.SafeSetManager(int(learner.config["max_lap_stored"]))
+    rec = SS.SafeSetRecorder(man)
+    x, u_prev = x0.clone(), u0.clone()
+    half_b = float(tracker.vehicle["b"]) / 2.0
+    worst_excess = torch.zeros(B, dtype=torch.float64, device=x.device)
+    n_fail = torch.zeros(B, dtype=torch.int64, device=x.device)
+    lap_times, lap_kind, t_lap_start, t = [], [], None, 0.0
+    debug_left = [12]
+    solver, learning = tracker, False
+    inp = solver.prepare(trk, x, dt, speed_scale=warm_speed_scale)
+    out = solver.alloc_outputs(B)
+    S = int(learner.config["num_ss_pts"])
+    lam = torch.zeros((S, B), dtype=torch.float64, device=x.device)
+    curv0 = np.asarray(track["curvature"], dtype=np.float64)
+    # The state box also applies to knot 0 (racing_mpc.cpp:147,201), so a plant that lands a hair outside an active
+    # bound (the QP rides vx = vx_max; the nonlinear plant overshoots by the linearisation error) would make every
+    # following problem infeasible.  The harness hands the controller the measured state projected onto the box.
+    x_lo = torch.as_tensor(learner.config["x_min"], dtype=torch.float64, device=x.device)[:, None]
+    x_hi = torch.as_tensor(learner.config["x_max"], dtype=torch.float64, device=x.device)[:, None]
+    for k in range(max_steps):
+        inp["x_ic"], inp["u_ic"] = (torch.minimum(torch.maximum(x, x_lo), x_hi) if learning else x), u_prev
+        # car 0 feeds the recorder (RacingMPC::solve, racing_mpc.cpp:246): state, applied input, curvature, time
+        x_h = x[:, 0].cpu().numpy()
+        k_h = float(np.interp(x_h[0] % L, np.arange(curv0.size) * L / curv0.size, curv0, period=L))
+        if rec.step(x_h, u_prev[:, 0].cpu().numpy(), k_h, t, L):
+            lap_times.append(t - t_lap_start)
+            lap_kind.append("lmpc" if learning else "tracking")
+            man.sync(learner)
+            if not learning and len(man.laps) >= warm_laps:
+                solver, learning = learner, True
+                out = solver.alloc_outputs(B)
+                out["convex_combi_optm"] = lam
+            if learning and lap_kind.count("lmpc") >= learn_laps:
+                break
+        if rec.initialized and (t_lap_start is None or rec.x and len(rec.x) == 1):
+            t_lap_start = t
+        if learning:
+            # query = last knot of the abscissa-aligned reference (racing_mpc.cpp:219-223,249-254)
+            s_last, s0 = inp["X_ref"][0, -1], x[0]
+            kk = (s0 - s_last).abs() + L / 2
+            q = torch.stack([s_last + (kk - torch.fmod(kk, L)) * torch.sign(s0 - s_last), inp["X_ref"][1, -1]]).contiguous()
+            ss_x, ss_j, _ = solver.ss_query(q)
+            solver.solve(inp, out, ss_x=ss_x, ss_j=ss_j)
+        else:
+            solver.solve(inp, out)
+        ok = out["status"] == 0
+        n_fail += (~ok).to(torch.int64)
+        if debug and learning and not bool(ok[0]) and debug_left[0] > 0:
+            debug_left[0] -= 1
+            print("step", k, "t %.3f" % t, "car0 status", int(out["status"][0]), "iters", int(out["iters"][0]), "x", x[:, 0].cpu().numpy().round(3),
+                  "u_prev", u_prev[:, 0].cpu().numpy().round(4), "Xref vx %.2f..%.2f" % (float(inp["X_ref"][3, :, 0].min()), float(inp["X_ref"][3, :, 0].max())))
+        u_apply = torch.where(ok[None, :], out["U_optm"][:, 0, :], inp["U_ref"][:, 0, :]).contiguous()
+        solver.plant_step(trk, x, u_apply, dt / n_sub, n_sub)
+        exc = torch.maximum(x[1] + half_b - inp["bound_left"][0], inp["bound_right"][0] - (x[1] - half_b))
+        worst_excess = torch.maximum(worst_excess, exc)
+        u_prev = u_apply
+        inp = solver.shift(trk, inp, out, dt, speed_scale=warm_speed_scale if not learning else 1.0)
+        t += dt
+    return {"lap_times": lap_times, "lap_kind": lap_kind, "worst_excess": worst_excess, "n_fail": n_fail, "steps": k + 1,
+            "laps_in_set": len(man.laps)}

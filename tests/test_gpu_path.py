@@ -258,3 +258,28 @@ def test_closed_loop_two_laps_inside_the_track(pkg):
     assert dist.min() >= 2 * tr["L"], dist.min()
     assert exc.max() <= 0.0, exc.max()          # body edge never leaves the track
     assert nf.mean() < 0.01 * 1100, nf.mean()   # < 1 % failed solves per car
+
+
+def test_lmpc_experiment_lap_times_improve(pkg):
+    """The reference's LMPC experiment (sim_barc_lmpc) on the device: two laps under the tracking MPC fill the safe
+    set through SafeSetRecorder / SafeSetManager, then the learning MPC drives 64 cars sharing car 0's set, every
+    lap of car 0 is added, and its lap time falls lap over lap while every car stays inside the track."""
+    import torch
+
+    N, B = 20, 64
+    tracker = pkg.Solver(pkg.presets.barc_tracking_mpc(N), pkg.presets.barc_vehicle(), device=0)
+    learner = pkg.Solver(pkg.presets.barc_lmpc(N, 3), pkg.presets.barc_vehicle(), device=0)
+    tr = pkg.workloads.synthetic_track("barc")
+    rng = np.random.default_rng(0)
+    x0 = np.stack([np.full(B, 0.5), rng.uniform(-0.05, 0.05, B), np.zeros(B), np.full(B, 2.0), np.zeros(B), np.zeros(B)])
+    x0[:, 0] = [0.5, 0.0, 0.0, 2.0, 0.0, 0.0]
+    res = pkg.closed_loop.run_lmpc(tracker, learner, tr, torch.as_tensor(x0, device="cuda"),
+                                   torch.zeros((2, B), dtype=torch.float64, device="cuda"), warm_laps=2, learn_laps=4,
+                                   warm_speed_scale=0.7)
+    lt, kind = np.array(res["lap_times"]), res["lap_kind"]
+    assert kind == ["tracking", "tracking", "lmpc", "lmpc", "lmpc", "lmpc"], kind
+    assert lt[2:].max() < 0.85 * lt[:2].min()                  # learning laps clearly faster than the laps they learned from
+    assert (np.diff(lt[2:]) <= 0.026).all() and lt[-1] < lt[2]  # and not getting slower (one control period of slack)
+    assert float(res["worst_excess"].max()) <= 0.0             # no car leaves the track
+    assert int(res["n_fail"].max()) <= 5 and int(res["n_fail"][0]) == 0
+    assert res["laps_in_set"] == 3                             # the ring keeps max_lap_stored laps
