@@ -188,14 +188,18 @@ def main():
         flat = [torch.empty(packed_numel(N, B), dtype=torch.float64, device=dev) for _ in range(2)]
         gbuf = [torch.empty(world * flat[0].numel(), dtype=torch.float64, device=dev) for _ in range(2)]
 
-    def step(k, handle_prev):
+    def solve_step(k):
         o = outs[k & 1]
         if lmpc:
             ss_x, ss_j, _ = solver.ss_query(query)
             solver.solve(inp, o, ss_x=ss_x, ss_j=ss_j)
         else:
             solver.solve(inp, o)
-        if gather:
+        return o
+
+    def step(k, handle_prev):
+        o = solve_step(k)
+        if gather:  # a collective: every rank must take this path the same number of times
             if handle_prev is not None:
                 handle_prev.wait()
             f = pack_results(o, flat[k & 1])
@@ -236,7 +240,7 @@ def main():
         for k in range(n_lat):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            step(0, None)
+            solve_step(0)   # rank-local: no collective in this loop
             e1.record()
             e1.synchronize()
             lat.append(e0.elapsed_time(e1))
