@@ -815,6 +815,7 @@ static int ipm_solve(prob_t* p, int* iters_out, double* kkt_out) {
      * has not lost a tenth over five iterations while still large (step lengths stuck below ~2 %), give up.  (A
      * tighter test -- "not halved" -- rejects feasible problems with a slow start: IAC at 60 m/s into a corner
      * needs 20-30 iterations and contracts by 0.6-0.8 per five early on.) */
+    if (it % 5 == 0) {
       if (it >= 10 && rdmax > 1e-6 && rdmax > 0.9 * rd_check) {
         status = LMPC_SOLVE_INFEASIBLE;
         break;
