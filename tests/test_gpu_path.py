@@ -283,3 +283,30 @@ def test_lmpc_experiment_lap_times_improve(pkg):
     assert float(res["worst_excess"].max()) <= 0.0             # no car leaves the track
     assert int(res["n_fail"].max()) <= 5 and int(res["n_fail"][0]) == 0
     assert res["laps_in_set"] == 3                             # the ring keeps max_lap_stored laps
+
+
+def test_hard_boundary_without_slack(pkg):
+    """q_boundary = 0: no shared slack, the track boundary is a hard row pair (racing_mpc.cpp:529-543) and also
+    applies to knot 0."""
+    import dataclasses
+
+    veh, cfg = P.barc_vehicle(), dataclasses.replace(P.barc_tracking_mpc(10), q_boundary=0.0)
+    preset = pkg.presets.barc_tracking_mpc(10)
+    preset["q_boundary"] = 0.0
+    solver = pkg.Solver(preset, pkg.presets.barc_vehicle(), device=0)
+    tr = pkg.workloads.synthetic_track("barc")
+    u_lo, u_hi, _, _ = Q.effective_bounds(cfg, veh)
+    x, u = pkg.workloads.sample_initial_states("barc", 32, tr["L"], u_lo, u_hi, 3)
+    x[:16, 1] = np.clip(x[:16, 1], -0.1, 0.1)
+    inp = S.cold_start_inputs(cfg, veh, tr, x, u, 0.025)
+    out = to_np(solver.solve(inp))
+    twin = cbind.solve_batch(cfg, veh, inp)
+    assert (out["status"] == twin["status"]).all() and (out["status"][:16] == 0).sum() >= 12
+    ok = out["status"] == 0
+    assert np.abs((out["X_optm"] - twin["X_optm"]) / P.SCALE_X[:, None, None])[:, :, ok].max() < TOL_TWIN
+    assert (out["kkt"][3] == 0).all()                       # no slack variable in this configuration
+    for b in np.where(ok)[0][:3]:
+        qp = Q.build_qp(cfg, veh, S.problem(inp, b))
+        yex, info = Q.solve_dense(qp)
+        assert info["status"] == 0
+        assert np.abs((out["X_optm"][:, :, b] - qp.split(yex)["X_optm"]) / P.SCALE_X[:, None]).max() < TOL_XU
