@@ -287,6 +287,45 @@ class Solver:
         out["_inputs_keepalive"] = a
         return out
 
+    # ---- full_dynamics = true (racing_mpc.cpp:162-166; IPOPT upstream, racing_mpc_node.cpp:299-314) ----
+    def solve_full_dynamics(self, inp: dict, max_sqp: int = 10, tol: float = 1e-9):
+        """The nonlinear-dynamics problem x_{i+1} = f_d(x_i, u_i, k_i, t_i) by sequential QPs over the same kernels:
+        re-linearise about the last solution until it stops moving (full steps; the per-knot parameters -- curvature,
+        bounds, vel_ref -- stay fixed, as they are parameters of the reference's NLP too).  Problems whose QP fails
+        keep their last successful iterate and report that QP's status.  Returns the last QP's output dict plus
+        "sqp_iters" [B] and "sqp_move" [B] (largest scaled change of X in the last accepted step)."""
+        torch = self._torch
+        cur = dict(inp)
+        X = self._t(inp["X_ref"]).clone()
+        U = self._t(inp["U_ref"]).clone()
+        B = X.shape[2]
+        active = torch.ones(B, dtype=torch.bool, device=self.device)
+        sqp_iters = torch.zeros(B, dtype=torch.int32, device=self.device)
+        move = torch.full((B,), float("inf"), dtype=torch.float64, device=self.device)
+        scale = torch.tensor([2000.0, 10.0, 0.1, 80.0, 2.0, 2.0], dtype=torch.float64, device=self.device)[:, None, None]
+        out = None
+        for _ in range(max_sqp):
+            cur["X_ref"], cur["U_ref"] = X, U
+            o = self.solve(cur)
+            ok = (o["status"] == 0) & active
+            step = ((o["X_optm"] - X).abs() / scale).amax(dim=(0, 1))
+            X = torch.where(ok[None, None, :], o["X_optm"], X)
+            U = torch.where(ok[None, None, :], o["U_optm"], U)
+            move = torch.where(ok, step, move)
+            sqp_iters += ok.to(torch.int32)
+            if out is None:
+                out = {k: (v.clone() if hasattr(v, "clone") else v) for k, v in o.items()}
+            else:
+                for k in ("X_optm", "U_optm", "dU_optm"):
+                    out[k] = torch.where(ok[None, None, :], o[k], out[k])
+                for k in ("status", "iters"):
+                    out[k] = torch.where(active, o[k], out[k])
+            active = ok & (step > tol)
+            if not bool(active.any()):
+                break
+        out["sqp_iters"], out["sqp_move"] = sqp_iters, move
+        return out
+
     # ---- safe set (safe_set.cpp:116-180) ----
     def set_safe_set(self, laps_x, total_length: float):
         import numpy as np

@@ -310,3 +310,29 @@ def test_hard_boundary_without_slack(pkg):
         yex, info = Q.solve_dense(qp)
         assert info["status"] == 0
         assert np.abs((out["X_optm"][:, :, b] - qp.split(yex)["X_optm"]) / P.SCALE_X[:, None]).max() < TOL_XU
+
+
+def test_full_dynamics_sqp_closes_the_nonlinear_defect(pkg):
+    """full_dynamics = true (racing_mpc.cpp:162-166): sequential QPs drive x_{i+1} - f_d(x_i, u_i, k_i, t_i) to zero;
+    the single QP (linearised about the cold-start rollout) leaves a defect of the order of the linearisation error."""
+    veh, cfg, solver, tr, x, u = make(pkg, "barc20", 96, 8)
+    x[:, 3] = np.clip(x[:, 3], 1.6, 3.0)   # the reference's RK4 model is unstable below ~1.5 m/s at dt = 25 ms
+    inp = S.cold_start_inputs(cfg, veh, tr, x, u, 0.025)
+    one = to_np(solver.solve(inp))
+    # Gauss-Newton SQP (cost Hessian only) converges linearly, ~0.15 per iteration here; the defect of an iterate is the
+    # linearisation error of the step that produced it, i.e. quadratic in that step
+    nlp = to_np(solver.solve_full_dynamics(inp, max_sqp=12))
+    ok = (one["status"] == 0) & (nlp["status"] == 0) & (nlp["sqp_move"] < 1e-4)
+    assert ok.mean() > 0.9
+
+    def defect(o):
+        X, U = o["X_optm"], o["U_optm"]
+        nxt = D.rk4(X[:, :-1].transpose(1, 2, 0), U.transpose(1, 2, 0), inp["curvatures"][:-1], inp["T_ref"], veh)
+        return np.abs((X[:, 1:].transpose(1, 2, 0) - nxt) / P.SCALE_X).max(axis=(0, 2))
+
+    d1, dn = defect(one)[ok], defect(nlp)[ok]
+    assert dn.max() < 1e-7 and np.median(d1) > 1e4 * np.median(dn) and (nlp["sqp_iters"][ok] >= 2).all()
+    # constraints of the NLP hold at the SQP point (they are the QP's rows at the last iterate)
+    u_lo, u_hi, _, _ = Q.effective_bounds(cfg, veh)
+    assert (nlp["U_optm"][:, :, ok] <= u_hi[:, None, None] + 1e-8).all() and (nlp["U_optm"][:, :, ok] >= u_lo[:, None, None] - 1e-8).all()
+    assert (nlp["X_optm"][3, 1:-1][:, ok] >= cfg.x_min[3] - 1e-8).all()
