@@ -81,3 +81,11 @@ def sample_states_near_laps(laps, batch: int, L: float, seed: int = 0):
     x = lap[idx] + rng.normal(0, 1, (batch, 6)) * np.array([0.0, 0.03, 0.03, 0.1, 0.02, 0.1])
     x[:, 0] = np.mod(x[:, 0], L)
     return x, np.zeros((batch, 2))
+
+
+def track_from_file(path, M: int = 1024) -> dict:
+    """Uniform periodic device tables sampled from one of the reference's 17-column track files
+    (racing_trajectory.py: same interpolants as RacingTrajectory upstream)."""
+    from .racing_trajectory import RacingTrajectory
+
+    return RacingTrajectory(path).to_track_table(M)

@@ -336,3 +336,25 @@ def test_full_dynamics_sqp_closes_the_nonlinear_defect(pkg):
     u_lo, u_hi, _, _ = Q.effective_bounds(cfg, veh)
     assert (nlp["U_optm"][:, :, ok] <= u_hi[:, None, None] + 1e-8).all() and (nlp["U_optm"][:, :, ok] >= u_lo[:, None, None] - 1e-8).all()
     assert (nlp["X_optm"][3, 1:-1][:, ok] >= cfg.x_min[3] - 1e-8).all()
+
+
+def test_closed_loop_on_the_reference_barc_track(pkg):
+    """SURVEY.md 8d config 1 on the reference's own track file (15_barc_optm.txt through the RacingTrajectory
+    interpolants), velocity_profile_scale = 0.9 as sim_barc_tracking_mpc launches it: 256 cars, more than two laps,
+    no solver failure; the (soft) boundary row is respected to a centimetre on a track 0.19 m narrow at its tightest."""
+    import torch
+    from pathlib import Path
+
+    tab = pkg.workloads.track_from_file(Path(__file__).resolve().parent / "golden" / "barc_track" / "15_barc_optm.txt", 1024)
+    N, B = 20, 256
+    solver = pkg.Solver(pkg.presets.barc_tracking_mpc(N), pkg.presets.barc_vehicle(), device=0)
+    rng = np.random.default_rng(1)
+    s0 = rng.uniform(0, tab["L"], B)
+    v0 = 0.8 * np.interp(s0, np.arange(1024) * tab["L"] / 1024, tab["vel"])
+    x0 = np.stack([s0, rng.uniform(-0.05, 0.05, B), np.zeros(B), v0, np.zeros(B), np.zeros(B)])
+    res = pkg.closed_loop.run(solver, tab, torch.as_tensor(x0, device="cuda"), torch.zeros((2, B), dtype=torch.float64, device="cuda"),
+                              steps=int(2.2 * tab["L"] / 3.0 / 0.025), speed_scale=0.9)
+    laps = res["distance"].cpu().numpy() / tab["L"]
+    assert laps.min() > 2.0
+    assert int(res["n_fail"].max()) == 0
+    assert float(torch.nan_to_num(res["worst_excess"], nan=1e9).max()) < 0.01

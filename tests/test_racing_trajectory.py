@@ -1,0 +1,81 @@
+"""Track tables and interpolants (RacingTrajectory, racing_trajectory.cpp:25-236) -- CPU only.
+tests/golden/barc_track/15_barc_optm.txt is the reference's own BARC track (its test data, unchanged)."""
+from pathlib import Path
+
+import numpy as np
+import pytest
+from scipy.interpolate import make_interp_spline
+
+from oracle.trajectory import TrackOracle
+
+TRACK = Path(__file__).resolve().parent / "golden" / "barc_track" / "15_barc_optm.txt"
+
+
+@pytest.fixture(scope="module")
+def tracks(pkg):
+    rt = pkg.racing_trajectory
+    return rt, rt.RacingTrajectory(TRACK), TrackOracle(np.loadtxt(TRACK))
+
+
+def test_not_a_knot_spline_matches_the_published_algorithm(pkg):
+    rt = pkg.racing_trajectory
+    rng = np.random.default_rng(0)
+    x = np.cumsum(rng.uniform(0.05, 0.4, 40))
+    y = np.sin(x) + 0.1 * rng.normal(size=40)
+    mine, ref = rt.NotAKnotCubic(x, y), make_interp_spline(x, y, k=3)
+    q = np.linspace(x[0], x[-1], 1001)
+    for nu, tol in ((0, 1e-12), (1, 1e-11), (2, 1e-10)):
+        assert np.abs(mine(q, nu) - ref(q, nu)).max() < tol
+    assert np.abs(mine(x) - y).max() < 1e-13       # interpolates the data
+
+
+def test_interpolants_match_the_restatement_on_the_barc_track(tracks):
+    rt, tr, orc = tracks
+    assert tr.total_length == pytest.approx(15.6298, abs=1e-3) and tr.table.shape == (153, 17)
+    s = np.linspace(-3.0, 2.5 * tr.total_length, 2001)      # the interpolants accept any abscissa (wrapped, :98)
+    ref = orc.eval(s)
+    got = {"x": tr.x(s), "y": tr.y(s), "vel": tr.velocity(s), "left": tr.left_boundary(s), "right": tr.right_boundary(s),
+           "yaw": tr.yaw(s), "curvature": tr.curvature(s)}
+    for k, tol in (("x", 1e-11), ("y", 1e-11), ("vel", 1e-10), ("left", 1e-11), ("right", 1e-11), ("yaw", 1e-9), ("curvature", 1e-8)):
+        assert np.abs(got[k] - ref[k]).max() < tol, k
+    # the waypoints themselves are reproduced, the loop closes smoothly, bounds have the reference's signs
+    w = tr.table
+    assert np.abs(tr.x(w[:, rt.DIST_TO_SF_BWD]) - w[:, rt.PX]).max() < 1e-12
+    assert abs(tr.x(1e-9) - tr.x(tr.total_length - 1e-9)) < 1e-7 and abs(tr.yaw(1e-9) - tr.yaw(tr.total_length - 1e-9)) < 1e-5
+    assert (tr.left_boundary(s) > 0).all() and (tr.right_boundary(s) < 0).all()
+
+
+def test_curvature_is_the_expression_as_written(tracks):
+    """x' y'' - y' x'' / |r'|^3 (racing_trajectory.cpp:108-110): not the geometric curvature unless |r'| = 1."""
+    rt, tr, _ = tracks
+    s = np.linspace(0.0, tr.total_length, 400, endpoint=False)
+    sm = tr._mod(s)
+    dx, dy, d2x, d2y = tr._x(sm, 1), tr._y(sm, 1), tr._x(sm, 2), tr._y(sm, 2)
+    assert np.allclose(tr.curvature(s), dx * d2y - (dy * d2x) / np.hypot(dx, dy) ** 3, rtol=1e-12, atol=1e-14)
+    geometric = (dx * d2y - dy * d2x) / np.hypot(dx, dy) ** 3
+    assert np.abs(tr.curvature(s) - geometric).max() < 0.05 * np.abs(geometric).max()   # arc-length abscissa: |r'| ~ 1
+
+
+def test_frenet_global_round_trip(tracks):
+    rt, tr, _ = tracks
+    rng = np.random.default_rng(2)
+    for _ in range(25):
+        s, t, xi = rng.uniform(0, tr.total_length), rng.uniform(-0.25, 0.25), rng.uniform(-0.4, 0.4)
+        x, y, phi = tr.frenet_to_global(s, t, xi)
+        s2, t2, xi2 = tr.global_to_frenet(float(x), float(y), float(phi))
+        ds = (s2 - s + tr.total_length / 2) % tr.total_length - tr.total_length / 2
+        assert abs(ds) < 1e-6 and abs(t2 - t) < 1e-6 and abs(xi2 - xi) < 1e-6
+    # warm-started projection of a moved pose stays on the same branch (racing_trajectory.cpp:204-212)
+    s0, _, _ = tr.global_to_frenet(*[float(v) for v in tr.frenet_to_global(3.0, 0.1, 0.0)])
+    s1, t1, _ = tr.global_to_frenet(*[float(v) for v in tr.frenet_to_global(3.2, -0.05, 0.0)], s0=s0)
+    assert abs(s1 - 3.2) < 1e-6 and abs(t1 + 0.05) < 1e-6
+
+
+def test_device_table_samples_the_interpolants(tracks):
+    _, tr, orc = tracks
+    tab = tr.to_track_table(512)
+    s = np.arange(512) * tr.total_length / 512
+    ref = orc.eval(s)
+    assert tab["M"] == 512 and tab["L"] == tr.total_length
+    for k, kr in (("curvature", "curvature"), ("bound_left", "left"), ("bound_right", "right"), ("vel", "vel")):
+        assert np.abs(tab[k] - ref[kr]).max() < 1e-8
