@@ -112,20 +112,63 @@ __device__ __forceinline__ void wave_sync() { __builtin_amdgcn_wave_barrier(); }
 __device__ __forceinline__ double uni(double x) {
   return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)), __builtin_amdgcn_readfirstlane(__double2loint(x)));
 }
-__device__ __forceinline__ double wave_sum(double x) {
+// Wave reductions on the VALU (DPP), not through the LDS crossbar (ds_bpermute): the LDS pipeline is this kernel's
+// tightest resource and a 6-step bpermute chain costs ~460 cycles of latency against ~130 here.  Four row_ror steps
+// leave every lane of a 16-lane row with the row's total, row_bcast15 / row_bcast31 fold the rows into lane 63.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_move(double x, double identity) {
+  const int lo = __builtin_amdgcn_update_dpp(__double2loint(identity), __double2loint(x), CTRL, ROW_MASK, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(identity), __double2hiint(x), CTRL, ROW_MASK, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+#define DPP_ROW_ROR(n) (0x120 + (n))
+#define DPP_ROW_BCAST15 0x142
+#define DPP_ROW_BCAST31 0x143
+struct op_sum {
+  static __device__ __forceinline__ double id() { return 0.0; }
+  static __device__ __forceinline__ double f(double a, double b) { return a + b; }
+};
+struct op_max {
+  static __device__ __forceinline__ double id() { return -INFINITY; }
+  static __device__ __forceinline__ double f(double a, double b) { return fmax(a, b); }
+};
+struct op_min {
+  static __device__ __forceinline__ double id() { return INFINITY; }
+  static __device__ __forceinline__ double f(double a, double b) { return fmin(a, b); }
+};
+// NV independent reductions in lock-step (their steps interleave); results as wave-uniform scalars
+template <class OP, int NV>
+__device__ __forceinline__ void wave_reduce_n(double (&v)[NV]) {
 #pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) x += __shfl_xor(x, m);
-  return uni(x);
+  for (int k = 0; k < NV; ++k) v[k] = OP::f(v[k], dpp_move<DPP_ROW_ROR(8), 0xf>(v[k], OP::id()));
+#pragma unroll
+  for (int k = 0; k < NV; ++k) v[k] = OP::f(v[k], dpp_move<DPP_ROW_ROR(4), 0xf>(v[k], OP::id()));
+#pragma unroll
+  for (int k = 0; k < NV; ++k) v[k] = OP::f(v[k], dpp_move<DPP_ROW_ROR(2), 0xf>(v[k], OP::id()));
+#pragma unroll
+  for (int k = 0; k < NV; ++k) v[k] = OP::f(v[k], dpp_move<DPP_ROW_ROR(1), 0xf>(v[k], OP::id()));
+#pragma unroll
+  for (int k = 0; k < NV; ++k) v[k] = OP::f(v[k], dpp_move<DPP_ROW_BCAST15, 0xa>(v[k], OP::id()));
+#pragma unroll
+  for (int k = 0; k < NV; ++k) v[k] = OP::f(v[k], dpp_move<DPP_ROW_BCAST31, 0xc>(v[k], OP::id()));
+#pragma unroll
+  for (int k = 0; k < NV; ++k)
+    v[k] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v[k]), 63), __builtin_amdgcn_readlane(__double2loint(v[k]), 63));
+}
+__device__ __forceinline__ double wave_sum(double x) {
+  double v[1] = {x};
+  wave_reduce_n<op_sum, 1>(v);
+  return v[0];
 }
 __device__ __forceinline__ double wave_max(double x) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) x = fmax(x, __shfl_xor(x, m));
-  return uni(x);
+  double v[1] = {x};
+  wave_reduce_n<op_max, 1>(v);
+  return v[0];
 }
 __device__ __forceinline__ double wave_min(double x) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) x = fmin(x, __shfl_xor(x, m));
-  return uni(x);
+  double v[1] = {x};
+  wave_reduce_n<op_min, 1>(v);
+  return v[0];
 }
 
 // 1/x: hardware v_rcp_f64 seed + one Newton step (full fp64 accuracy for normal x); replaces the
@@ -135,17 +178,9 @@ __device__ __forceinline__ double frcp(double x) {
   return __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
 }
 
-// NV independent wave sums in lock-step: the six shuffle steps of all values overlap, so the cost is
-// ~NV * 12 ds_bpermute issues + one latency chain instead of NV chains.
 template <int NV>
 __device__ __forceinline__ void wave_sum_n(double (&v)[NV]) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) {
-#pragma unroll
-    for (int k = 0; k < NV; ++k) v[k] += __shfl_xor(v[k], m);
-  }
-#pragma unroll
-  for (int k = 0; k < NV; ++k) v[k] = uni(v[k]);
+  wave_reduce_n<op_sum, NV>(v);
 }
 
 // Inverse of a symmetric positive definite 6x6 (row-major, full storage) by Cholesky; every index is
