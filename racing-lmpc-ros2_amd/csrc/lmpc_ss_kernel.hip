@@ -16,6 +16,19 @@
 
 #include <limits.h>
 
+// one DPP step of the arg-min: lanes outside ROW_MASK see the identity (+inf, INT_MAX)
+#define ARGMIN_STEP(CTRL, ROW_MASK)                                                                                      \
+  {                                                                                                                      \
+    const int od_lo = __builtin_amdgcn_update_dpp(0, __double2loint(d), CTRL, ROW_MASK, 0xf, false);                     \
+    const int od_hi = __builtin_amdgcn_update_dpp(0x7ff00000, __double2hiint(d), CTRL, ROW_MASK, 0xf, false);            \
+    const int oi = __builtin_amdgcn_update_dpp(INT_MAX, i, CTRL, ROW_MASK, 0xf, false);                                  \
+    const double od = __hiloint2double(od_hi, od_lo);                                                                    \
+    if (od < d || (od == d && oi < i)) {                                                                                 \
+      d = od;                                                                                                            \
+      i = oi;                                                                                                            \
+    }                                                                                                                    \
+  }
+
 __global__ __launch_bounds__(64) void lmpc_ss_query_kernel(int B, int n_laps, int S, int K,
                                                            const int* __restrict__ npts, const int* __restrict__ off,
                                                            const double* __restrict__ x, double Lt,
@@ -50,17 +63,18 @@ __global__ __launch_bounds__(64) void lmpc_ss_query_kernel(int B, int n_laps, in
     }
     const int take = K < n3 ? K : n3;
     for (int q = 0; q < take && tot < S; ++q, ++tot) {
+      // wave-wide lexicographic arg-min of (distance, unrolled index) on the VALU: four row_ror steps give every
+      // lane of a 16-lane row the row's winner, row_bcast15 / row_bcast31 fold the rows into lane 63
       double d = bestd;
       int i = besti;
-#pragma unroll
-      for (int m = 32; m >= 1; m >>= 1) {
-        const double od = __shfl_xor(d, m);
-        const int oi = __shfl_xor(i, m);
-        if (od < d || (od == d && oi < i)) {
-          d = od;
-          i = oi;
-        }
-      }
+      ARGMIN_STEP(0x128, 0xf)
+      ARGMIN_STEP(0x124, 0xf)
+      ARGMIN_STEP(0x122, 0xf)
+      ARGMIN_STEP(0x121, 0xf)
+      ARGMIN_STEP(0x142, 0xa)
+      ARGMIN_STEP(0x143, 0xc)
+      d = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(d), 63), __builtin_amdgcn_readlane(__double2loint(d), 63));
+      i = __builtin_amdgcn_readlane(i, 63);
       const int rep = i / n, j = i - rep * n;
       const double jv = (double)(n - 1 - j) + (1 - rep) * (double)(n - 1);
       if (tot == 0) j0 = jv;
