@@ -8,17 +8,23 @@
 // iteration touches resident in LDS (~20 KB at N = 20 -> 8 problems per CU).
 //   * Riccati factorisation: the augmented state z = [x; u_prev] has 8 components, so the 8x8
 //     cost-to-go matrix is exactly one wave: lane l owns element (r, c) = (l >> 3, l & 7).
-//     Matrix products are 6-term dot products read from LDS (b128 row reads, padded rows);
-//     no cross-lane shuffles are needed in any matrix or vector phase.
+//     Matrix products are 6-term dot products whose operands come as LDS row reads (b128; padded /
+//     skewed rows keep them bank-conflict free); each lane keeps its own element in a register.
 //   * Riccati vector solves: lane (s, r) = (l >> 3, l & 7) computes component r of right-hand
 //     side s, so the predictor step and the boundary-slack Schur vector are solved in the same
-//     instruction stream (two RHS for the price of one).
+//     instruction stream (two RHS for the price of one); the running vector makes one LDS trip per
+//     stage, the stage's 2-vector is spread with ds_swizzle / v_readlane.
 //   * Inequality rows: the 11 two-sided slots of each knot (6 state, 2 input, 2 input-rate,
 //     1 track boundary) are dealt round-robin to lanes; slacks and multipliers never leave
 //     registers.  The slot owner also owns the primal component the slot constrains: it writes
 //     that component's barrier weight and gradient entry and applies its update.
-//   * Wave-wide scalars (mu, step length, Schur dot products) use 6-step xor-shuffle reductions.
-// Too small for MFMA (6..8-wide blocks); the kernel is FP64-VALU / LDS-latency bound.
+//   * Wave-wide scalars (mu, step length, Schur dot products) are DPP reductions on the VALU and
+//     live in SGPRs afterwards.
+//   * The whole iteration is a chain of ~120 dependent stage steps: operands that do not depend on
+//     the chain are fetched one stage ahead, exchanges through LDS use compiler-only fences (one
+//     wave per workgroup: no s_barrier, no wait for the write to retire).
+// Too small for MFMA (6..8-wide blocks); the kernel is bound by LDS instruction issue and FP64
+// VALU issue, not by HBM.
 //
 // Algorithm (twin of oracle/c/lmpc_oracle.c, which documents the derivation): Mehrotra
 // predictor-corrector interior point; Newton systems by Riccati recursion on (z, v = dU); the
