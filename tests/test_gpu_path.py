@@ -358,3 +358,27 @@ def test_closed_loop_on_the_reference_barc_track(pkg):
     assert laps.min() > 2.0
     assert int(res["n_fail"].max()) == 0
     assert float(torch.nan_to_num(res["worst_excess"], nan=1e9).max()) < 0.01
+
+
+@pytest.mark.parametrize("N", [30, 60, 80])
+def test_longer_horizons_match_the_twin(pkg, N):
+    """The shipped YAMLs use horizons of 40-80 knots; these exercise the KQ = 7 / 11 / 14 row layouts."""
+    veh, cfg = P.barc_vehicle(), P.barc_tracking_mpc(N)
+    solver = pkg.Solver(pkg.presets.barc_tracking_mpc(N), pkg.presets.barc_vehicle(), device=0)
+    tr = pkg.workloads.synthetic_track("barc")
+    u_lo, u_hi, _, _ = Q.effective_bounds(cfg, veh)
+    x, u = pkg.workloads.sample_initial_states("barc", 48, tr["L"], u_lo, u_hi, 40 + N)
+    x[:, 3] = np.clip(x[:, 3], 1.6, 3.0)
+    inp = S.cold_start_inputs(cfg, veh, tr, x, u, 0.025)
+    out = to_np(solver.solve(inp))
+    twin = cbind.solve_batch(cfg, veh, inp)
+    assert (out["status"] == twin["status"]).mean() > 0.95 and (out["status"] == 0).mean() > 0.9
+    ok = (out["status"] == 0) & (twin["status"] == 0)
+    assert np.abs(out["iters"][ok] - twin["iters"][ok]).max() <= 1
+    e = np.abs((out["X_optm"] - twin["X_optm"]) / P.SCALE_X[:, None, None]).max(axis=(0, 1))[ok]
+    assert np.percentile(e, 95) < TOL_TWIN and e.max() < TOL_DEGENERATE
+    # dynamics rows hold exactly along the whole horizon
+    A, Bm, g = (t.cpu().numpy() for t in solver.linearize(inp))
+    X, U = out["X_optm"], out["U_optm"]
+    pred = np.einsum("rcib,cib->rib", A, X[:, :-1]) + np.einsum("rcib,cib->rib", Bm, U) + g
+    assert np.abs(pred - X[:, 1:])[:, :, ok].max() < 1e-7
