@@ -24,10 +24,10 @@ __global__ void lmpc_shift_kernel(lmpc_params, int, lmpc_track, const double*, c
                                   const double*, const int*, double, double, double, double*, double*, double*, double*,
                                   double*, double*, double*);
 __global__ void lmpc_plant_kernel(lmpc_params, int, lmpc_track, double*, const double*, double, int);
-template <int KQ, int KS>
-__global__ void lmpc_solve_kernel(lmpc_params, int, const double*, const double*, const double*, const double*,
-                                  const double*, const double*, const double*, const double*, const double*, double*,
-                                  double*, double*, double*, int*, int*, double*);
+template <typename real, int KQ, int KS>
+__global__ void lmpc_solve_kernel(lmpc_params, int, const real*, const real*, const real*, const real*, const real*,
+                                  const real*, const real*, const real*, const real*, real*, real*, real*, real*, int*,
+                                  int*, real*);
 __global__ void lmpc_ss_query_kernel(int, int, int, int, const int*, const int*, const double*, double, const double*,
                                      double*, double*, int*, double*);
 __global__ void lmpc_reg_residual_kernel(lmpc_vehicle, int, const int*, const double*, const double*, const double*,
@@ -104,7 +104,7 @@ struct solve_args {
 
 template <int KQ, int KS>
 const void* solve_fn() {
-  return reinterpret_cast<const void*>(&lmpc_solve_kernel<KQ, KS>);
+  return reinterpret_cast<const void*>(&lmpc_solve_kernel<double, KQ, KS>);
 }
 
 // the (KQ, KS) instantiations that exist: KQ = ceil(11 N / 64) rounded up to {2,4,7,11,14}, KS = safe-set points / 64

@@ -112,12 +112,31 @@ struct Prof {};
 // compiler must not move memory operations across the exchange point.
 __device__ __forceinline__ void wave_sync() { __builtin_amdgcn_wave_barrier(); }
 
-// A value that is the same in every lane, moved to scalar registers (two v_readfirstlane): the solver's
+// A value that is the same in every lane, moved to scalar registers (v_readfirstlane): the solver's
 // wave-wide scalars (mu, step lengths, sigma, ...) then cost no vector registers while they are carried
-// across the Riccati sweeps, and feed the FP64 VALU as scalar operands.
+// across the Riccati sweeps, and feed the VALU as scalar operands.
 __device__ __forceinline__ double uni(double x) {
   return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)), __builtin_amdgcn_readfirstlane(__double2loint(x)));
 }
+__device__ __forceinline__ float uni(float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); }
+
+// Lane k's value of a wave-distributed number as a wave-uniform scalar (v_readlane_b32; the result lives in SGPRs
+// and feeds the FMAs as a scalar operand).
+__device__ __forceinline__ double lane_bcast(double v, int k) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), k);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), k);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ float lane_bcast(float v, int k) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), k)); }
+
+// ds_swizzle bit mode: source lane = (lane & 0x18) | K, i.e. lane K of each group of 8 (PATTERN = 0x18 | K << 5)
+template <int PATTERN>
+__device__ __forceinline__ double group_bcast(double v) {
+  return __hiloint2double(__builtin_amdgcn_ds_swizzle(__double2hiint(v), PATTERN), __builtin_amdgcn_ds_swizzle(__double2loint(v), PATTERN));
+}
+template <int PATTERN>
+__device__ __forceinline__ float group_bcast(float v) { return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), PATTERN)); }
+
 // Wave reductions on the VALU (DPP), not through the LDS crossbar (ds_bpermute): the LDS pipeline is this kernel's
 // tightest resource and a 6-step bpermute chain costs ~460 cycles of latency against ~130 here.  Four row_ror steps
 // leave every lane of a 16-lane row with the row's total, row_bcast15 / row_bcast31 fold the rows into lane 63.
@@ -127,84 +146,110 @@ __device__ __forceinline__ double dpp_move(double x, double identity) {
   const int hi = __builtin_amdgcn_update_dpp(__double2hiint(identity), __double2hiint(x), CTRL, ROW_MASK, 0xf, false);
   return __hiloint2double(hi, lo);
 }
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_move(float x, float identity) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(identity), __float_as_int(x), CTRL, ROW_MASK, 0xf, false));
+}
 #define DPP_ROW_ROR(n) (0x120 + (n))
 #define DPP_ROW_BCAST15 0x142
 #define DPP_ROW_BCAST31 0x143
 struct op_sum {
-  static __device__ __forceinline__ double id() { return 0.0; }
-  static __device__ __forceinline__ double f(double a, double b) { return a + b; }
+  template <typename real> static __device__ __forceinline__ real id() { return real(0); }
+  template <typename real> static __device__ __forceinline__ real f(real a, real b) { return a + b; }
 };
 struct op_max {
-  static __device__ __forceinline__ double id() { return -INFINITY; }
-  static __device__ __forceinline__ double f(double a, double b) { return fmax(a, b); }
+  template <typename real> static __device__ __forceinline__ real id() { return -real(INFINITY); }
+  template <typename real> static __device__ __forceinline__ real f(real a, real b) { return fmax(a, b); }
 };
 struct op_min {
-  static __device__ __forceinline__ double id() { return INFINITY; }
-  static __device__ __forceinline__ double f(double a, double b) { return fmin(a, b); }
+  template <typename real> static __device__ __forceinline__ real id() { return real(INFINITY); }
+  template <typename real> static __device__ __forceinline__ real f(real a, real b) { return fmin(a, b); }
 };
 // NV independent reductions in lock-step (their steps interleave); results as wave-uniform scalars
-template <class OP, int NV>
-__device__ __forceinline__ void wave_reduce_n(double (&v)[NV]) {
+template <class OP, int NV, typename real>
+__device__ __forceinline__ void wave_reduce_n(real (&v)[NV]) {
+  const real id = OP::template id<real>();
 #pragma unroll
-  for (int k = 0; k < NV; ++k) v[k] = OP::f(v[k], dpp_move<DPP_ROW_ROR(8), 0xf>(v[k], OP::id()));
+  for (int k = 0; k < NV; ++k) v[k] = OP::f(v[k], dpp_move<DPP_ROW_ROR(8), 0xf>(v[k], id));
 #pragma unroll
-  for (int k = 0; k < NV; ++k) v[k] = OP::f(v[k], dpp_move<DPP_ROW_ROR(4), 0xf>(v[k], OP::id()));
+  for (int k = 0; k < NV; ++k) v[k] = OP::f(v[k], dpp_move<DPP_ROW_ROR(4), 0xf>(v[k], id));
 #pragma unroll
-  for (int k = 0; k < NV; ++k) v[k] = OP::f(v[k], dpp_move<DPP_ROW_ROR(2), 0xf>(v[k], OP::id()));
+  for (int k = 0; k < NV; ++k) v[k] = OP::f(v[k], dpp_move<DPP_ROW_ROR(2), 0xf>(v[k], id));
 #pragma unroll
-  for (int k = 0; k < NV; ++k) v[k] = OP::f(v[k], dpp_move<DPP_ROW_ROR(1), 0xf>(v[k], OP::id()));
+  for (int k = 0; k < NV; ++k) v[k] = OP::f(v[k], dpp_move<DPP_ROW_ROR(1), 0xf>(v[k], id));
 #pragma unroll
-  for (int k = 0; k < NV; ++k) v[k] = OP::f(v[k], dpp_move<DPP_ROW_BCAST15, 0xa>(v[k], OP::id()));
+  for (int k = 0; k < NV; ++k) v[k] = OP::f(v[k], dpp_move<DPP_ROW_BCAST15, 0xa>(v[k], id));
 #pragma unroll
-  for (int k = 0; k < NV; ++k) v[k] = OP::f(v[k], dpp_move<DPP_ROW_BCAST31, 0xc>(v[k], OP::id()));
+  for (int k = 0; k < NV; ++k) v[k] = OP::f(v[k], dpp_move<DPP_ROW_BCAST31, 0xc>(v[k], id));
 #pragma unroll
-  for (int k = 0; k < NV; ++k)
-    v[k] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v[k]), 63), __builtin_amdgcn_readlane(__double2loint(v[k]), 63));
+  for (int k = 0; k < NV; ++k) v[k] = lane_bcast(v[k], 63);
 }
-__device__ __forceinline__ double wave_sum(double x) {
-  double v[1] = {x};
+template <typename real>
+__device__ __forceinline__ real wave_sum(real x) {
+  real v[1] = {x};
   wave_reduce_n<op_sum, 1>(v);
   return v[0];
 }
-__device__ __forceinline__ double wave_max(double x) {
-  double v[1] = {x};
+template <typename real>
+__device__ __forceinline__ real wave_max(real x) {
+  real v[1] = {x};
   wave_reduce_n<op_max, 1>(v);
   return v[0];
 }
-__device__ __forceinline__ double wave_min(double x) {
-  double v[1] = {x};
+template <typename real>
+__device__ __forceinline__ real wave_min(real x) {
+  real v[1] = {x};
   wave_reduce_n<op_min, 1>(v);
   return v[0];
 }
+template <int NV, typename real>
+__device__ __forceinline__ void wave_sum_n(real (&v)[NV]) {
+  wave_reduce_n<op_sum, NV>(v);
+}
 
-// 1/x: hardware v_rcp_f64 seed + one Newton step (full fp64 accuracy for normal x); replaces the
-// ~12-instruction IEEE division sequence in the per-row arithmetic.
+// 1/x: hardware v_rcp seed + one Newton step (full accuracy for normal x); replaces the ~12-instruction IEEE
+// division sequence in the per-row arithmetic.
 __device__ __forceinline__ double frcp(double x) {
   double r = __builtin_amdgcn_rcp(x);
   return __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
 }
-
-template <int NV>
-__device__ __forceinline__ void wave_sum_n(double (&v)[NV]) {
-  wave_reduce_n<op_sum, NV>(v);
+__device__ __forceinline__ float frcp(float x) {
+  float r = __builtin_amdgcn_rcpf(x);
+  return __builtin_fmaf(__builtin_fmaf(-x, r, 1.0f), r, r);
 }
+
+// Per-precision constants of the iteration.  fp32: the complementarity floor of a single-precision Riccati
+// recursion is ~1e-6 (weights lam/t ~ 1e5 already cancel four digits in P), rows are feasible to ~1e-4.
+template <typename real> struct ipm_limits;
+template <> struct ipm_limits<double> {
+  static __device__ __forceinline__ double tol(double cfg) { return cfg; }
+  static constexpr double rd_ok = 1e-9, rd_infeasible = 1e-6, tiny = 1e-300;
+};
+template <> struct ipm_limits<float> {
+  static __device__ __forceinline__ float tol(double cfg) { return fmaxf((float)cfg, 2e-6f); }
+  static constexpr float rd_ok = 1e-4f, rd_infeasible = 1e-2f, tiny = 1e-30f;
+};
+template <typename real> struct vec2;
+template <> struct vec2<double> { typedef double2 type; };
+template <> struct vec2<float> { typedef float2 type; };
 
 // Inverse of a symmetric positive definite 6x6 (row-major, full storage) by Cholesky; every index is
 // a compile-time constant after unrolling, so the factor lives in registers.  Executed redundantly by
 // all lanes on wave-uniform data.
-__device__ __forceinline__ void spd_inv6(const double (&F)[36], double (&Fi)[36]) {
-  double Lc[36];
+template <typename real>
+__device__ __forceinline__ void spd_inv6(const real (&F)[36], real (&Fi)[36]) {
+  real Lc[36];
 #pragma unroll
   for (int j = 0; j < 6; ++j) {
-    double d = F[j * 6 + j];
+    real d = F[j * 6 + j];
 #pragma unroll
     for (int k = 0; k < j; ++k) d -= Lc[j * 6 + k] * Lc[j * 6 + k];
     d = sqrt(d);
-    const double id = 1.0 / d;
+    const real id = 1.0 / d;
     Lc[j * 6 + j] = id;  // store the reciprocal of the pivot
 #pragma unroll
     for (int i = j + 1; i < 6; ++i) {
-      double t = F[i * 6 + j];
+      real t = F[i * 6 + j];
 #pragma unroll
       for (int k = 0; k < j; ++k) t -= Lc[i * 6 + k] * Lc[j * 6 + k];
       Lc[i * 6 + j] = t * id;
@@ -212,17 +257,17 @@ __device__ __forceinline__ void spd_inv6(const double (&F)[36], double (&Fi)[36]
   }
 #pragma unroll
   for (int c = 0; c < 6; ++c) {
-    double y[6], x[6];
+    real y[6], x[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
-      double t = (i == c) ? 1.0 : 0.0;
+      real t = (i == c) ? 1.0 : 0.0;
 #pragma unroll
       for (int k = 0; k < i; ++k) t -= Lc[i * 6 + k] * y[k];
       y[i] = t * Lc[i * 6 + i];
     }
 #pragma unroll
     for (int i = 5; i >= 0; --i) {
-      double t = y[i];
+      real t = y[i];
 #pragma unroll
       for (int k = i + 1; k < 6; ++k) t -= Lc[k * 6 + i] * x[k];
       x[i] = t * Lc[i * 6 + i];
@@ -234,13 +279,14 @@ __device__ __forceinline__ void spd_inv6(const double (&F)[36], double (&Fi)[36]
 
 // LMPC simplex row j: gradient of the (eps-eliminated) terminal cost wrt lambda_j including the row's
 // barrier coefficient, bl_j = ss_j - cf_j - u_j'E eps; also returns 1/max(theta_j, floor).
-__device__ __forceinline__ double simplex_bl(double lm, double t, double l, double pprod, double ssj, const double (&u)[6],
-                                             double smu, double pm, const double* ct, const double* T, double& itf) {
-  const double it_ = frcp(t);
-  const double th = l * it_;
+template <typename real>
+__device__ __forceinline__ real simplex_bl(real lm, real t, real l, real pprod, real ssj, const real (&u)[6],
+                                             real smu, real pm, const real* ct, const real* T, real& itf) {
+  const real it_ = frcp(t);
+  const real th = l * it_;
   itf = frcp(fmax(th, TH_L_MIN));
-  const double cf = th * (-lm + t) + (smu - pm * pprod) * it_;
-  double ue = 0.0;
+  const real cf = th * (-lm + t) + (smu - pm * pprod) * it_;
+  real ue = 0.0;
 #pragma unroll
   for (int k = 0; k < 6; ++k) ue += u[k] * ct[CT_E + k] * T[TL_EPS + k];
   return ssj - cf - ue;
@@ -248,38 +294,32 @@ __device__ __forceinline__ double simplex_bl(double lm, double t, double l, doub
 
 // Register-resident state of the LMPC simplex rows lambda_j >= 0 (KS safe-set points per lane); empty for
 // the tracking kernel so that it costs it nothing.
-template <int KS>
+template <typename real, int KS>
 struct SimplexRows {
   bool on[KS];
-  double lm[KS], t[KS], l[KS], p[KS], j[KS], u[KS][6], dl[KS];
-  double ss0[6];
-  double r1;  // 1 - 1'lambda
+  real lm[KS], t[KS], l[KS], p[KS], j[KS], u[KS][6], dl[KS];
+  real ss0[6];
+  real r1;  // 1 - 1'lambda
 };
-template <>
-struct SimplexRows<0> {};
+template <typename real>
+struct SimplexRows<real, 0> {};
 
+template <typename real>
 struct Lds {
-  double* base;
+  real* base;
   int N;
-  __device__ __forceinline__ double* st(int i) const { return base + i * LMPC_STAGE_STRIDE; }
-  __device__ __forceinline__ double* kn(int i) const { return base + (N - 1) * LMPC_STAGE_STRIDE + i * LMPC_KNOT_STRIDE; }
-  __device__ __forceinline__ double* tail() const { return base + (N - 1) * LMPC_STAGE_STRIDE + N * LMPC_KNOT_STRIDE; }
+  __device__ __forceinline__ real* st(int i) const { return base + i * LMPC_STAGE_STRIDE; }
+  __device__ __forceinline__ real* kn(int i) const { return base + (N - 1) * LMPC_STAGE_STRIDE + i * LMPC_KNOT_STRIDE; }
+  __device__ __forceinline__ real* tail() const { return base + (N - 1) * LMPC_STAGE_STRIDE + N * LMPC_KNOT_STRIDE; }
 };
 
 // true cost Hessian entry on z_i (no barrier terms), racing_mpc.cpp:459-476; terminal knot or a knot 1 <= i <= N-2
-__device__ __forceinline__ double qz_entry(const double* ct, bool terminal, int r, int c) {
+template <typename real>
+__device__ __forceinline__ real qz_entry(const real* ct, bool terminal, int r, int c) {
   const int rx = r < 6 ? r : 0, ru = r >= 6 ? r - 6 : 0, cu = c >= 6 ? c - 6 : 0;
-  const double dx = terminal ? ct[CT_QT + rx] : ct[CT_QD + rx];
-  const double uu = ct[CT_QU + ru * 2 + cu];
+  const real dx = terminal ? ct[CT_QT + rx] : ct[CT_QD + rx];
+  const real uu = ct[CT_QU + ru * 2 + cu];
   return (r < 6 || c < 6) ? ((r == c) ? dx : 0.0) : uu;
-}
-
-// Lane k's value of a wave-distributed double as a wave-uniform scalar (two v_readlane_b32; the
-// result lives in SGPRs and feeds v_fma_f64 as a scalar operand).
-__device__ __forceinline__ double lane_bcast(double v, int k) {
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), k);
-  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), k);
-  return __hiloint2double(hi, lo);
 }
 
 // Pin the issue order of LDS traffic: one wave's DS instructions return in issue order, so the read a
@@ -298,21 +338,21 @@ __device__ __forceinline__ double lane_bcast(double v, int k) {
 // own element of P / W in a register, everything that does not depend on the chain (model rows, barrier
 // weights) is fetched one stage ahead, and the three exchanges per stage (P, W, Y rows through LDS) are
 // the only waits; the 2x2 inverse starts from v_readlane copies of Y_uu while the Y rows are in flight.
-template <bool HAS_PT>
-__device__ void riccati_factor(const Lds& L, int lane, const double* PT) {
+template <bool HAS_PT, typename real>
+__device__ void riccati_factor(const Lds<real>& L, int lane, const real* PT) {
   const int N = L.N, r = lane >> 3, c = lane & 7;
-  double* T = L.tail();
-  double* MP = T + TL_P;
-  double* MW = T + TL_W;
-  double* MY = T + TL_Y;
-  const double* ct = T + TL_CT;
+  real* T = L.tail();
+  real* MP = T + TL_P;
+  real* MW = T + TL_W;
+  real* MY = T + TL_Y;
+  const real* ct = T + TL_CT;
   const bool diag = r == c;
-  const double qmid = qz_entry(ct, false, r, c);
-  double pown;
+  const real qmid = qz_entry(ct, false, r, c);
+  real pown;
   {
-    const double* kn = L.kn(N - 1);
-    double e = qz_entry(ct, true, r, c);
-    const double th = kn[KN_R0 + r] + (r == 1 ? kn[KN_EY] : 0.0);
+    const real* kn = L.kn(N - 1);
+    real e = qz_entry(ct, true, r, c);
+    const real th = kn[KN_R0 + r] + (r == 1 ? kn[KN_EY] : 0.0);
     if (diag) e += th;
     if (HAS_PT && r < 6 && c < 6) e += PT[r * 6 + c];  // LMPC: safe-set block condensed onto x_T
     pown = e;
@@ -322,11 +362,11 @@ __device__ void riccati_factor(const Lds& L, int lane, const double* PT) {
   // rest to their own (dead) W cell
   const int res_off = lane < 16 ? ST_ROW(c) + 6 + r : (lane == 18 ? ST_HI11 : ST_HI + (lane - 16));
   const bool res_on = lane < 19;
-  double* const res_junk = MW + r * MROW + c;
+  real* const res_junk = MW + r * MROW + c;
   // phase-1/2 operands of stage N-2 (later stages: fetched during phase 3 of the stage before)
-  double ar[6], ac[6];
+  real ar[6], ac[6];
   {
-    const double* st = L.st(N - 2);
+    const real* st = L.st(N - 2);
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
       ar[k] = st[ST_ROW(r) + k];
@@ -335,37 +375,37 @@ __device__ void riccati_factor(const Lds& L, int lane, const double* PT) {
   }
   wave_sync();
   for (int i = N - 2; i >= 0; --i) {
-    double* st = L.st(i);
-    const double* kn = L.kn(i);
+    real* st = L.st(i);
+    const real* kn = L.kn(i);
     // W = Abar' P : W[r][c] = sum_k Abar[k][r] P[k][c]  (+ P[r][c] for the u rows); P[k][c] read as P[c][k]
-    double pr[6];
+    real pr[6];
 #pragma unroll
     for (int k = 0; k < 6; ++k) pr[k] = MP[c * MROW + k];
     ISSUE_ORDER();
     // phase-3 operands of this stage, queued behind the P row
-    const double t = st[ST_DT], thr = kn[KN_R0 + r], ey = kn[KN_EY], thv0 = kn[KN_R0 + 8], thv1 = kn[KN_R0 + 9];
-    const double sv00 = ct[CT_SV + 0], sv01 = ct[CT_SV + 1], sv11 = ct[CT_SV + 3];
+    const real t = st[ST_DT], thr = kn[KN_R0 + r], ey = kn[KN_EY], thv0 = kn[KN_R0 + 8], thv1 = kn[KN_R0 + 9];
+    const real sv00 = ct[CT_SV + 0], sv01 = ct[CT_SV + 1], sv11 = ct[CT_SV + 3];
     ISSUE_ORDER();
-    double w = (r >= 6) ? pown : 0.0;
+    real w = (r >= 6) ? pown : 0.0;
 #pragma unroll
     for (int k = 0; k < 6; ++k) w += ar[k] * pr[k];
     MW[r * MROW + c] = w;
     wave_sync();
     // Y = W Abar
-    double wr[6];
+    real wr[6];
 #pragma unroll
     for (int k = 0; k < 6; ++k) wr[k] = MW[r * MROW + k];
-    double y = (c >= 6) ? w : 0.0;
+    real y = (c >= 6) ? w : 0.0;
 #pragma unroll
     for (int k = 0; k < 6; ++k) y += wr[k] * ac[k];
     MY[r * MROW + c] = y;
     wave_sync();
     // H = Sv + Thv + t^2 Y_uu, K = H^-1 t Y[6:8,:], P <- Qz + Thz + Y - t^2 Y[6:8,r]' H^-1 Y[6:8,c]
-    const double y6r = MY[6 * MROW + r], y7r = MY[7 * MROW + r];
-    const double y6c = MY[6 * MROW + c], y7c = MY[7 * MROW + c];
+    const real y6r = MY[6 * MROW + r], y7r = MY[7 * MROW + r];
+    const real y6c = MY[6 * MROW + c], y7c = MY[7 * MROW + c];
     AFTER_VALUE(y);
     {  // phase-1/2 operands of the next stage (their registers are dead by now), queued behind the Y rows
-      const double* stn = L.st(i > 0 ? i - 1 : 0);
+      const real* stn = L.st(i > 0 ? i - 1 : 0);
 #pragma unroll
       for (int k = 0; k < 6; ++k) {
         ar[k] = stn[ST_ROW(r) + k];
@@ -373,22 +413,22 @@ __device__ void riccati_factor(const Lds& L, int lane, const double* PT) {
       }
     }
     ISSUE_ORDER();
-    const double y66 = lane_bcast(y, 54), y67 = lane_bcast(y, 55), y77 = lane_bcast(y, 63);
-    const double tt = t * t;
-    const double h00 = sv00 + thv0 + tt * y66;
-    const double h01 = sv01 + tt * y67;
-    const double h11 = sv11 + thv1 + tt * y77;
-    const double idet = frcp(h00 * h11 - h01 * h01);
-    const double hi00 = h11 * idet, hi01 = -h01 * idet, hi11 = h00 * idet;
-    const double g0 = t * y6c, g1 = t * y7c;
-    const double k0c = hi00 * g0 + hi01 * g1;
-    const double k1c = hi01 * g0 + hi11 * g1;
-    double pn = qmid + y - t * (y6r * k0c + y7r * k1c);
-    const double th = thr + (r == 1 ? ey : 0.0);
+    const real y66 = lane_bcast(y, 54), y67 = lane_bcast(y, 55), y77 = lane_bcast(y, 63);
+    const real tt = t * t;
+    const real h00 = sv00 + thv0 + tt * y66;
+    const real h01 = sv01 + tt * y67;
+    const real h11 = sv11 + thv1 + tt * y77;
+    const real idet = frcp(h00 * h11 - h01 * h01);
+    const real hi00 = h11 * idet, hi01 = -h01 * idet, hi11 = h00 * idet;
+    const real g0 = t * y6c, g1 = t * y7c;
+    const real k0c = hi00 * g0 + hi01 * g1;
+    const real k1c = hi01 * g0 + hi11 * g1;
+    real pn = qmid + y - t * (y6r * k0c + y7r * k1c);
+    const real th = thr + (r == 1 ? ey : 0.0);
     if (diag) pn += th;
     pown = pn;
     MP[r * MROW + c] = pn;  // (not used after stage 0)
-    const double res = lane < 8 ? k0c : (lane < 16 ? k1c : (lane == 16 ? hi00 : (lane == 17 ? hi01 : hi11)));
+    const real res = lane < 8 ? k0c : (lane < 16 ? k1c : (lane == 16 ? hi00 : (lane == 17 ? hi01 : hi11)));
     *(res_on ? st + res_off : res_junk) = res;
     wave_sync();
   }
@@ -403,68 +443,66 @@ __device__ void riccati_factor(const Lds& L, int lane, const double* PT) {
 // running vector makes one trip through LDS (one write, broadcast b128 reads), the 2-vector a stage
 // condenses to (B'p, du) is spread with v_readlane, and the stage operands are fetched one stage ahead.
 // Lanes >= 8 NRHS mirror lanes below and write to dead cells of the factor work matrices.
-template <int NRHS>
-__device__ void riccati_solve(const Lds& L, int lane, Prof& pf) {
+template <int NRHS, typename real>
+__device__ void riccati_solve(const Lds<real>& L, int lane, Prof& pf) {
   const int N = L.N;
   const int r = lane & 7, s = (lane >> 3) & (NRHS - 1);
   const bool own = lane < 8 * NRHS;
   const int reg = KN_R0 + 10 * s;
-  double* T = L.tail();
-  double* const junk0 = T + TL_W + lane;  // 64 + 64 dead cells: W (80) and Y (80) are contiguous
-  double* const junk1 = T + TL_W + 80 + lane;
-  double* const pvec = T + TL_PV + 8 * s;
-  double* const pdst = own ? pvec + r : junk0;
-  auto spread2 = [&](double v, double& a, double& b) {  // values of lanes (s, 6) and (s, 7) to the whole group
+  real* T = L.tail();
+  real* const junk0 = T + TL_W + lane;  // 64 + 64 dead cells: W (80) and Y (80) are contiguous
+  real* const junk1 = T + TL_W + 80 + lane;
+  real* const pvec = T + TL_PV + 8 * s;
+  real* const pdst = own ? pvec + r : junk0;
+  auto spread2 = [&](real v, real& a, real& b) {  // values of lanes (s, 6) and (s, 7) to the whole group
     if constexpr (NRHS == 2) {
-      // ds_swizzle bit mode: source lane = (lane & 0x18) | 6 (resp. 7), i.e. lane 6 / 7 of each group of 8
-      const int lo = __double2loint(v), hi = __double2hiint(v);
-      a = __hiloint2double(__builtin_amdgcn_ds_swizzle(hi, 0x00D8), __builtin_amdgcn_ds_swizzle(lo, 0x00D8));
-      b = __hiloint2double(__builtin_amdgcn_ds_swizzle(hi, 0x00F8), __builtin_amdgcn_ds_swizzle(lo, 0x00F8));
+      a = group_bcast<0x00D8>(v);
+      b = group_bcast<0x00F8>(v);
     } else {
       a = lane_bcast(v, 6);
       b = lane_bcast(v, 7);
     }
   };
   // ---- backward: p_i = q_i + Abar' p_{i+1} - K' (q_v + Bbar' p_{i+1});  kff_i = H^-1 (q_v + Bbar' p_{i+1})
-  double p = L.kn(N - 1)[reg + r];
+  real p = L.kn(N - 1)[reg + r];
   *pdst = p;
-  double row[6];  // [A B](:, r), fetched one stage ahead
+  real row[6];  // [A B](:, r), fetched one stage ahead
   {
-    const double* st = L.st(N - 2);
+    const real* st = L.st(N - 2);
 #pragma unroll
     for (int k = 0; k < 6; ++k) row[k] = st[ST_ROW(r) + k];
   }
   wave_sync();
   for (int i = N - 2; i >= 0; --i) {
-    double* st = L.st(i);
-    const double* kn = L.kn(i);
-    double pb[6];
+    real* st = L.st(i);
+    const real* kn = L.kn(i);
+    real pb[6];
 #pragma unroll
     for (int k = 0; k < 6; ++k) pb[k] = pvec[k];
     ISSUE_ORDER();
     // what the stage needs after the product, queued behind the costate
-    const double k0r = st[ST_ROW(r) + 6], k1r = st[ST_ROW(r) + 7], t = st[ST_DT];
-    const double qz = kn[reg + r], qv0 = kn[reg + 8], qv1 = kn[reg + 9];
-    const double hi00 = st[ST_HI], hi01 = st[ST_HI + 1], hi11 = st[ST_HI11];
+    const real k0r = st[ST_ROW(r) + 6], k1r = st[ST_ROW(r) + 7], t = st[ST_DT];
+    const real qz = kn[reg + r], qv0 = kn[reg + 8], qv1 = kn[reg + 9];
+    const real hi00 = st[ST_HI], hi01 = st[ST_HI + 1], hi11 = st[ST_HI11];
     ISSUE_ORDER();
-    double w = (r >= 6) ? p : 0.0;  // w = Abar' p: rows 6,7 also take p_u
+    real w = (r >= 6) ? p : 0.0;  // w = Abar' p: rows 6,7 also take p_u
 #pragma unroll
     for (int k = 0; k < 6; ++k) w = __builtin_fma(row[k], pb[k], w);
     AFTER_VALUE(w);
-    double w6, w7;
+    real w6, w7;
     spread2(w, w6, w7);
     ISSUE_ORDER();
     {
-      const double* stn = L.st(i > 0 ? i - 1 : 0);
+      const real* stn = L.st(i > 0 ? i - 1 : 0);
 #pragma unroll
       for (int k = 0; k < 6; ++k) row[k] = stn[ST_ROW(r) + k];
     }
     ISSUE_ORDER();
-    const double hv0 = __builtin_fma(t, w6, qv0);
-    const double hv1 = __builtin_fma(t, w7, qv1);
+    const real hv0 = __builtin_fma(t, w6, qv0);
+    const real hv1 = __builtin_fma(t, w7, qv1);
     p = qz + w - (k0r * hv0 + k1r * hv1);  // (not used after stage 0)
     *pdst = p;
-    const double kff = (r == 0) ? hi00 * hv0 + hi01 * hv1 : hi01 * hv0 + hi11 * hv1;
+    const real kff = (r == 0) ? hi00 * hv0 + hi01 * hv1 : hi01 * hv0 + hi11 * hv1;
     *((own && r < 2) ? st + ST_KFF(s) + r : junk1) = kff;
     wave_sync();
   }
@@ -472,44 +510,44 @@ __device__ void riccati_solve(const Lds& L, int lane, Prof& pf) {
   // ---- forward: dv_i = -kff_i - K dz_i,  dz_{i+1} = Abar dz_i + Bbar dv_i
   // lanes r < 6 take a state row, lanes 6, 7 the two rows of K: column k of M is [A B](:, k) | K(:, k)
   *(own ? L.kn(0) + reg + r : junk0) = 0.0;
-  double col[8], a0;  // M(r, :) and the feed-forward term, fetched one stage ahead
+  real col[8], a0;  // M(r, :) and the feed-forward term, fetched one stage ahead
   {
-    const double* st = L.st(0);
+    const real* st = L.st(0);
 #pragma unroll
     for (int k = 0; k < 8; ++k) col[k] = st[ST_ROW(k) + r];
     a0 = st[ST_KFF(s) + (r & 1)];
   }
   wave_sync();
   for (int i = 0; i < N - 1; ++i) {
-    const double* st = L.st(i);
-    double* kn = L.kn(i);
-    double dz[8];
+    const real* st = L.st(i);
+    real* kn = L.kn(i);
+    real dz[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) dz[k] = kn[reg + k];
     ISSUE_ORDER();
-    const double b0 = st[ST_ROW(6) + r], b1 = st[ST_ROW(7) + r], t = st[ST_DT];
+    const real b0 = st[ST_ROW(6) + r], b1 = st[ST_ROW(7) + r], t = st[ST_DT];
     ISSUE_ORDER();
-    double acc = (r >= 6) ? a0 : 0.0;
+    real acc = (r >= 6) ? a0 : 0.0;
 #pragma unroll
     for (int k = 0; k < 6; ++k) acc = __builtin_fma(col[k], dz[k], acc);
-    const double ax = acc;  // state rows: A dz_x
+    const real ax = acc;  // state rows: A dz_x
     acc = __builtin_fma(col[6], dz[6], acc);
     acc = __builtin_fma(col[7], dz[7], acc);
     AFTER_VALUE(acc);
-    const double dv = -acc;  // lanes 6, 7
-    const double du = __builtin_fma(t, dv, (r == 6) ? dz[6] : dz[7]);
-    double du0, du1;
+    const real dv = -acc;  // lanes 6, 7
+    const real du = __builtin_fma(t, dv, (r == 6) ? dz[6] : dz[7]);
+    real du0, du1;
     spread2(du, du0, du1);
     ISSUE_ORDER();
     {
-      const double* stn = L.st(i < N - 2 ? i + 1 : i);
+      const real* stn = L.st(i < N - 2 ? i + 1 : i);
 #pragma unroll
       for (int k = 0; k < 8; ++k) col[k] = stn[ST_ROW(k) + r];
       a0 = stn[ST_KFF(s) + (r & 1)];
     }
     ISSUE_ORDER();
-    const double nx = __builtin_fma(b1, du1, __builtin_fma(b0, du0, ax));
-    const double d = (r < 6) ? nx : du;
+    const real nx = __builtin_fma(b1, du1, __builtin_fma(b0, du0, ax));
+    const real d = (r < 6) ? nx : du;
     *(own ? kn + LMPC_KNOT_STRIDE + reg + r : junk0) = d;
     *((own && r >= 6) ? kn + reg + 2 + r : junk1) = dv;
     wave_sync();
@@ -521,59 +559,62 @@ __device__ void riccati_solve(const Lds& L, int lane, Prof& pf) {
 // The linearised model can be open-loop unstable (|eig A| > 1 at low speed with dt = 25 ms), so
 // the start trajectory is generated under the stabilising Riccati feedback.  Same lane roles as the
 // forward sweep of riccati_solve.
-__device__ void feedback_rollout(const Lds& L, int lane) {
+template <typename real>
+__device__ void feedback_rollout(const Lds<real>& L, int lane) {
   const int N = L.N, r = lane & 7;
   const bool own = lane < 8;
-  double* T = L.tail();
-  double* const junk0 = T + TL_W + lane;
-  double* const junk1 = T + TL_W + 80 + lane;
+  real* T = L.tail();
+  real* const junk0 = T + TL_W + lane;
+  real* const junk1 = T + TL_W + 80 + lane;
   for (int i = 0; i < N - 1; ++i) {
-    const double* st = L.st(i);
-    double* kn = L.kn(i);
-    double dz[8], col[8];
+    const real* st = L.st(i);
+    real* kn = L.kn(i);
+    real dz[8], col[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) dz[k] = kn[k];
 #pragma unroll
     for (int k = 0; k < 8; ++k) col[k] = st[ST_ROW(k) + r];
-    const double t = st[ST_DT];
-    const double g = st[ST_G + (r < 6 ? r : 0)];
-    double acc = 0.0;
+    const real t = st[ST_DT];
+    const real g = st[ST_G + (r < 6 ? r : 0)];
+    real acc = 0.0;
 #pragma unroll
     for (int k = 0; k < 6; ++k) acc = __builtin_fma(col[k], dz[k], acc);
-    const double ax = acc;
+    const real ax = acc;
     acc = __builtin_fma(col[6], dz[6], acc);
     acc = __builtin_fma(col[7], dz[7], acc);
-    const double v = -acc;
-    const double u = __builtin_fma(t, v, (r == 6) ? dz[6] : dz[7]);
-    const double u0 = lane_bcast(u, 6), u1 = lane_bcast(u, 7);
-    const double nx = g + __builtin_fma(col[7], u1, __builtin_fma(col[6], u0, ax));
+    const real v = -acc;
+    const real u = __builtin_fma(t, v, (r == 6) ? dz[6] : dz[7]);
+    const real u0 = lane_bcast(u, 6), u1 = lane_bcast(u, 7);
+    const real nx = g + __builtin_fma(col[7], u1, __builtin_fma(col[6], u0, ax));
     *(own ? kn + LMPC_KNOT_STRIDE + r : junk0) = (r < 6) ? nx : u;
     *((own && r >= 6) ? kn + 2 + r : junk1) = v;
     wave_sync();
   }
 }
 
-template <int KQ, int KS>
+template <typename real, int KQ, int KS>
 __global__ __launch_bounds__(64, ((KQ <= 4 && KS == 0) ? 2 : 1)) void lmpc_solve_kernel(
-    lmpc_params P, int B, const double* __restrict__ ws_lin, const double* __restrict__ x_ic,
-    const double* __restrict__ u_ic, const double* __restrict__ T_ref, const double* __restrict__ bl,
-    const double* __restrict__ br, const double* __restrict__ vref, const double* __restrict__ ss_x,
-    const double* __restrict__ ss_j, double* __restrict__ lam_out, double* __restrict__ X_out,
-    double* __restrict__ U_out, double* __restrict__ dU_out, int* __restrict__ status_out,
-    int* __restrict__ iters_out, double* __restrict__ kkt_out) {
-  extern __shared__ __attribute__((aligned(16))) double lds[];
+    lmpc_params P, int B, const real* __restrict__ ws_lin, const real* __restrict__ x_ic,
+    const real* __restrict__ u_ic, const real* __restrict__ T_ref, const real* __restrict__ bl,
+    const real* __restrict__ br, const real* __restrict__ vref, const real* __restrict__ ss_x,
+    const real* __restrict__ ss_j, real* __restrict__ lam_out, real* __restrict__ X_out,
+    real* __restrict__ U_out, real* __restrict__ dU_out, int* __restrict__ status_out,
+    int* __restrict__ iters_out, real* __restrict__ kkt_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];  // one symbol for every instantiation
+  real* const lds = reinterpret_cast<real*>(lds_raw);
   const int b = blockIdx.x;
   const int lane = threadIdx.x;
   const int N = P.N, NS = N - 1;
-  Lds L{lds, N};
-  double* T = L.tail();
-  double* ct = T + TL_CT;
-  double* KN0 = L.kn(0);
+  typedef typename vec2<real>::type real2;
+  Lds<real> L{lds, N};
+  real* T = L.tail();
+  real* ct = T + TL_CT;
+  real* KN0 = L.kn(0);
   PT_DECL
 
   // ---------------- load: linearisation records, per-knot data, constant tables ----------------
   {
-    const double* wsb = ws_lin + (size_t)b * NS * LMPC_LIN_RECORD;
+    const real* wsb = ws_lin + (size_t)b * NS * LMPC_LIN_RECORD;
     for (int e = lane; e < NS * LMPC_LIN_RECORD; e += 64) {
       const int i = e / LMPC_LIN_RECORD, o = e - i * LMPC_LIN_RECORD;
       const int c = o / 6;
@@ -581,7 +622,7 @@ __global__ __launch_bounds__(64, ((KQ <= 4 && KS == 0) ? 2 : 1)) void lmpc_solve
     }
     for (int i = lane; i < NS; i += 64) L.st(i)[ST_DT] = T_ref[(size_t)i * B + b];
     for (int i = lane; i < N; i += 64) {
-      double* kn = L.kn(i);
+      real* kn = L.kn(i);
       kn[KN_QLIN] = P.learning ? 0.0 : (i == N - 1 ? P.qv_term : P.qv_stage) * vref[(size_t)i * B + b];
       kn[8] = 0.0;
       kn[9] = 0.0;
@@ -631,8 +672,8 @@ __global__ __launch_bounds__(64, ((KQ <= 4 && KS == 0) ? 2 : 1)) void lmpc_solve
   int s_gf[KQ];   // gradient recipe: ct index of the coefficient on the value | on its partner << 8 | (partner offset + 1) << 16,
                   // and flags << 20: F_UP / F_LO row exists, F_SIG boundary slot carrying sigma, F_QLIN takes the linear
                   // vx cost, F_MOVE owns a moving primal component, F_EY boundary slot, F_SCH boundary slot of a knot >= 1
-  double s_tu[KQ], s_tl[KQ], s_lu[KQ], s_ll[KQ], s_pu[KQ], s_pl[KQ];
-  double m_rows = 0.0;
+  real s_tu[KQ], s_tl[KQ], s_lu[KQ], s_ll[KQ], s_pu[KQ], s_pl[KQ];
+  real m_rows = 0.0;
 #pragma unroll
   for (int q = 0; q < KQ; ++q) {
     const int j = lane + 64 * q;
@@ -642,7 +683,7 @@ __global__ __launch_bounds__(64, ((KQ <= 4 && KS == 0) ? 2 : 1)) void lmpc_solve
     const int kb = valid ? KNB + i * LMPC_KNOT_STRIDE : JB;
     o_val[q] = kb + (sl < SL_EY ? sl : 1);
     o_hl[q] = (valid && sl < SL_EY) ? CTB + CT_HL + 2 * sl : kb + KN_BHL;
-    double hi = INFINITY, lo = -INFINITY;
+    real hi = INFINITY, lo = -INFINITY;
     bool on = false;
     int ca = CT_ZERO, cb = CT_ZERO, pd = 0;
     if (valid) {
@@ -683,12 +724,12 @@ __global__ __launch_bounds__(64, ((KQ <= 4 && KS == 0) ? 2 : 1)) void lmpc_solve
   // where the slot writes its barrier weight / gradient entry: the rhs0 cell of its component, or the boundary cell
   auto o_w = [&](int q) { return o_val[q] + ((flags(q) & F_EY) ? KN_EY - 1 : KN_R0); };
   auto o_csig = [&](int q) { return (flags(q) & F_EY) ? o_val[q] + (KN_CSIG - 1) : JB + KN_CSIG; };
-  auto bounds = [&](int q) { return *reinterpret_cast<const double2*>(&lds[o_hl[q]]); };
+  auto bounds = [&](int q) { return *reinterpret_cast<const real2*>(&lds[o_hl[q]]); };
   // ---------------- LMPC: simplex rows lambda_j >= 0, one safe-set point per lane and k < KS ----------------
   // (racing_mpc.cpp:484-504).  The points are centred on the first one (valid because 1'lambda = 1):
   // all sums below then run over O(1) offsets instead of absolute abscissae.
   const int S = P.S;
-  SimplexRows<KS> sx;
+  SimplexRows<real, KS> sx;
   if constexpr (KS > 0) {
 #pragma unroll
     for (int k = 0; k < 6; ++k) sx.ss0[k] = ss_x[((size_t)k * S) * B + b];
@@ -707,25 +748,25 @@ __global__ __launch_bounds__(64, ((KQ <= 4 && KS == 0) ? 2 : 1)) void lmpc_solve
       m_rows += sx.on[q] ? 1.0 : 0.0;
     }
   }
-  const double m_tot = wave_sum(m_rows) + (has_sigma ? 1.0 : 0.0);
-  const double inv_m = uni(1.0 / m_tot);
+  const real m_tot = wave_sum(m_rows) + (has_sigma ? 1.0 : 0.0);
+  const real inv_m = uni(1.0 / m_tot);
 
   // knot-0 feasibility: the state box applies to x_0 = x_ic (racing_mpc.cpp:147,201)
   bool feasible = true;
   {
     bool ok = true;
     if (lane < 6) {
-      const double v = KN0[lane];
+      const real v = KN0[lane];
       ok = (v <= ct[CT_HL + 2 * lane]) && (v >= ct[CT_HL + 2 * lane + 1]);
     }
     if (lane == 6 && !has_sigma) {
-      const double ey = KN0[1];
+      const real ey = KN0[1];
       ok = (ey <= bl[b] - P.marg) && (ey >= br[b] + P.marg);
     }
     feasible = wave_min(ok ? 1.0 : 0.0) > 0.5;
   }
 
-  double sigma = 0.0, ts = 0.1, lams = 0.0;
+  real sigma = 0.0, ts = 0.1, lams = 0.0;
 
   // ---------------- start point: minimiser of the cost over the dynamics alone ----------------
 #pragma unroll
@@ -740,14 +781,14 @@ __global__ __launch_bounds__(64, ((KQ <= 4 && KS == 0) ? 2 : 1)) void lmpc_solve
   riccati_factor<(KS > 0)>(L, lane, T + TL_PT);
   feedback_rollout(L, lane);
   if constexpr (KS > 0) {
-    double ul[6] = {0, 0, 0, 0, 0, 0};
+    real ul[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int q = 0; q < KS; ++q)
 #pragma unroll
       for (int k = 0; k < 6; ++k) ul[k] += sx.u[q][k] * sx.lm[q];
     wave_sum_n<6>(ul);
     if (lane < 6) {
-      double e = 0.0;
+      real e = 0.0;
 #pragma unroll
       for (int k = 0; k < 6; ++k)
         if (k == lane) e = (L.kn(N - 1)[k] - sx.ss0[k]) - ul[k];
@@ -758,9 +799,9 @@ __global__ __launch_bounds__(64, ((KQ <= 4 && KS == 0) ? 2 : 1)) void lmpc_solve
   }
   PT_MARK(1)
 
-  const double tau = 0.995, mu0 = 0.1, thr_frac = 0.5;
+  const real tau = 0.995, mu0 = 0.1, thr_frac = 0.5;
   int status = LMPC_SOLVE_MAX_ITER, it = 0;
-  double mu = 0.0, mu_prev = INFINITY, rdmax = 0.0, rd_check = 0.0, last_step = 0.0, hsig = 0.0, ce = 0.0;
+  real mu = 0.0, mu_prev = INFINITY, rdmax = 0.0, rd_check = 0.0, last_step = 0.0, hsig = 0.0, ce = 0.0;
   const int max_iter = feasible ? P.max_iter : 0;
 
   // it == -1 is the start-point Newton step (all row weights zero, full step); it >= 0 the
@@ -769,10 +810,10 @@ __global__ __launch_bounds__(64, ((KQ <= 4 && KS == 0) ? 2 : 1)) void lmpc_solve
     const bool ipm = it >= 0;
     // ======== rows: complementarity, residual, barrier weights ========
     if (ipm) {
-      double musum = 0.0, rdl = 0.0, eysum = 0.0;
+      real musum = 0.0, rdl = 0.0, eysum = 0.0;
       {
-        double val[KQ];
-        double2 hl[KQ];
+        real val[KQ];
+        real2 hl[KQ];
 #pragma unroll
         for (int q = 0; q < KQ; ++q) {
           val[q] = lds[o_val[q]];
@@ -781,8 +822,8 @@ __global__ __launch_bounds__(64, ((KQ <= 4 && KS == 0) ? 2 : 1)) void lmpc_solve
 #pragma unroll
         for (int q = 0; q < KQ; ++q) {
           const int f = flags(q);
-          const double sg = (f & F_SIG) ? sigma : 0.0;
-          const double thu = s_lu[q] * frcp(s_tu[q]), thd = s_ll[q] * frcp(s_tl[q]);
+          const real sg = (f & F_SIG) ? sigma : 0.0;
+          const real thu = s_lu[q] * frcp(s_tu[q]), thd = s_ll[q] * frcp(s_tl[q]);
           musum += s_lu[q] * s_tu[q] + s_ll[q] * s_tl[q];
           rdl = fmax(rdl, (f & F_UP) ? fabs(val[q] - sg + s_tu[q] - hl[q].x) : 0.0);
           rdl = fmax(rdl, (f & F_LO) ? fabs(-val[q] - sg + s_tl[q] + hl[q].y) : 0.0);
@@ -792,15 +833,15 @@ __global__ __launch_bounds__(64, ((KQ <= 4 && KS == 0) ? 2 : 1)) void lmpc_solve
         }
       }
       if constexpr (KS > 0) {
-        double tt[21], av[14];  // T (upper triangle) | a[6], sum 1/theta, U lambda [6], sum lambda
+        real tt[21], av[14];  // T (upper triangle) | a[6], sum 1/theta, U lambda [6], sum lambda
 #pragma unroll
         for (int k = 0; k < 21; ++k) tt[k] = 0.0;
 #pragma unroll
         for (int k = 0; k < 14; ++k) av[k] = 0.0;
 #pragma unroll
         for (int q = 0; q < KS; ++q) {
-          const double on = sx.on[q] ? 1.0 : 0.0;
-          const double itf = on * frcp(fmax(sx.l[q] * frcp(sx.t[q]), TH_L_MIN));
+          const real on = sx.on[q] ? 1.0 : 0.0;
+          const real itf = on * frcp(fmax(sx.l[q] * frcp(sx.t[q]), TH_L_MIN));
           musum += on * sx.l[q] * sx.t[q];
           rdl = fmax(rdl, on * fabs(-sx.lm[q] + sx.t[q]));
           int n = 0;
@@ -817,7 +858,7 @@ __global__ __launch_bounds__(64, ((KQ <= 4 && KS == 0) ? 2 : 1)) void lmpc_solve
         wave_sum_n<21>(tt);
         wave_sum_n<14>(av);
         sx.r1 = 1.0 - av[13];
-        double F[36], Fi[36], Fia[6];
+        real F[36], Fi[36], Fia[6];
         {
           int n = 0;
 #pragma unroll
@@ -836,16 +877,16 @@ __global__ __launch_bounds__(64, ((KQ <= 4 && KS == 0) ? 2 : 1)) void lmpc_solve
 #pragma unroll
         for (int k = 0; k < 6; ++k) F[k * 6 + k] += 1.0 / ct[CT_E + k];
         spd_inv6(F, Fi);
-        double s11 = av[6];
+        real s11 = av[6];
 #pragma unroll
         for (int r = 0; r < 6; ++r) {
-          double t = 0.0;
+          real t = 0.0;
 #pragma unroll
           for (int c = 0; c < 6; ++c) t += Fi[r * 6 + c] * av[c];
           Fia[r] = t;
           s11 -= av[r] * t;
         }
-        const double is11 = 1.0 / s11;
+        const real is11 = 1.0 / s11;
         if (lane == 0) {
 #pragma unroll
           for (int r = 0; r < 6; ++r) {
@@ -862,7 +903,7 @@ __global__ __launch_bounds__(64, ((KQ <= 4 && KS == 0) ? 2 : 1)) void lmpc_solve
         }
       }
       {
-        double red[2] = {musum, eysum};
+        real red[2] = {musum, eysum};
         wave_sum_n<2>(red);
         musum = red[0];
         hsig = P.qsig + red[1];
@@ -907,39 +948,39 @@ __global__ __launch_bounds__(64, ((KQ <= 4 && KS == 0) ? 2 : 1)) void lmpc_solve
       PT_MARK(3)
     }
 
-    double sigc = 0.0, alpha = 1.0, dsigma = 0.0, dts = 0.0, dlams = 0.0;
-    double d_val[KQ];
+    real sigc = 0.0, alpha = 1.0, dsigma = 0.0, dts = 0.0, dlams = 0.0;
+    real d_val[KQ];
     const int npass = ipm ? 2 : 1;
     for (int pass = 0; pass < npass; ++pass) {
-      const double smu = (pass == 1) ? sigc * mu : 0.0, pm = (pass == 1) ? 1.0 : 0.0;
+      const real smu = (pass == 1) ? sigc * mu : 0.0, pm = (pass == 1) ? 1.0 : 0.0;
       // ======== gradient: cost gradient + row coefficients, written by the component owner ========
-      double sgsum = 0.0;  // sum of boundary-row coefficients entering the sigma gradient
+      real sgsum = 0.0;  // sum of boundary-row coefficients entering the sigma gradient
       if constexpr (KS > 0) {
         if (ipm) {
-          double sbl = 0.0;
-          double bs[7] = {0, 0, 0, 0, 0, 0, 0};
+          real sbl = 0.0;
+          real bs[7] = {0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
           for (int q = 0; q < KS; ++q) {
-            double itf;
-            const double w = sx.on[q] ? simplex_bl(sx.lm[q], sx.t[q], sx.l[q], sx.p[q], sx.j[q], sx.u[q], smu, pm, ct, T, itf) * itf : 0.0;
+            real itf;
+            const real w = sx.on[q] ? simplex_bl(sx.lm[q], sx.t[q], sx.l[q], sx.p[q], sx.j[q], sx.u[q], smu, pm, ct, T, itf) * itf : 0.0;
             bs[6] += w;
 #pragma unroll
             for (int k = 0; k < 6; ++k) bs[k] += sx.u[q][k] * w;
           }
           wave_sum_n<7>(bs);
           sbl = bs[6];
-          double Fib[6], aFib = 0.0;
+          real Fib[6], aFib = 0.0;
 #pragma unroll
           for (int r = 0; r < 6; ++r) {
-            double t = 0.0;
+            real t = 0.0;
 #pragma unroll
             for (int c = 0; c < 6; ++c) t += T[TL_FI + r * 6 + c] * bs[c];
             Fib[r] = t;
             aFib += T[TL_A + r] * t;
           }
-          const double coef = (sbl - aFib + sx.r1) / T[TL_S11];
+          const real coef = (sbl - aFib + sx.r1) / T[TL_S11];
           if (lane < 6) {
-            double tg = 0.0;
+            real tg = 0.0;
 #pragma unroll
             for (int k = 0; k < 6; ++k)
               if (k == lane) tg = ct[CT_E + k] * T[TL_EPS + k] + Fib[k] - T[TL_FIA + k] * coef;
@@ -948,8 +989,8 @@ __global__ __launch_bounds__(64, ((KQ <= 4 && KS == 0) ? 2 : 1)) void lmpc_solve
         }
       }
       {
-        double val[KQ], par[KQ], ca[KQ], cb[KQ], ql[KQ];
-        double2 hl[KQ];
+        real val[KQ], par[KQ], ca[KQ], cb[KQ], ql[KQ];
+        real2 hl[KQ];
 #pragma unroll
         for (int q = 0; q < KQ; ++q) {
           const int gr = s_gf[q];
@@ -963,13 +1004,13 @@ __global__ __launch_bounds__(64, ((KQ <= 4 && KS == 0) ? 2 : 1)) void lmpc_solve
 #pragma unroll
         for (int q = 0; q < KQ; ++q) {
           const int f = flags(q);
-          const double sg = (f & F_SIG) ? sigma : 0.0;
-          const double itu = frcp(s_tu[q]), itl = frcp(s_tl[q]);
-          double cu = s_lu[q] * itu * (val[q] - sg + s_tu[q] - hl[q].x) + (smu - pm * s_pu[q]) * itu;
-          double cd = s_ll[q] * itl * (-val[q] - sg + s_tl[q] + hl[q].y) + (smu - pm * s_pl[q]) * itl;
+          const real sg = (f & F_SIG) ? sigma : 0.0;
+          const real itu = frcp(s_tu[q]), itl = frcp(s_tl[q]);
+          real cu = s_lu[q] * itu * (val[q] - sg + s_tu[q] - hl[q].x) + (smu - pm * s_pu[q]) * itu;
+          real cd = s_ll[q] * itl * (-val[q] - sg + s_tl[q] + hl[q].y) + (smu - pm * s_pl[q]) * itl;
           cu = (ipm && (f & F_UP)) ? cu : 0.0;
           cd = (ipm && (f & F_LO)) ? cd : 0.0;
-          const double g = ca[q] * val[q] + cb[q] * par[q] + ((f & F_QLIN) ? ql[q] : 0.0);  // (zero coefficients on a boundary slot)
+          const real g = ca[q] * val[q] + cb[q] * par[q] + ((f & F_QLIN) ? ql[q] : 0.0);  // (zero coefficients on a boundary slot)
           lds[o_w(q)] = g + cu - cd;
           if (pass == 0) lds[(f & F_EY) ? JB + KN_EY : o_w(q) + 10] = 0.0;
           sgsum += (f & F_SIG) ? (cu + cd) : 0.0;
@@ -978,7 +1019,7 @@ __global__ __launch_bounds__(64, ((KQ <= 4 && KS == 0) ? 2 : 1)) void lmpc_solve
       wave_sync();
       PT_MARK(12)
       for (int i = lane; i < N; i += 64) {
-        double* kn = L.kn(i);
+        real* kn = L.kn(i);
         kn[KN_R0 + 1] += kn[KN_EY];
         if (pass == 0) kn[KN_R1 + 1] = (i >= 1) ? kn[KN_CSIG] : 0.0;
       }
@@ -995,8 +1036,8 @@ __global__ __launch_bounds__(64, ((KQ <= 4 && KS == 0) ? 2 : 1)) void lmpc_solve
         riccati_solve<1>(L, lane, pf);
       PT_MARK(5)
       // ======== step of every constrained value; boundary slack by Schur complement ========
-      double dz0[KQ], dz1[KQ], val[KQ];
-      double2 hl[KQ];
+      real dz0[KQ], dz1[KQ], val[KQ];
+      real2 hl[KQ];
 #pragma unroll
       for (int q = 0; q < KQ; ++q) {
         dz0[q] = lds[o_val[q] + 10];
@@ -1009,11 +1050,11 @@ __global__ __launch_bounds__(64, ((KQ <= 4 && KS == 0) ? 2 : 1)) void lmpc_solve
         for (int q = 0; q < KQ; ++q) d_val[q] = dz0[q];
         break;
       }
-      double cfs = 0.0;
+      real cfs = 0.0;
       if (has_sigma) {
-        double red[3] = {0.0, 0.0, sgsum};  // c'dz (this rhs), c'e (Schur vector), sum of boundary coefficients
+        real red[3] = {0.0, 0.0, sgsum};  // c'dz (this rhs), c'e (Schur vector), sum of boundary coefficients
         {
-          double cs[KQ];
+          real cs[KQ];
 #pragma unroll
           for (int q = 0; q < KQ; ++q) cs[q] = lds[o_csig(q)];
 #pragma unroll
@@ -1025,45 +1066,45 @@ __global__ __launch_bounds__(64, ((KQ <= 4 && KS == 0) ? 2 : 1)) void lmpc_solve
         }
         wave_sum_n<3>(red);
         if (pass == 0) ce = red[1];
-        const double its = frcp(ts);
+        const real its = frcp(ts);
         cfs = lams * its * (-sigma + ts) + (smu - pm * dts * dlams) * its;
-        const double qsg = P.qsig * sigma - red[2] - cfs;
+        const real qsg = P.qsig * sigma - red[2] - cfs;
         dsigma = uni(-(qsg + red[0]) / (hsig + ce));
       }
       if constexpr (KS > 0) {
         // d lambda_j = (r_j - u_j'F^-1 gamma)/theta_j - Mi1_j (sr - a'F^-1 gamma - sx.r1)/s11,  r_j = u_j'E dx_T - bl_j
-        const double* knT = L.kn(N - 1);
-        double e[6], gs[7] = {0, 0, 0, 0, 0, 0, 0}, rj[KS], itfq[KS];
+        const real* knT = L.kn(N - 1);
+        real e[6], gs[7] = {0, 0, 0, 0, 0, 0, 0}, rj[KS], itfq[KS];
 #pragma unroll
         for (int k = 0; k < 6; ++k) e[k] = ct[CT_E + k] * (knT[KN_R0 + k] + dsigma * knT[KN_R1 + k]);
 #pragma unroll
         for (int q = 0; q < KS; ++q) {
-          double itf;
-          double r = -simplex_bl(sx.lm[q], sx.t[q], sx.l[q], sx.p[q], sx.j[q], sx.u[q], smu, pm, ct, T, itf);
+          real itf;
+          real r = -simplex_bl(sx.lm[q], sx.t[q], sx.l[q], sx.p[q], sx.j[q], sx.u[q], smu, pm, ct, T, itf);
 #pragma unroll
           for (int k = 0; k < 6; ++k) r += sx.u[q][k] * e[k];
           r = sx.on[q] ? r : 0.0;
           rj[q] = r;
           itfq[q] = itf;
-          const double w = r * itf;
+          const real w = r * itf;
           gs[6] += w;
 #pragma unroll
           for (int k = 0; k < 6; ++k) gs[k] += sx.u[q][k] * w;
         }
         wave_sum_n<7>(gs);
-        double Fig[6], aFig = 0.0;
+        real Fig[6], aFig = 0.0;
 #pragma unroll
         for (int r = 0; r < 6; ++r) {
-          double t = 0.0;
+          real t = 0.0;
 #pragma unroll
           for (int c = 0; c < 6; ++c) t += T[TL_FI + r * 6 + c] * gs[c];
           Fig[r] = t;
           aFig += T[TL_A + r] * t;
         }
-        const double coef = (gs[6] - aFig - sx.r1) / T[TL_S11];
+        const real coef = (gs[6] - aFig - sx.r1) / T[TL_S11];
 #pragma unroll
         for (int q = 0; q < KS; ++q) {
-          double ug = 0.0, ua = 0.0;
+          real ug = 0.0, ua = 0.0;
 #pragma unroll
           for (int k = 0; k < 6; ++k) {
             ug += sx.u[q][k] * Fig[k];
@@ -1073,25 +1114,25 @@ __global__ __launch_bounds__(64, ((KQ <= 4 && KS == 0) ? 2 : 1)) void lmpc_solve
         }
       }
       // ======== row steps; largest feasible step as 1 / max(1, max -dt/t, max -dlam/lam) ========
-      auto row_step = [&](bool on, double t, double lam, double pprod, double rd, double cdy, double& dt_, double& dl_,
-                          double& it_) {
+      auto row_step = [&](bool on, real t, real lam, real pprod, real rd, real cdy, real& dt_, real& dl_,
+                          real& it_) {
         it_ = frcp(t);
         dt_ = on ? (-rd - cdy) : 0.0;
         dl_ = on ? (-lam + (smu - pm * pprod) * it_ - lam * it_ * dt_) : 0.0;
       };
-      double dtu[KQ], dlu[KQ], dtl[KQ], dll[KQ];
-      double rmax = 1.0;
+      real dtu[KQ], dlu[KQ], dtl[KQ], dll[KQ];
+      real rmax = 1.0;
 #pragma unroll
       for (int q = 0; q < KQ; ++q) {
         const int f = flags(q);
-        const double dval = dz0[q] + dsigma * dz1[q];
+        const real dval = dz0[q] + dsigma * dz1[q];
         d_val[q] = dval;
-        const double sg = (f & F_SIG) ? sigma : 0.0, dsg = (f & F_SIG) ? dsigma : 0.0;
-        const double itu = frcp(s_tu[q]), itl = frcp(s_tl[q]);
-        const double a = (f & F_UP) ? -(val[q] - sg + s_tu[q] - hl[q].x) - (dval - dsg) : 0.0;
-        const double bq = (f & F_UP) ? -s_lu[q] + (smu - pm * s_pu[q]) * itu - s_lu[q] * itu * a : 0.0;
-        const double c = (f & F_LO) ? -(-val[q] - sg + s_tl[q] + hl[q].y) - (-dval - dsg) : 0.0;
-        const double d = (f & F_LO) ? -s_ll[q] + (smu - pm * s_pl[q]) * itl - s_ll[q] * itl * c : 0.0;
+        const real sg = (f & F_SIG) ? sigma : 0.0, dsg = (f & F_SIG) ? dsigma : 0.0;
+        const real itu = frcp(s_tu[q]), itl = frcp(s_tl[q]);
+        const real a = (f & F_UP) ? -(val[q] - sg + s_tu[q] - hl[q].x) - (dval - dsg) : 0.0;
+        const real bq = (f & F_UP) ? -s_lu[q] + (smu - pm * s_pu[q]) * itu - s_lu[q] * itu * a : 0.0;
+        const real c = (f & F_LO) ? -(-val[q] - sg + s_tl[q] + hl[q].y) - (-dval - dsg) : 0.0;
+        const real d = (f & F_LO) ? -s_ll[q] + (smu - pm * s_pl[q]) * itl - s_ll[q] * itl * c : 0.0;
         dtu[q] = a;
         dlu[q] = bq;
         dtl[q] = c;
@@ -1102,21 +1143,21 @@ __global__ __launch_bounds__(64, ((KQ <= 4 && KS == 0) ? 2 : 1)) void lmpc_solve
       if constexpr (KS > 0) {
 #pragma unroll
         for (int q = 0; q < KS; ++q) {
-          double dt_, dl_, it_;
+          real dt_, dl_, it_;
           row_step(sx.on[q], sx.t[q], sx.l[q], sx.p[q], -sx.lm[q] + sx.t[q], -sx.dl[q], dt_, dl_, it_);
           rmax = fmax(rmax, fmax(-dt_ * it_, -dl_ * frcp(fmax(sx.l[q], 1e-300))));
         }
       }
       rmax = wave_max(rmax);
       if (has_sigma) {
-        const double th = lams / ts, rds = -sigma + ts;
+        const real th = lams / ts, rds = -sigma + ts;
         dts = uni(-rds + dsigma);
         dlams = uni(-lams + cfs - th * rds - th * dts);
         rmax = fmax(rmax, fmax(-dts / ts, -dlams / lams));
       }
-      const double amax = uni(1.0 / rmax);
+      const real amax = uni(1.0 / rmax);
       if (pass == 1) alpha = uni(fmin(1.0, tau * amax));
-      double sacc = 0.0;
+      real sacc = 0.0;
 #pragma unroll
       for (int q = 0; q < KQ; ++q) {
         if (pass == 0) {
@@ -1133,7 +1174,7 @@ __global__ __launch_bounds__(64, ((KQ <= 4 && KS == 0) ? 2 : 1)) void lmpc_solve
       if constexpr (KS > 0) {
 #pragma unroll
         for (int q = 0; q < KS; ++q) {
-          double dt_, dl_, it_;
+          real dt_, dl_, it_;
           row_step(sx.on[q], sx.t[q], sx.l[q], sx.p[q], -sx.lm[q] + sx.t[q], -sx.dl[q], dt_, dl_, it_);
           if (pass == 0) {
             sacc += sx.on[q] ? (sx.t[q] + amax * dt_) * (sx.l[q] + amax * dl_) : 0.0;
@@ -1148,7 +1189,7 @@ __global__ __launch_bounds__(64, ((KQ <= 4 && KS == 0) ? 2 : 1)) void lmpc_solve
       if (pass == 0) {
         sacc = wave_sum(sacc);
         if (has_sigma) sacc += (ts + amax * dts) * (lams + amax * dlams);
-        const double ratio = (sacc * inv_m) / mu;
+        const real ratio = (sacc * inv_m) / mu;
         sigc = uni(ratio * ratio * ratio);
         wave_sync();
       }
@@ -1156,11 +1197,11 @@ __global__ __launch_bounds__(64, ((KQ <= 4 && KS == 0) ? 2 : 1)) void lmpc_solve
 
     // ======== primal update by the component owners ========
     PT_MARK(6)
-    double stepmax = 0.0;
+    real stepmax = 0.0;
 #pragma unroll
     for (int q = 0; q < KQ; ++q) {
       const bool mv = (flags(q) & F_MOVE) != 0;
-      const double dz = mv ? alpha * d_val[q] : 0.0;
+      const real dz = mv ? alpha * d_val[q] : 0.0;
       lds[mv ? o_val[q] : JB + q] += dz;
       stepmax = fmax(stepmax, fabs(dz));
     }
@@ -1174,8 +1215,8 @@ __global__ __launch_bounds__(64, ((KQ <= 4 && KS == 0) ? 2 : 1)) void lmpc_solve
       }
     } else {
       // ---- slacks and multipliers at the start point: t = max(slack, 0.5 range), lam = mu0 / t ----
-      double val[KQ];
-      double2 hl[KQ];
+      real val[KQ];
+      real2 hl[KQ];
 #pragma unroll
       for (int q = 0; q < KQ; ++q) {
         val[q] = lds[o_val[q]];
@@ -1183,9 +1224,9 @@ __global__ __launch_bounds__(64, ((KQ <= 4 && KS == 0) ? 2 : 1)) void lmpc_solve
       }
 #pragma unroll
       for (int q = 0; q < KQ; ++q) {
-        double range = ((flags(q) & (F_UP | F_LO)) == (F_UP | F_LO)) ? (hl[q].x - hl[q].y) : 1.0;
+        real range = ((flags(q) & (F_UP | F_LO)) == (F_UP | F_LO)) ? (hl[q].x - hl[q].y) : 1.0;
         if (!(range > 1e-3)) range = 1e-3;
-        const double thr = thr_frac * range;
+        const real thr = thr_frac * range;
         if (flags(q) & F_UP) {
           s_tu[q] = fmax(hl[q].x - val[q], thr);
           s_lu[q] = mu0 / s_tu[q];
@@ -1231,14 +1272,14 @@ __global__ __launch_bounds__(64, ((KQ <= 4 && KS == 0) ? 2 : 1)) void lmpc_solve
     iters_out[b] = it;
 #ifdef LMPC_PHASE_TIMING
     if (kkt_out) {
-      for (int k = 0; k < 16; ++k) kkt_out[k * (size_t)B + b] = (double)pf.acc[k];
-      kkt_out[16 * (size_t)B + b] = (double)pf.w0;               // 100 MHz wall clock at start
-      kkt_out[17 * (size_t)B + b] = (double)wall_clock64();      // ... at end
+      for (int k = 0; k < 16; ++k) kkt_out[k * (size_t)B + b] = (real)pf.acc[k];
+      kkt_out[16 * (size_t)B + b] = (real)pf.w0;               // 100 MHz wall clock at start
+      kkt_out[17 * (size_t)B + b] = (real)wall_clock64();      // ... at end
       unsigned hwid, xcc;
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-      kkt_out[18 * (size_t)B + b] = (double)hwid;
-      kkt_out[19 * (size_t)B + b] = (double)(xcc & 0xf);
+      kkt_out[18 * (size_t)B + b] = (real)hwid;
+      kkt_out[19 * (size_t)B + b] = (real)(xcc & 0xf);
     }
 #else
     if (kkt_out) {
@@ -1251,21 +1292,21 @@ __global__ __launch_bounds__(64, ((KQ <= 4 && KS == 0) ? 2 : 1)) void lmpc_solve
   }
 }
 
-template __global__ void lmpc_solve_kernel<2, 0>(lmpc_params, int, const double*, const double*, const double*, const double*, const double*, const double*,
+template __global__ void lmpc_solve_kernel<double, 2, 0>(lmpc_params, int, const double*, const double*, const double*, const double*, const double*, const double*,
     const double*, const double*, const double*, double*, double*, double*, double*, int*, int*, double*);
-template __global__ void lmpc_solve_kernel<4, 0>(lmpc_params, int, const double*, const double*, const double*, const double*, const double*, const double*,
+template __global__ void lmpc_solve_kernel<double, 4, 0>(lmpc_params, int, const double*, const double*, const double*, const double*, const double*, const double*,
     const double*, const double*, const double*, double*, double*, double*, double*, int*, int*, double*);
-template __global__ void lmpc_solve_kernel<7, 0>(lmpc_params, int, const double*, const double*, const double*, const double*, const double*, const double*,
+template __global__ void lmpc_solve_kernel<double, 7, 0>(lmpc_params, int, const double*, const double*, const double*, const double*, const double*, const double*,
     const double*, const double*, const double*, double*, double*, double*, double*, int*, int*, double*);
-template __global__ void lmpc_solve_kernel<11, 0>(lmpc_params, int, const double*, const double*, const double*, const double*, const double*, const double*,
+template __global__ void lmpc_solve_kernel<double, 11, 0>(lmpc_params, int, const double*, const double*, const double*, const double*, const double*, const double*,
     const double*, const double*, const double*, double*, double*, double*, double*, int*, int*, double*);
-template __global__ void lmpc_solve_kernel<14, 0>(lmpc_params, int, const double*, const double*, const double*, const double*, const double*, const double*,
+template __global__ void lmpc_solve_kernel<double, 14, 0>(lmpc_params, int, const double*, const double*, const double*, const double*, const double*, const double*,
     const double*, const double*, const double*, double*, double*, double*, double*, int*, int*, double*);
-template __global__ void lmpc_solve_kernel<4, 2>(lmpc_params, int, const double*, const double*, const double*, const double*, const double*, const double*,
+template __global__ void lmpc_solve_kernel<double, 4, 2>(lmpc_params, int, const double*, const double*, const double*, const double*, const double*, const double*,
     const double*, const double*, const double*, double*, double*, double*, double*, int*, int*, double*);
-template __global__ void lmpc_solve_kernel<4, 3>(lmpc_params, int, const double*, const double*, const double*, const double*, const double*, const double*,
+template __global__ void lmpc_solve_kernel<double, 4, 3>(lmpc_params, int, const double*, const double*, const double*, const double*, const double*, const double*,
     const double*, const double*, const double*, double*, double*, double*, double*, int*, int*, double*);
-template __global__ void lmpc_solve_kernel<7, 2>(lmpc_params, int, const double*, const double*, const double*, const double*, const double*, const double*,
+template __global__ void lmpc_solve_kernel<double, 7, 2>(lmpc_params, int, const double*, const double*, const double*, const double*, const double*, const double*,
     const double*, const double*, const double*, double*, double*, double*, double*, int*, int*, double*);
-template __global__ void lmpc_solve_kernel<7, 3>(lmpc_params, int, const double*, const double*, const double*, const double*, const double*, const double*,
+template __global__ void lmpc_solve_kernel<double, 7, 3>(lmpc_params, int, const double*, const double*, const double*, const double*, const double*, const double*,
     const double*, const double*, const double*, double*, double*, double*, double*, int*, int*, double*);
