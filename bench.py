@@ -130,6 +130,8 @@ def main():
     ap.add_argument("--workload", choices=["tracking", "lmpc", "iac"], default="tracking",
                     help="tracking = BASELINE configs[1] (the quoted metric); lmpc = configs[2] (5-lap safe set); "
                          "iac = configs[3]'s problem (IAC/Putnam tracking, use --horizon 40 --batch 8192) in fp64")
+    ap.add_argument("--precision", choices=["f64", "f32"], default="f64",
+                    help="f32: lmpc_solve_batch_f32 (BASELINE configs[3] as quoted: --workload iac --horizon 40 --batch 8192 --precision f32)")
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL result gather for N > 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-batch1", action="store_true", help="skip the single-car latency probe (profiling runs: keeps every "
@@ -151,6 +153,7 @@ def main():
     dev = torch.device("cuda", local)
 
     pkg = load_package()
+    f32 = args.precision == "f32"
     N, B = args.horizon, args.batch
     lmpc = args.workload == "lmpc"
     iac = args.workload == "iac"
@@ -185,12 +188,20 @@ def main():
     gather = world > 1 and not args.no_gather
     if gather:
         import torch.distributed as dist
-        flat = [torch.empty(packed_numel(N, B), dtype=torch.float64, device=dev) for _ in range(2)]
-        gbuf = [torch.empty(world * flat[0].numel(), dtype=torch.float64, device=dev) for _ in range(2)]
+        gdt = torch.float32 if f32 else torch.float64
+        flat = [torch.empty(packed_numel(N, B), dtype=gdt, device=dev) for _ in range(2)]
+        gbuf = [torch.empty(world * flat[0].numel(), dtype=gdt, device=dev) for _ in range(2)]
+
+    if f32:
+        assert not lmpc, "single precision is built for the tracking problem"
+        inp32 = {k: (v.to(torch.float32).contiguous() if hasattr(v, "to") else v) for k, v in inp.items()}
+        outs = [solver.solve_f32(inp32), solver.solve_f32(inp32)]
 
     def solve_step(k):
         o = outs[k & 1]
-        if lmpc:
+        if f32:
+            solver.solve_f32(inp32, o)
+        elif lmpc:
             ss_x, ss_j, _ = solver.ss_query(query)
             solver.solve(inp, o, ss_x=ss_x, ss_j=ss_j)
         else:
@@ -252,11 +263,11 @@ def main():
         lat1 = []
         if not lmpc and not args.no_batch1:
             inp1 = {k: (v[..., :1].contiguous() if hasattr(v, "dim") and v.dim() >= 1 else v) for k, v in inp.items()}
-            out1 = solver.alloc_outputs(1)
+            out1 = solver.solve_f32(inp1) if f32 else solver.alloc_outputs(1)
             for k in range(250):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                solver.solve(inp1, out1)
+                (solver.solve_f32 if f32 else solver.solve)(inp1, out1)
                 e1.record()
                 e1.synchronize()
                 if k >= 50:
@@ -269,7 +280,7 @@ def main():
     if rank == 0:
         value = world * B * args.steps / elapsed
         sol_avg = float(np.mean(sol_ms))
-        algo_bytes = ((13 * N + 5) + (10 * N - 4)) * 8 + 8
+        algo_bytes = ((13 * N + 5) + (10 * N - 4)) * (4 if f32 else 8) + 8
         if lmpc:
             algo_bytes += (7 + 1) * 160 * 8  # + ss_x, ss_j in and lambda out (13 936 B at S = 160)
         achieved = algo_bytes * B / (sol_avg * 1e-3) / 1e9
@@ -277,10 +288,11 @@ def main():
             "metric": "QP solves/sec (nx=6,nu=2,N=%d)" % N, "value": value, "unit": "solves/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32" if f32 else "f64", "data": "synthetic",
             "config": {"workload": ("BARC LMPC with 5-lap safe set (160 points), batch=%d per GPU, N=%d, fp64: safe-set kNN kernel + "
                                     "QP kernel per step (BASELINE configs[2])" if lmpc else
-                                    "IAC Putnam tracking MPC, batch=%d per GPU, N=%d, fp64 (problem of BASELINE configs[3]; fp32 not built)" if iac else
+                                    ("IAC Putnam tracking MPC, batch=%d per GPU, N=%d, fp32 (BASELINE configs[3])" if f32 else
+                                     "IAC Putnam tracking MPC, batch=%d per GPU, N=%d, fp64 (problem of BASELINE configs[3])") if iac else
                                     "BARC tracking MPC, batch=%d random x0 per GPU, N=%d, fp64 (BASELINE configs[1])") % (B, N),
                        "batch_per_gpu": B, "horizon": N, "result_gather": "rccl all_gather (async)" if gather else "none"},
             "p50_solve_ms": float(np.percentile(lat, 50)), "p99_solve_ms": float(np.percentile(lat, 99)),
@@ -288,7 +300,8 @@ def main():
             "batch1_solve_ms": {"p50": float(np.percentile(lat1, 50)), "p99": float(np.percentile(lat1, 99)), "control_period_ms": 25.0} if lat1 else None,
             "solved_fraction": float((st == 0).mean()), "mean_ipm_iters": float(iters.mean()),
             "kernels_ms": {"linearize": float(np.mean(lin_ms)), "qp_solve": sol_avg},
-            "launch": solver.launch_info(),
+            "launch": ({**solver.launch_info(), "lds_bytes_per_problem": solver.launch_info()["lds_bytes_per_problem"] // 2,
+                        "resident_problems_per_cu": None, "note": "fp32 records are half the fp64 size"} if f32 else solver.launch_info()),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None if (lmpc or N != 20 or B != 4096) else measured_traffic_bytes(),

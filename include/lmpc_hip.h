@@ -157,6 +157,16 @@ int lmpc_solve_batch(lmpc_handle* h, int32_t batch, const double* x_ic, const do
                      const double* ss_j, double* X_optm, double* U_optm, double* dU_optm,
                      double* convex_combi_optm, int32_t* status, int32_t* iters, double* kkt);
 
+/* Single precision (BASELINE configs[3]: "IAC Putnam tracking MPC, N=40, ..., fp32"): the tracking problem with every
+ * array in float and the interior point / Riccati recursion in fp32 (the linearisation is evaluated in fp64 and
+ * rounded).  Same layouts and meaning as lmpc_solve_batch, no safe-set arguments; kkt [4][B] optional.  The abscissa
+ * is carried relative to x_ic[0] inside the kernel (the QP is invariant to that shift), so a 2.8 km lap keeps its
+ * resolution.  Stopping rule: complementarity <= max(tol, 2e-6), row residuals <= 1e-4.  N <= 40. */
+int lmpc_solve_batch_f32(lmpc_handle* h, int32_t batch, const float* x_ic, const float* u_ic, const float* X_ref,
+                         const float* U_ref, const float* T_ref, const float* bound_left, const float* bound_right,
+                         const float* curvatures, const float* vel_ref, float* X_optm, float* U_optm, float* dU_optm,
+                         int32_t* status, int32_t* iters, float* kkt);
+
 /* RacingMPC::solve for ONE problem with HOST pointers in the reference's own (CasADi DM,
  * column-major) layout: X_ref is 6 x N with a knot's state contiguous, U_ref 2 x (N-1), the
  * per-knot rows are plain arrays.  Stages the data through buffers owned by the handle, runs

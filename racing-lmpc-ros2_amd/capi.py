@@ -19,7 +19,7 @@ _ABI_SYMBOLS = ("lmpc_create", "lmpc_destroy", "lmpc_last_error", "lmpc_set_stre
                 "lmpc_linearize_batch", "lmpc_solve_batch", "lmpc_set_safe_set", "lmpc_ss_query_batch",
                 "lmpc_prepare_batch", "lmpc_reserve", "lmpc_query_launch", "lmpc_enable_timing",
                 "lmpc_last_kernel_ms", "lmpc_query_residency", "lmpc_solve_host", "lmpc_shift_batch",
-                "lmpc_plant_step_batch", "lmpc_set_regression_laps", "lmpc_regress_batch", "lmpc_ss_query_host")
+                "lmpc_plant_step_batch", "lmpc_set_regression_laps", "lmpc_regress_batch", "lmpc_ss_query_host", "lmpc_solve_batch_f32")
 
 
 class LmpcError(RuntimeError):
@@ -284,6 +284,27 @@ class Solver:
                                        _ptr(out["dU_optm"]), _ptr(out.get("convex_combi_optm")),
                                        _ptr(out["status"]), _ptr(out["iters"]), _ptr(out.get("kkt")))
         self._check(rc, "lmpc_solve_batch")
+        out["_inputs_keepalive"] = a
+        return out
+
+    # ---- single precision (BASELINE configs[3]) ----
+    def solve_f32(self, inp: dict, out: dict | None = None):
+        """lmpc_solve_batch_f32: every array in float32 (inputs are converted if they are not), tracking problem only."""
+        torch = self._torch
+        self.use_current_stream()
+        keys = ("x_ic", "u_ic", "X_ref", "U_ref", "T_ref", "bound_left", "bound_right", "curvatures", "vel_ref")
+        a = [torch.as_tensor(inp[k], device=self.device).to(torch.float32).contiguous() for k in keys]
+        B, N = a[0].shape[1], self.N
+        if out is None:
+            kw = dict(dtype=torch.float32, device=self.device)
+            out = {"X_optm": torch.empty((6, N, B), **kw), "U_optm": torch.empty((2, N - 1, B), **kw),
+                   "dU_optm": torch.empty((2, N - 1, B), **kw), "kkt": torch.empty((4, B), **kw),
+                   "status": torch.empty((B,), dtype=torch.int32, device=self.device),
+                   "iters": torch.empty((B,), dtype=torch.int32, device=self.device)}
+        rc = self.lib.lmpc_solve_batch_f32(self._h, C.c_int32(B), *[_ptr(t) for t in a], _ptr(out["X_optm"]),
+                                           _ptr(out["U_optm"]), _ptr(out["dU_optm"]), _ptr(out["status"]),
+                                           _ptr(out["iters"]), _ptr(out.get("kkt")))
+        self._check(rc, "lmpc_solve_batch_f32")
         out["_inputs_keepalive"] = a
         return out
 

@@ -15,9 +15,8 @@
 
 #include "lmpc_device.h"
 
-template <bool WS_LAYOUT>
-__global__ void lmpc_linearize_kernel(lmpc_params, int, const double*, const double*, const double*, const double*,
-                                      double*, double*, double*);
+template <bool WS_LAYOUT, typename io>
+__global__ void lmpc_linearize_kernel(lmpc_params, int, const io*, const io*, const io*, const io*, io*, io*, io*);
 __global__ void lmpc_prepare_kernel(lmpc_params, int, lmpc_track, const double*, double, double, double, double*,
                                     double*, double*, double*, double*, double*, double*);
 __global__ void lmpc_shift_kernel(lmpc_params, int, lmpc_track, const double*, const double*, const double*,
@@ -43,6 +42,8 @@ struct lmpc_handle {
   hipStream_t stream = nullptr;  // nullptr = the device's default (null) stream
   double* ws = nullptr;  // [cap][N-1][LMPC_LIN_RECORD]
   size_t ws_cap = 0;
+  float* ws_f32 = nullptr;  // the same for the single-precision solve
+  size_t ws_f32_cap = 0;
   // safe set (device): laps newest-first offsets
   int ss_laps = 0;
   int ss_total = 0;
@@ -232,6 +233,7 @@ void lmpc_destroy(lmpc_handle* h) {
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
   if (h->ws) (void)hipFree(h->ws);
+  if (h->ws_f32) (void)hipFree(h->ws_f32);
   if (h->ss_npts) (void)hipFree(h->ss_npts);
   if (h->ss_off) (void)hipFree(h->ss_off);
   if (h->ss_x) (void)hipFree(h->ss_x);
@@ -320,7 +322,7 @@ int lmpc_linearize_batch(lmpc_handle* h, int32_t batch, const double* X_ref, con
   if (batch == 0) return LMPC_OK;
   HIP_TRY(h, hipSetDevice(h->device));
   dim3 grid((batch + 255) / 256, h->P.N - 1);
-  hipLaunchKernelGGL(lmpc_linearize_kernel<false>, grid, dim3(256), 0, h->stream, h->P, batch, X_ref, U_ref, T_ref,
+  hipLaunchKernelGGL((lmpc_linearize_kernel<false, double>), grid, dim3(256), 0, h->stream, h->P, batch, X_ref, U_ref, T_ref,
                      curvatures, A, Bm, g);
   HIP_TRY(h, hipGetLastError());
   return LMPC_OK;
@@ -346,7 +348,7 @@ int lmpc_solve_batch(lmpc_handle* h, int32_t batch, const double* x_ic, const do
   const int N = h->P.N;
   if (h->timing) HIP_TRY(h, hipEventRecord(h->ev[0], h->stream));
   dim3 grid((batch + 255) / 256, N - 1);
-  hipLaunchKernelGGL(lmpc_linearize_kernel<true>, grid, dim3(256), 0, h->stream, h->P, batch, X_ref, U_ref, T_ref,
+  hipLaunchKernelGGL((lmpc_linearize_kernel<true, double>), grid, dim3(256), 0, h->stream, h->P, batch, X_ref, U_ref, T_ref,
                      curvatures, h->ws, (double*)nullptr, (double*)nullptr);
   HIP_TRY(h, hipGetLastError());
   if (h->reg_on) {  // error-dynamics regression onto the workspace (safe_set.cpp:182-245)
@@ -365,6 +367,50 @@ int lmpc_solve_batch(lmpc_handle* h, int32_t batch, const double* x_ic, const do
   a.X = X_optm; a.U = U_optm; a.dU = dU_optm; a.status = status; a.iters = iters; a.kkt = kkt;
   const int rc = launch_solve(h, fn, a);
   if (rc != LMPC_OK) return rc;
+  if (h->timing) HIP_TRY(h, hipEventRecord(h->ev[2], h->stream));
+  return LMPC_OK;
+}
+
+int lmpc_solve_batch_f32(lmpc_handle* h, int32_t batch, const float* x_ic, const float* u_ic, const float* X_ref,
+                         const float* U_ref, const float* T_ref, const float* bound_left, const float* bound_right,
+                         const float* curvatures, const float* vel_ref, float* X_optm, float* U_optm, float* dU_optm,
+                         int32_t* status, int32_t* iters, float* kkt) {
+  if (!h) return LMPC_ERR_ARGUMENT;
+  if (batch < 0 || !x_ic || !u_ic || !X_ref || !U_ref || !T_ref || !bound_left || !bound_right || !curvatures ||
+      !vel_ref || !X_optm || !U_optm || !dU_optm || !status || !iters)
+    return fail(h, LMPC_ERR_ARGUMENT, "lmpc_solve_batch_f32: null pointer or negative batch");
+  if (h->P.learning) return fail(h, LMPC_ERR_UNSUPPORTED, "single precision is built for the tracking problem only");
+  if (batch == 0) return LMPC_OK;
+  HIP_TRY(h, hipSetDevice(h->device));
+  const int N = h->P.N;
+  const int kq = kq_for(N);
+  const void* fn = kq == 2 || kq == 4 ? reinterpret_cast<const void*>(&lmpc_solve_kernel<float, 4, 0>)
+                   : kq == 7          ? reinterpret_cast<const void*>(&lmpc_solve_kernel<float, 7, 0>)
+                                      : nullptr;
+  if (!fn) return fail(h, LMPC_ERR_UNSUPPORTED, "single precision is built for N <= 40");
+  if ((size_t)batch > h->ws_f32_cap) {
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (h->ws_f32) HIP_TRY(h, hipFree(h->ws_f32));
+    h->ws_f32 = nullptr;
+    h->ws_f32_cap = 0;
+    HIP_TRY(h, hipMalloc(&h->ws_f32, (size_t)batch * (N - 1) * LMPC_LIN_RECORD * sizeof(float)));
+    h->ws_f32_cap = (size_t)batch;
+  }
+  if (h->timing) HIP_TRY(h, hipEventRecord(h->ev[0], h->stream));
+  dim3 grid((batch + 255) / 256, N - 1);
+  hipLaunchKernelGGL((lmpc_linearize_kernel<true, float>), grid, dim3(256), 0, h->stream, h->P, batch, X_ref, U_ref, T_ref,
+                     curvatures, h->ws_f32, (float*)nullptr, (float*)nullptr);
+  HIP_TRY(h, hipGetLastError());
+  if (h->timing) HIP_TRY(h, hipEventRecord(h->ev[1], h->stream));
+  const size_t lds = (size_t)lmpc_lds_doubles(N, 0) * sizeof(float);
+  HIP_TRY(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  lmpc_params P = h->P;
+  int B = batch;
+  const float *ws = h->ws_f32, *nul = nullptr;
+  float* nulo = nullptr;
+  void* args[] = {&P, &B, &ws, &x_ic, &u_ic, &T_ref, &bound_left, &bound_right, &vel_ref, &nul, &nul, &nulo,
+                  &X_optm, &U_optm, &dU_optm, &status, &iters, &kkt};
+  HIP_TRY(h, hipLaunchKernel(fn, dim3(batch), dim3(64), args, lds, h->stream));
   if (h->timing) HIP_TRY(h, hipEventRecord(h->ev[2], h->stream));
   return LMPC_OK;
 }

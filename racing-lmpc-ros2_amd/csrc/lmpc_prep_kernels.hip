@@ -18,12 +18,12 @@
 // WS_LAYOUT = true : workspace for the solve kernel, record per (b, i): ABt[8][6] | g[6]
 //                    (ABt[c][k] = [A B][k][c], i.e. columns contiguous)
 // WS_LAYOUT = false: C-ABI arrays A [6][6][N-1][B], Bm [6][2][N-1][B], g [6][N-1][B]
-template <bool WS_LAYOUT>
-__global__ __launch_bounds__(256) void lmpc_linearize_kernel(lmpc_params P, int B, const double* __restrict__ X_ref,
-                                                             const double* __restrict__ U_ref,
-                                                             const double* __restrict__ T_ref,
-                                                             const double* __restrict__ curv, double* __restrict__ outA,
-                                                             double* __restrict__ outB, double* __restrict__ outg) {
+// io = element type of the arrays (double, or float for the single-precision solve); the arithmetic is fp64.
+template <bool WS_LAYOUT, typename io>
+__global__ __launch_bounds__(256) void lmpc_linearize_kernel(lmpc_params P, int B, const io* __restrict__ X_ref,
+                                                             const io* __restrict__ U_ref, const io* __restrict__ T_ref,
+                                                             const io* __restrict__ curv, io* __restrict__ outA,
+                                                             io* __restrict__ outB, io* __restrict__ outg) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   const int i = blockIdx.y;
   const int N = P.N, NS = N - 1;
@@ -79,26 +79,28 @@ __global__ __launch_bounds__(256) void lmpc_linearize_kernel(lmpc_params P, int 
       const double d = e[r] + dt / 6 * acc[r];  // [A B][r][c]
       gacc[r] -= d * xu;
       if (WS_LAYOUT)
-        outA[((size_t)b * NS + i) * LMPC_LIN_RECORD + c * 6 + r] = d;
+        outA[((size_t)b * NS + i) * LMPC_LIN_RECORD + c * 6 + r] = (io)d;
       else if (c < 6)
-        outA[((size_t)(r * 6 + c) * NS + i) * B + b] = d;
+        outA[((size_t)(r * 6 + c) * NS + i) * B + b] = (io)d;
       else
-        outB[((size_t)(r * 2 + (c - 6)) * NS + i) * B + b] = d;
+        outB[((size_t)(r * 2 + (c - 6)) * NS + i) * B + b] = (io)d;
     }
   }
 #pragma unroll
   for (int r = 0; r < 6; ++r) {
     if (WS_LAYOUT)
-      outA[((size_t)b * NS + i) * LMPC_LIN_RECORD + 48 + r] = gacc[r];
+      outA[((size_t)b * NS + i) * LMPC_LIN_RECORD + 48 + r] = (io)gacc[r];
     else
-      outg[((size_t)r * NS + i) * B + b] = gacc[r];
+      outg[((size_t)r * NS + i) * B + b] = (io)gacc[r];
   }
 }
 
-template __global__ void lmpc_linearize_kernel<true>(lmpc_params, int, const double*, const double*, const double*,
-                                                     const double*, double*, double*, double*);
-template __global__ void lmpc_linearize_kernel<false>(lmpc_params, int, const double*, const double*, const double*,
-                                                      const double*, double*, double*, double*);
+template __global__ void lmpc_linearize_kernel<true, double>(lmpc_params, int, const double*, const double*, const double*,
+                                                             const double*, double*, double*, double*);
+template __global__ void lmpc_linearize_kernel<true, float>(lmpc_params, int, const float*, const float*, const float*, const float*,
+                                                            float*, float*, float*);
+template __global__ void lmpc_linearize_kernel<false, double>(lmpc_params, int, const double*, const double*, const double*,
+                                                              const double*, double*, double*, double*);
 
 // periodic linear interpolation on a uniform table of M samples over [0, L)
 __device__ __forceinline__ double track_lookup(const double* __restrict__ tab, int M, double L, double s) {

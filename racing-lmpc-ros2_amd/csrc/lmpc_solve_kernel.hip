@@ -218,6 +218,9 @@ __device__ __forceinline__ float frcp(float x) {
   return __builtin_fmaf(__builtin_fmaf(-x, r, 1.0f), r, r);
 }
 
+__device__ __forceinline__ double rfma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ float rfma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
 // Per-precision constants of the iteration.  fp32: the complementarity floor of a single-precision Riccati
 // recursion is ~1e-6 (weights lam/t ~ 1e5 already cancel four digits in P), rows are feasible to ~1e-4.
 template <typename real> struct ipm_limits;
@@ -352,7 +355,7 @@ __device__ void riccati_factor(const Lds<real>& L, int lane, const real* PT) {
   {
     const real* kn = L.kn(N - 1);
     real e = qz_entry(ct, true, r, c);
-    const real th = kn[KN_R0 + r] + (r == 1 ? kn[KN_EY] : 0.0);
+    const real th = kn[KN_R0 + r] + (r == 1 ? kn[KN_EY] : real(0));
     if (diag) e += th;
     if (HAS_PT && r < 6 && c < 6) e += PT[r * 6 + c];  // LMPC: safe-set block condensed onto x_T
     pown = e;
@@ -424,7 +427,7 @@ __device__ void riccati_factor(const Lds<real>& L, int lane, const real* PT) {
     const real k0c = hi00 * g0 + hi01 * g1;
     const real k1c = hi01 * g0 + hi11 * g1;
     real pn = qmid + y - t * (y6r * k0c + y7r * k1c);
-    const real th = thr + (r == 1 ? ey : 0.0);
+    const real th = thr + (r == 1 ? ey : real(0));
     if (diag) pn += th;
     pown = pn;
     MP[r * MROW + c] = pn;  // (not used after stage 0)
@@ -487,7 +490,7 @@ __device__ void riccati_solve(const Lds<real>& L, int lane, Prof& pf) {
     ISSUE_ORDER();
     real w = (r >= 6) ? p : 0.0;  // w = Abar' p: rows 6,7 also take p_u
 #pragma unroll
-    for (int k = 0; k < 6; ++k) w = __builtin_fma(row[k], pb[k], w);
+    for (int k = 0; k < 6; ++k) w = rfma(row[k], pb[k], w);
     AFTER_VALUE(w);
     real w6, w7;
     spread2(w, w6, w7);
@@ -498,8 +501,8 @@ __device__ void riccati_solve(const Lds<real>& L, int lane, Prof& pf) {
       for (int k = 0; k < 6; ++k) row[k] = stn[ST_ROW(r) + k];
     }
     ISSUE_ORDER();
-    const real hv0 = __builtin_fma(t, w6, qv0);
-    const real hv1 = __builtin_fma(t, w7, qv1);
+    const real hv0 = rfma(t, w6, qv0);
+    const real hv1 = rfma(t, w7, qv1);
     p = qz + w - (k0r * hv0 + k1r * hv1);  // (not used after stage 0)
     *pdst = p;
     const real kff = (r == 0) ? hi00 * hv0 + hi01 * hv1 : hi01 * hv0 + hi11 * hv1;
@@ -529,13 +532,13 @@ __device__ void riccati_solve(const Lds<real>& L, int lane, Prof& pf) {
     ISSUE_ORDER();
     real acc = (r >= 6) ? a0 : 0.0;
 #pragma unroll
-    for (int k = 0; k < 6; ++k) acc = __builtin_fma(col[k], dz[k], acc);
+    for (int k = 0; k < 6; ++k) acc = rfma(col[k], dz[k], acc);
     const real ax = acc;  // state rows: A dz_x
-    acc = __builtin_fma(col[6], dz[6], acc);
-    acc = __builtin_fma(col[7], dz[7], acc);
+    acc = rfma(col[6], dz[6], acc);
+    acc = rfma(col[7], dz[7], acc);
     AFTER_VALUE(acc);
     const real dv = -acc;  // lanes 6, 7
-    const real du = __builtin_fma(t, dv, (r == 6) ? dz[6] : dz[7]);
+    const real du = rfma(t, dv, (r == 6) ? dz[6] : dz[7]);
     real du0, du1;
     spread2(du, du0, du1);
     ISSUE_ORDER();
@@ -546,7 +549,7 @@ __device__ void riccati_solve(const Lds<real>& L, int lane, Prof& pf) {
       a0 = stn[ST_KFF(s) + (r & 1)];
     }
     ISSUE_ORDER();
-    const real nx = __builtin_fma(b1, du1, __builtin_fma(b0, du0, ax));
+    const real nx = rfma(b1, du1, rfma(b0, du0, ax));
     const real d = (r < 6) ? nx : du;
     *(own ? kn + LMPC_KNOT_STRIDE + reg + r : junk0) = d;
     *((own && r >= 6) ? kn + reg + 2 + r : junk1) = dv;
@@ -578,14 +581,14 @@ __device__ void feedback_rollout(const Lds<real>& L, int lane) {
     const real g = st[ST_G + (r < 6 ? r : 0)];
     real acc = 0.0;
 #pragma unroll
-    for (int k = 0; k < 6; ++k) acc = __builtin_fma(col[k], dz[k], acc);
+    for (int k = 0; k < 6; ++k) acc = rfma(col[k], dz[k], acc);
     const real ax = acc;
-    acc = __builtin_fma(col[6], dz[6], acc);
-    acc = __builtin_fma(col[7], dz[7], acc);
+    acc = rfma(col[6], dz[6], acc);
+    acc = rfma(col[7], dz[7], acc);
     const real v = -acc;
-    const real u = __builtin_fma(t, v, (r == 6) ? dz[6] : dz[7]);
+    const real u = rfma(t, v, (r == 6) ? dz[6] : dz[7]);
     const real u0 = lane_bcast(u, 6), u1 = lane_bcast(u, 7);
-    const real nx = g + __builtin_fma(col[7], u1, __builtin_fma(col[6], u0, ax));
+    const real nx = g + rfma(col[7], u1, rfma(col[6], u0, ax));
     *(own ? kn + LMPC_KNOT_STRIDE + r : junk0) = (r < 6) ? nx : u;
     *((own && r >= 6) ? kn + 2 + r : junk1) = v;
     wave_sync();
@@ -593,7 +596,7 @@ __device__ void feedback_rollout(const Lds<real>& L, int lane) {
 }
 
 template <typename real, int KQ, int KS>
-__global__ __launch_bounds__(64, ((KQ <= 4 && KS == 0) ? 2 : 1)) void lmpc_solve_kernel(
+__global__ __launch_bounds__(64, ((KS == 0 && (KQ <= 4 || (sizeof(real) == 4 && KQ <= 7))) ? 2 : 1)) void lmpc_solve_kernel(
     lmpc_params P, int B, const real* __restrict__ ws_lin, const real* __restrict__ x_ic,
     const real* __restrict__ u_ic, const real* __restrict__ T_ref, const real* __restrict__ bl,
     const real* __restrict__ br, const real* __restrict__ vref, const real* __restrict__ ss_x,
@@ -606,6 +609,10 @@ __global__ __launch_bounds__(64, ((KQ <= 4 && KS == 0) ? 2 : 1)) void lmpc_solve
   const int lane = threadIdx.x;
   const int N = P.N, NS = N - 1;
   typedef typename vec2<real>::type real2;
+  typedef ipm_limits<real> lim;
+  const real inf = real(INFINITY), marg = real(P.marg), qsig = real(P.qsig), tol = lim::tol(P.tol);
+  // single precision carries the abscissa relative to x_ic[0] (the QP is invariant to the shift: A(:, s) = e_s)
+  const real s_shift = sizeof(real) == 4 ? x_ic[blockIdx.x] : real(0);
   Lds<real> L{lds, N};
   real* T = L.tail();
   real* ct = T + TL_CT;
@@ -623,14 +630,14 @@ __global__ __launch_bounds__(64, ((KQ <= 4 && KS == 0) ? 2 : 1)) void lmpc_solve
     for (int i = lane; i < NS; i += 64) L.st(i)[ST_DT] = T_ref[(size_t)i * B + b];
     for (int i = lane; i < N; i += 64) {
       real* kn = L.kn(i);
-      kn[KN_QLIN] = P.learning ? 0.0 : (i == N - 1 ? P.qv_term : P.qv_stage) * vref[(size_t)i * B + b];
+      kn[KN_QLIN] = P.learning ? real(0) : real(i == N - 1 ? P.qv_term : P.qv_stage) * vref[(size_t)i * B + b];
       kn[8] = 0.0;
       kn[9] = 0.0;
-      kn[KN_BHL] = bl[(size_t)i * B + b] - P.marg;
-      kn[KN_BHL + 1] = br[(size_t)i * B + b] + P.marg;
+      kn[KN_BHL] = bl[(size_t)i * B + b] - marg;
+      kn[KN_BHL + 1] = br[(size_t)i * B + b] + marg;
     }
     if (lane < 6) {
-      KN0[lane] = x_ic[(size_t)lane * B + b];
+      KN0[lane] = (lane == 0) ? x_ic[b] - s_shift : x_ic[(size_t)lane * B + b];
       ct[CT_QD + lane] = P.learning ? 0.0 : P.Qd[lane];
       ct[CT_QT + lane] = P.learning ? 0.0 : P.Qt[lane];
       ct[CT_HL + 2 * lane] = P.x_max[lane];
@@ -683,7 +690,7 @@ __global__ __launch_bounds__(64, ((KQ <= 4 && KS == 0) ? 2 : 1)) void lmpc_solve
     const int kb = valid ? KNB + i * LMPC_KNOT_STRIDE : JB;
     o_val[q] = kb + (sl < SL_EY ? sl : 1);
     o_hl[q] = (valid && sl < SL_EY) ? CTB + CT_HL + 2 * sl : kb + KN_BHL;
-    real hi = INFINITY, lo = -INFINITY;
+    real hi = inf, lo = -inf;
     bool on = false;
     int ca = CT_ZERO, cb = CT_ZERO, pd = 0;
     if (valid) {
@@ -704,12 +711,12 @@ __global__ __launch_bounds__(64, ((KQ <= 4 && KS == 0) ? 2 : 1)) void lmpc_solve
           pd = k == 0 ? 1 : -1;
         }
       } else {
-        hi = bl[(size_t)i * B + b] - P.marg;
-        lo = br[(size_t)i * B + b] + P.marg;
+        hi = bl[(size_t)i * B + b] - marg;
+        lo = br[(size_t)i * B + b] + marg;
         on = has_sigma || i >= 1;
       }
     }
-    const bool au = on && (hi < INFINITY), al = on && (lo > -INFINITY);
+    const bool au = on && (hi < inf), al = on && (lo > -inf);
     const bool eys = valid && sl == SL_EY;
     const int fl = (au ? F_UP : 0) | (al ? F_LO : 0) | ((eys && has_sigma) ? F_SIG : 0) | ((valid && sl == 3) ? F_QLIN : 0) |
              ((valid && sl < SL_EY && (i >= 1 || sl >= SL_V)) ? F_MOVE : 0) | (eys ? F_EY : 0) | ((eys && i >= 1) ? F_SCH : 0);
@@ -748,8 +755,8 @@ __global__ __launch_bounds__(64, ((KQ <= 4 && KS == 0) ? 2 : 1)) void lmpc_solve
       m_rows += sx.on[q] ? 1.0 : 0.0;
     }
   }
-  const real m_tot = wave_sum(m_rows) + (has_sigma ? 1.0 : 0.0);
-  const real inv_m = uni(1.0 / m_tot);
+  const real m_tot = wave_sum(m_rows) + (has_sigma ? real(1) : real(0));
+  const real inv_m = uni(real(1) / m_tot);
 
   // knot-0 feasibility: the state box applies to x_0 = x_ic (racing_mpc.cpp:147,201)
   bool feasible = true;
@@ -761,7 +768,7 @@ __global__ __launch_bounds__(64, ((KQ <= 4 && KS == 0) ? 2 : 1)) void lmpc_solve
     }
     if (lane == 6 && !has_sigma) {
       const real ey = KN0[1];
-      ok = (ey <= bl[b] - P.marg) && (ey >= br[b] + P.marg);
+      ok = (ey <= bl[b] - marg) && (ey >= br[b] + marg);
     }
     feasible = wave_min(ok ? 1.0 : 0.0) > 0.5;
   }
@@ -801,7 +808,7 @@ __global__ __launch_bounds__(64, ((KQ <= 4 && KS == 0) ? 2 : 1)) void lmpc_solve
 
   const real tau = 0.995, mu0 = 0.1, thr_frac = 0.5;
   int status = LMPC_SOLVE_MAX_ITER, it = 0;
-  real mu = 0.0, mu_prev = INFINITY, rdmax = 0.0, rd_check = 0.0, last_step = 0.0, hsig = 0.0, ce = 0.0;
+  real mu = 0.0, mu_prev = inf, rdmax = 0.0, rd_check = 0.0, last_step = 0.0, hsig = 0.0, ce = 0.0;
   const int max_iter = feasible ? P.max_iter : 0;
 
   // it == -1 is the start-point Newton step (all row weights zero, full step); it >= 0 the
@@ -825,11 +832,11 @@ __global__ __launch_bounds__(64, ((KQ <= 4 && KS == 0) ? 2 : 1)) void lmpc_solve
           const real sg = (f & F_SIG) ? sigma : 0.0;
           const real thu = s_lu[q] * frcp(s_tu[q]), thd = s_ll[q] * frcp(s_tl[q]);
           musum += s_lu[q] * s_tu[q] + s_ll[q] * s_tl[q];
-          rdl = fmax(rdl, (f & F_UP) ? fabs(val[q] - sg + s_tu[q] - hl[q].x) : 0.0);
-          rdl = fmax(rdl, (f & F_LO) ? fabs(-val[q] - sg + s_tl[q] + hl[q].y) : 0.0);
+          rdl = fmax(rdl, (f & F_UP) ? fabs(val[q] - sg + s_tu[q] - hl[q].x) : real(0));
+          rdl = fmax(rdl, (f & F_LO) ? fabs(-val[q] - sg + s_tl[q] + hl[q].y) : real(0));
           lds[o_w(q)] = thu + thd;
           lds[o_csig(q)] = (f & F_SIG) ? (thd - thu) : 0.0;
-          eysum += (f & F_SIG) ? (thu + thd) : 0.0;
+          eysum += (f & F_SIG) ? (thu + thd) : real(0);
         }
       }
       if constexpr (KS > 0) {
@@ -906,7 +913,7 @@ __global__ __launch_bounds__(64, ((KQ <= 4 && KS == 0) ? 2 : 1)) void lmpc_solve
         real red[2] = {musum, eysum};
         wave_sum_n<2>(red);
         musum = red[0];
-        hsig = P.qsig + red[1];
+        hsig = qsig + red[1];
       }
       rdmax = wave_max(rdl);
       if (has_sigma) {
@@ -919,13 +926,13 @@ __global__ __launch_bounds__(64, ((KQ <= 4 && KS == 0) ? 2 : 1)) void lmpc_solve
         status = LMPC_SOLVE_INFEASIBLE;
         break;
       }
-      if (mu <= P.tol && rdmax <= 1e-9) {
+      if (mu <= tol && rdmax <= lim::rd_ok) {
         status = LMPC_SOLVE_OPTIMAL;
         break;
       }
       // accuracy floor: with the rows feasible, a complementarity that has stopped halving within two decades
       // of the tolerance is as small as the Riccati recursion can make it (weights lam/t ~ 1e12 cancel in P)
-      if (rdmax <= 1e-9 && mu <= 100.0 * P.tol && mu > 0.5 * mu_prev) {
+      if (rdmax <= lim::rd_ok && mu <= real(100) * tol && mu > real(0.5) * mu_prev) {
         status = LMPC_SOLVE_OPTIMAL;
         break;
       }
@@ -935,7 +942,7 @@ __global__ __launch_bounds__(64, ((KQ <= 4 && KS == 0) ? 2 : 1)) void lmpc_solve
       // also bounds the straggler that would otherwise hold its CU slot for max_iter iterations).  "Not halved" is
       // too tight: feasible problems with a slow start (IAC at 60 m/s into a corner) contract by 0.6-0.8 per five.
       if (it % 5 == 0) {
-        if (it >= 10 && rdmax > 1e-6 && rdmax > 0.9 * rd_check) {
+        if (it >= 10 && rdmax > lim::rd_infeasible && rdmax > real(0.9) * rd_check) {
           status = LMPC_SOLVE_INFEASIBLE;
           break;
         }
@@ -1010,10 +1017,10 @@ __global__ __launch_bounds__(64, ((KQ <= 4 && KS == 0) ? 2 : 1)) void lmpc_solve
           real cd = s_ll[q] * itl * (-val[q] - sg + s_tl[q] + hl[q].y) + (smu - pm * s_pl[q]) * itl;
           cu = (ipm && (f & F_UP)) ? cu : 0.0;
           cd = (ipm && (f & F_LO)) ? cd : 0.0;
-          const real g = ca[q] * val[q] + cb[q] * par[q] + ((f & F_QLIN) ? ql[q] : 0.0);  // (zero coefficients on a boundary slot)
+          const real g = ca[q] * val[q] + cb[q] * par[q] + ((f & F_QLIN) ? ql[q] : real(0));  // (zero coefficients on a boundary slot)
           lds[o_w(q)] = g + cu - cd;
           if (pass == 0) lds[(f & F_EY) ? JB + KN_EY : o_w(q) + 10] = 0.0;
-          sgsum += (f & F_SIG) ? (cu + cd) : 0.0;
+          sgsum += (f & F_SIG) ? (cu + cd) : real(0);
         }
       }
       wave_sync();
@@ -1060,15 +1067,15 @@ __global__ __launch_bounds__(64, ((KQ <= 4 && KS == 0) ? 2 : 1)) void lmpc_solve
 #pragma unroll
           for (int q = 0; q < KQ; ++q) {
             const bool sch = (flags(q) & F_SCH) != 0;
-            red[0] += sch ? cs[q] * dz0[q] : 0.0;
-            red[1] += sch ? cs[q] * dz1[q] : 0.0;
+            red[0] += sch ? cs[q] * dz0[q] : real(0);
+            red[1] += sch ? cs[q] * dz1[q] : real(0);
           }
         }
         wave_sum_n<3>(red);
         if (pass == 0) ce = red[1];
         const real its = frcp(ts);
         cfs = lams * its * (-sigma + ts) + (smu - pm * dts * dlams) * its;
-        const real qsg = P.qsig * sigma - red[2] - cfs;
+        const real qsg = qsig * sigma - red[2] - cfs;
         dsigma = uni(-(qsg + red[0]) / (hsig + ce));
       }
       if constexpr (KS > 0) {
@@ -1137,8 +1144,8 @@ __global__ __launch_bounds__(64, ((KQ <= 4 && KS == 0) ? 2 : 1)) void lmpc_solve
         dlu[q] = bq;
         dtl[q] = c;
         dll[q] = d;
-        rmax = fmax(rmax, fmax(-a * itu, -bq * frcp(fmax(s_lu[q], 1e-300))));
-        rmax = fmax(rmax, fmax(-c * itl, -d * frcp(fmax(s_ll[q], 1e-300))));
+        rmax = fmax(rmax, fmax(-a * itu, -bq * frcp(fmax(s_lu[q], lim::tiny))));
+        rmax = fmax(rmax, fmax(-c * itl, -d * frcp(fmax(s_ll[q], lim::tiny))));
       }
       if constexpr (KS > 0) {
 #pragma unroll
@@ -1155,7 +1162,7 @@ __global__ __launch_bounds__(64, ((KQ <= 4 && KS == 0) ? 2 : 1)) void lmpc_solve
         dlams = uni(-lams + cfs - th * rds - th * dts);
         rmax = fmax(rmax, fmax(-dts / ts, -dlams / lams));
       }
-      const real amax = uni(1.0 / rmax);
+      const real amax = uni(real(1) / rmax);
       if (pass == 1) alpha = uni(fmin(1.0, tau * amax));
       real sacc = 0.0;
 #pragma unroll
@@ -1225,7 +1232,7 @@ __global__ __launch_bounds__(64, ((KQ <= 4 && KS == 0) ? 2 : 1)) void lmpc_solve
 #pragma unroll
       for (int q = 0; q < KQ; ++q) {
         real range = ((flags(q) & (F_UP | F_LO)) == (F_UP | F_LO)) ? (hl[q].x - hl[q].y) : 1.0;
-        if (!(range > 1e-3)) range = 1e-3;
+        if (!(range > real(1e-3))) range = real(1e-3);
         const real thr = thr_frac * range;
         if (flags(q) & F_UP) {
           s_tu[q] = fmax(hl[q].x - val[q], thr);
@@ -1253,7 +1260,7 @@ __global__ __launch_bounds__(64, ((KQ <= 4 && KS == 0) ? 2 : 1)) void lmpc_solve
   wave_sync();
   for (int e = lane; e < 6 * N; e += 64) {
     const int k = e / N, i = e - k * N;
-    X_out[(size_t)(k * N + i) * B + b] = L.kn(i)[k];
+    X_out[(size_t)(k * N + i) * B + b] = L.kn(i)[k] + (k == 0 ? s_shift : real(0));
   }
   for (int e = lane; e < 2 * NS; e += 64) {
     const int k = e / NS, i = e - k * NS;
@@ -1310,3 +1317,8 @@ template __global__ void lmpc_solve_kernel<double, 7, 2>(lmpc_params, int, const
     const double*, const double*, const double*, double*, double*, double*, double*, int*, int*, double*);
 template __global__ void lmpc_solve_kernel<double, 7, 3>(lmpc_params, int, const double*, const double*, const double*, const double*, const double*, const double*,
     const double*, const double*, const double*, double*, double*, double*, double*, int*, int*, double*);
+// single precision (BASELINE configs[3]): tracking problems only
+template __global__ void lmpc_solve_kernel<float, 4, 0>(lmpc_params, int, const float*, const float*, const float*, const float*, const float*, const float*,
+    const float*, const float*, const float*, float*, float*, float*, float*, int*, int*, float*);
+template __global__ void lmpc_solve_kernel<float, 7, 0>(lmpc_params, int, const float*, const float*, const float*, const float*, const float*, const float*,
+    const float*, const float*, const float*, float*, float*, float*, float*, int*, int*, float*);

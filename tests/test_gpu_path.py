@@ -382,3 +382,28 @@ def test_longer_horizons_match_the_twin(pkg, N):
     X, U = out["X_optm"], out["U_optm"]
     pred = np.einsum("rcib,cib->rib", A, X[:, :-1]) + np.einsum("rcib,cib->rib", Bm, U) + g
     assert np.abs(pred - X[:, 1:])[:, :, ok].max() < 1e-7
+
+
+def test_single_precision_solve_on_the_iac_problem(pkg, golden):
+    """BASELINE configs[3] as quoted (fp32): lmpc_solve_batch_f32 against the dense optimum on the golden vectors and
+    against the fp64 kernel on a batch.  Stated tolerance for fp32: 1e-3 in scaled units -- the order
+    of OSQP's eps the reference runs with; the complementarity floor of a single-precision Riccati recursion is ~1e-6."""
+    import torch
+
+    g = golden("qp_iac_tracking_n40")
+    veh, cfg, solver, tr, x, u = make(pkg, "iac40", 2048, 17)
+    o = to_np(solver.solve_f32(g))
+    assert (o["status"] == 0).all() and o["X_optm"].dtype == np.float32
+    assert scaled_err(o["X_optm"], g["X_optm"], P.SCALE_X) < 1e-3 and scaled_err(o["U_optm"], g["U_optm"], P.SCALE_U) < 1e-3
+    inp = solver.prepare(tr, x.T.copy(), 0.025)
+    inp["u_ic"] = torch.as_tensor(u.T.copy(), dtype=torch.float64, device="cuda")
+    o64, o32 = to_np(solver.solve(inp)), to_np(solver.solve_f32(inp))
+    ok = (o64["status"] == 0) & (o32["status"] == 0)
+    assert ok.mean() > 0.995 and ((o32["status"] == 0) | (o64["status"] != 0)).mean() > 0.998
+    e = np.abs((o32["X_optm"].astype(np.float64) - o64["X_optm"]) / P.SCALE_X[:, None, None]).max(axis=(0, 1))[ok]
+    assert np.median(e) < 1e-4 and np.percentile(e, 99) < 2e-3 and e.max() < 5e-2
+    # the abscissa keeps its resolution on a 2.8 km lap (carried relative to x_ic inside the kernel)
+    assert np.abs(o32["X_optm"][0, 0] - inp["x_ic"][0].cpu().numpy().astype(np.float32)).max() == 0.0
+    # rows of the QP hold to single precision
+    u_lo, u_hi, _, _ = Q.effective_bounds(cfg, veh)
+    assert (o32["U_optm"][:, :, ok] <= u_hi[:, None, None] + 1e-4).all() and (o32["U_optm"][:, :, ok] >= u_lo[:, None, None] - 1e-4).all()
