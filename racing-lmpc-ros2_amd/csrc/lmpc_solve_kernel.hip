@@ -421,7 +421,15 @@ __device__ void riccati_factor(const Lds<real>& L, int lane, const real* PT) {
     const real h00 = sv00 + thv0 + tt * y66;
     const real h01 = sv01 + tt * y67;
     const real h11 = sv11 + thv1 + tt * y77;
-    const real idet = frcp(h00 * h11 - h01 * h01);
+    real idet;
+    if constexpr (sizeof(real) == 4) {
+      // H = R + t^2 Y_uu is rank-one dominated once a state row is stiff: its determinant is the difference of two
+      // products that agree to six digits, which single precision cannot form -- a handful of fp64 operations per stage
+      const double det = (double)h00 * (double)h11 - (double)h01 * (double)h01;
+      idet = (real)(1.0 / det);
+    } else {
+      idet = frcp(h00 * h11 - h01 * h01);
+    }
     const real hi00 = h11 * idet, hi01 = -h01 * idet, hi11 = h00 * idet;
     const real g0 = t * y6c, g1 = t * y7c;
     const real k0c = hi00 * g0 + hi01 * g1;
@@ -956,6 +964,7 @@ __global__ __launch_bounds__(64, ((KS == 0 && (KQ <= 4 || (sizeof(real) == 4 && 
     }
 
     real sigc = 0.0, alpha = 1.0, dsigma = 0.0, dts = 0.0, dlams = 0.0;
+    bool numerics_failed = false;
     real d_val[KQ];
     const int npass = ipm ? 2 : 1;
     for (int pass = 0; pass < npass; ++pass) {
@@ -1129,11 +1138,13 @@ __global__ __launch_bounds__(64, ((KS == 0 && (KQ <= 4 || (sizeof(real) == 4 && 
       };
       real dtu[KQ], dlu[KQ], dtl[KQ], dll[KQ];
       real rmax = 1.0;
+      bool finite_step = true;
 #pragma unroll
       for (int q = 0; q < KQ; ++q) {
         const int f = flags(q);
         const real dval = dz0[q] + dsigma * dz1[q];
         d_val[q] = dval;
+        finite_step = finite_step && (fabs(dval) < inf);
         const real sg = (f & F_SIG) ? sigma : 0.0, dsg = (f & F_SIG) ? dsigma : 0.0;
         const real itu = frcp(s_tu[q]), itl = frcp(s_tl[q]);
         const real a = (f & F_UP) ? -(val[q] - sg + s_tu[q] - hl[q].x) - (dval - dsg) : 0.0;
@@ -1152,10 +1163,16 @@ __global__ __launch_bounds__(64, ((KS == 0 && (KQ <= 4 || (sizeof(real) == 4 && 
         for (int q = 0; q < KS; ++q) {
           real dt_, dl_, it_;
           row_step(sx.on[q], sx.t[q], sx.l[q], sx.p[q], -sx.lm[q] + sx.t[q], -sx.dl[q], dt_, dl_, it_);
-          rmax = fmax(rmax, fmax(-dt_ * it_, -dl_ * frcp(fmax(sx.l[q], 1e-300))));
+          rmax = fmax(rmax, fmax(-dt_ * it_, -dl_ * frcp(fmax(sx.l[q], lim::tiny))));
         }
       }
-      rmax = wave_max(rmax);
+      rmax = wave_max(finite_step ? rmax : inf);
+      if (!(rmax < inf) || !(dsigma == dsigma)) {
+        // a Newton step that is not a number (the Schur complement of sigma or the 2x2 H cancelled completely -- in
+        // practice single precision on its last iteration): keep the iterate, report it by what it has reached
+        numerics_failed = true;
+        break;
+      }
       if (has_sigma) {
         const real th = lams / ts, rds = -sigma + ts;
         dts = uni(-rds + dsigma);
@@ -1163,7 +1180,7 @@ __global__ __launch_bounds__(64, ((KS == 0 && (KQ <= 4 || (sizeof(real) == 4 && 
         rmax = fmax(rmax, fmax(-dts / ts, -dlams / lams));
       }
       const real amax = uni(real(1) / rmax);
-      if (pass == 1) alpha = uni(fmin(1.0, tau * amax));
+      if (pass == 1) alpha = uni(fmin(real(1), tau * amax));
       real sacc = 0.0;
 #pragma unroll
       for (int q = 0; q < KQ; ++q) {
@@ -1202,6 +1219,10 @@ __global__ __launch_bounds__(64, ((KS == 0 && (KQ <= 4 || (sizeof(real) == 4 && 
       }
     }
 
+    if (numerics_failed) {
+      status = (mu <= real(10) * tol && rdmax <= lim::rd_ok) ? LMPC_SOLVE_OPTIMAL : LMPC_SOLVE_MAX_ITER;
+      break;
+    }
     // ======== primal update by the component owners ========
     PT_MARK(6)
     real stepmax = 0.0;
