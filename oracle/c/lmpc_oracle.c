@@ -826,6 +826,7 @@ static int ipm_solve(prob_t* p, int* iters_out, double* kkt_out) {
     cost_gradient(p, w);
     newton_factor(p, w);
     double sigc = 0.0, alpha = 1.0;
+    int numerics_failed = 0;
     for (int pass = 0; pass < 2; ++pass) {
       for (int i = 0; i < N; ++i)
         for (int sl = 0; sl < NSLOT; ++sl)
@@ -844,6 +845,18 @@ static int ipm_solve(prob_t* p, int* iters_out, double* kkt_out) {
         if (pass == 1) w->cfl[j] += (sigc * mu - p->dtl[j] * p->dll[j]) / p->tl[j];
       }
       newton_solve(p, w);
+      /* a Newton step that is not a number (complete cancellation in the Schur complement of sigma or in H): keep
+       * the iterate and report it by what it has reached -- same rule as the kernel */
+      {
+        int finite = isfinite(p->dsigma);
+        for (int i = 0; i < N && finite; ++i)
+          for (int sl = 0; sl < NSLOT; ++sl)
+            if (!isfinite(slot_val(p->dz, p->dv, i, sl))) finite = 0;
+        if (!finite) {
+          numerics_failed = 1;
+          break;
+        }
+      }
       /* row steps and the largest step keeping t, lam > 0 */
       double amax = 1.0;
       for (int i = 0; i < N; ++i)
@@ -889,6 +902,10 @@ static int ipm_solve(prob_t* p, int* iters_out, double* kkt_out) {
         alpha = tau * amax;
         if (alpha > 1.0) alpha = 1.0;
       }
+    }
+    if (numerics_failed) {
+      status = (mu <= 10.0 * p->tol && rdmax <= 1e-9) ? LMPC_SOLVE_OPTIMAL : LMPC_SOLVE_MAX_ITER;
+      break;
     }
     primal_update(p, alpha);
     for (int i = 0; i < N; ++i)
