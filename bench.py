@@ -8,6 +8,7 @@ Prints ONE JSON line on rank 0.
 from __future__ import annotations
 
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -132,6 +133,9 @@ def main():
                          "iac = configs[3]'s problem (IAC/Putnam tracking, use --horizon 40 --batch 8192) in fp64")
     ap.add_argument("--precision", choices=["f64", "f32"], default="f64",
                     help="f32: lmpc_solve_batch_f32 (BASELINE configs[3] as quoted: --workload iac --horizon 40 --batch 8192 --precision f32)")
+    ap.add_argument("--streams", type=int, default=3,
+                    help="consecutive steps alternate between this many HIP streams (one handle, workspace and output buffer "
+                         "each), so the tail of one batch overlaps the head of the next; 1 = strictly one batch at a time")
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL result gather for N > 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-batch1", action="store_true", help="skip the single-car latency probe (profiling runs: keeps every "
@@ -160,15 +164,23 @@ def main():
     tr = pkg.workloads.synthetic_track("putnam" if iac else "barc")
     if lmpc:
         cfgd = pkg.presets.barc_lmpc(N, 5)  # 5 laps stored, 32 per lap -> 160 points
-        solver = pkg.Solver(cfgd, pkg.presets.barc_vehicle(), device=local)
         laps = pkg.workloads.synthetic_laps(tr, 5)
-        solver.set_safe_set(laps, tr["L"])
+
+        def make_solver():
+            sv = pkg.Solver(cfgd, pkg.presets.barc_vehicle(), device=local)
+            sv.set_safe_set(laps, tr["L"])
+            return sv
+        solver = make_solver()
         x, u = pkg.workloads.sample_states_near_laps(laps, B, tr["L"], seed=rank)
     elif iac:
-        solver = pkg.Solver(pkg.presets.iac_tracking_mpc(N), pkg.presets.iac_vehicle(), device=local)
+        def make_solver():
+            return pkg.Solver(pkg.presets.iac_tracking_mpc(N), pkg.presets.iac_vehicle(), device=local)
+        solver = make_solver()
         x, u = pkg.workloads.sample_initial_states("putnam", B, tr["L"], [-10.0, -0.314159], [5.0, 0.314159], seed=rank + 1)
     else:
-        solver = pkg.Solver(pkg.presets.barc_tracking_mpc(N), pkg.presets.barc_vehicle(), device=local)
+        def make_solver():
+            return pkg.Solver(pkg.presets.barc_tracking_mpc(N), pkg.presets.barc_vehicle(), device=local)
+        solver = make_solver()
         P = solver.config
         u_lo = [max(P["u_min"][0], -0.015), max(P["u_min"][1], -0.314159)]
         u_hi = [min(P["u_max"][0], 0.015), min(P["u_max"][1], 0.314159)]
@@ -176,7 +188,12 @@ def main():
     solver.reserve(B)
     inp = solver.prepare(tr, x.T.copy(), 0.025)   # node cold start on the device (racing_mpc_node.cpp:210-292)
     inp["u_ic"] = torch.as_tensor(u.T.copy(), dtype=torch.float64, device=dev)
-    outs = [solver.alloc_outputs(B), solver.alloc_outputs(B)]
+    S = max(1, args.streams)
+    solvers = [solver] + [make_solver() for _ in range(S - 1)]
+    for sv in solvers[1:]:
+        sv.reserve(B)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(S)] if S > 1 else [None]
+    outs = [solver.alloc_outputs(B) for _ in range(max(S, 2))]
     query = None
     if lmpc:
         for o in outs:
@@ -195,48 +212,65 @@ def main():
     if f32:
         assert not lmpc, "single precision is built for the tracking problem"
         inp32 = {k: (v.to(torch.float32).contiguous() if hasattr(v, "to") else v) for k, v in inp.items()}
-        outs = [solver.solve_f32(inp32), solver.solve_f32(inp32)]
+        outs = [solver.solve_f32(inp32) for _ in range(max(S, 2))]
+    if gather:  # one staging / receive buffer per stream
+        flat = [torch.empty_like(flat[0]) for _ in range(S)]
+        gbuf = [torch.empty_like(gbuf[0]) for _ in range(S)]
+    torch.cuda.synchronize()
 
-    def solve_step(k):
-        o = outs[k & 1]
+    def solve_step(k, sv=None):
+        sv = sv or solver
+        o = outs[k % len(outs)]
         if f32:
-            solver.solve_f32(inp32, o)
+            sv.solve_f32(inp32, o)
         elif lmpc:
-            ss_x, ss_j, _ = solver.ss_query(query)
-            solver.solve(inp, o, ss_x=ss_x, ss_j=ss_j)
+            ss_x, ss_j, _ = sv.ss_query(query)
+            sv.solve(inp, o, ss_x=ss_x, ss_j=ss_j)
         else:
-            solver.solve(inp, o)
+            sv.solve(inp, o)
         return o
 
-    def step(k, handle_prev):
-        o = solve_step(k)
-        if gather:  # a collective: every rank must take this path the same number of times
-            if handle_prev is not None:
-                handle_prev.wait()
-            f = pack_results(o, flat[k & 1])
-            return dist.all_gather_into_tensor(gbuf[k & 1], f, async_op=True)
-        return None
+    pending = [None] * S   # the gather in flight on each stream's buffers
 
-    h = None
+    def step(k):
+        j = k % S
+        with (torch.cuda.stream(streams[j]) if streams[j] is not None else contextlib.nullcontext()):
+            o = solve_step(j, solvers[j])
+            if gather:  # a collective: every rank must take this path the same number of times
+                if pending[j] is not None:
+                    pending[j].wait()
+                f = pack_results(o, flat[j])
+                pending[j] = dist.all_gather_into_tensor(gbuf[j], f, async_op=True)
+
+    def drain():
+        for j in range(S):
+            if pending[j] is not None:
+                pending[j].wait()
+                pending[j] = None
+        torch.cuda.synchronize()
+
     for k in range(args.warmup):
-        h = step(k, h)
-    if h is not None:
-        h.wait()
-    torch.cuda.synchronize()
+        step(k)
+    drain()
     if world > 1:
         dist.barrier()
         torch.cuda.synchronize()
     t0 = time.perf_counter()
-    h = None
     for k in range(args.steps):
-        h = step(k, h)
-    if h is not None:
-        h.wait()
-    torch.cuda.synchronize()
+        step(k)
+    drain()
     if world > 1:
         dist.barrier()
         torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    one_stream_value = None
+    if world == 1 and S > 1:  # the same steps strictly one after the other, for reference
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for k in range(args.steps):
+            solve_step(k)
+        torch.cuda.synchronize()
+        one_stream_value = B * args.steps / (time.perf_counter() - t1)
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -294,9 +328,9 @@ def main():
                                     ("IAC Putnam tracking MPC, batch=%d per GPU, N=%d, fp32 (BASELINE configs[3])" if f32 else
                                      "IAC Putnam tracking MPC, batch=%d per GPU, N=%d, fp64 (problem of BASELINE configs[3])") if iac else
                                     "BARC tracking MPC, batch=%d random x0 per GPU, N=%d, fp64 (BASELINE configs[1])") % (B, N),
-                       "batch_per_gpu": B, "horizon": N, "result_gather": "rccl all_gather (async)" if gather else "none"},
+                       "batch_per_gpu": B, "horizon": N, "streams": S, "result_gather": "rccl all_gather (async)" if gather else "none"},
             "p50_solve_ms": float(np.percentile(lat, 50)), "p99_solve_ms": float(np.percentile(lat, 99)),
-            "latency_samples": len(lat),
+            "latency_samples": len(lat), "value_one_stream": one_stream_value,
             "batch1_solve_ms": {"p50": float(np.percentile(lat1, 50)), "p99": float(np.percentile(lat1, 99)), "control_period_ms": 25.0} if lat1 else None,
             "solved_fraction": float((st == 0).mean()), "mean_ipm_iters": float(iters.mean()),
             "kernels_ms": {"linearize": float(np.mean(lin_ms)), "qp_solve": sol_avg},
