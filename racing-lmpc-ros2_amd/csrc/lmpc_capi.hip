@@ -380,6 +380,7 @@ int lmpc_solve_batch_f32(lmpc_handle* h, int32_t batch, const float* x_ic, const
       !vel_ref || !X_optm || !U_optm || !dU_optm || !status || !iters)
     return fail(h, LMPC_ERR_ARGUMENT, "lmpc_solve_batch_f32: null pointer or negative batch");
   if (h->P.learning) return fail(h, LMPC_ERR_UNSUPPORTED, "single precision is built for the tracking problem only");
+  if (h->reg_on) return fail(h, LMPC_ERR_UNSUPPORTED, "the error-dynamics regression is applied in double precision only");
   if (batch == 0) return LMPC_OK;
   HIP_TRY(h, hipSetDevice(h->device));
   const int N = h->P.N;
