@@ -32,7 +32,7 @@ def measured_traffic_bytes():
     kernel's reads are 8-byte strided or L2/MALL-resident workspace lines, so the raw counter is reported."""
     try:
         pmc = json.load(open(ROOT / "profiles" / "r01_pmc.json"))
-        k = next(v for n, v in pmc.items() if n.startswith("lmpc_solve_kernel<4, 0>"))
+        k = next(v for n, v in pmc.items() if n.startswith("lmpc_solve_kernel<") and "float" not in n and n.rstrip().endswith("4, 0>"))
         return (k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0
     except Exception:
         return None
@@ -45,7 +45,7 @@ def engine_utilisation(kernel_ms):
     that profile run.  Reported next to the HBM figure because the path is not HBM-bound."""
     try:
         pmc = json.load(open(ROOT / "profiles" / "r01_pmc.json"))
-        k = next(v for n, v in pmc.items() if n.startswith("lmpc_solve_kernel<4, 0>"))
+        k = next(v for n, v in pmc.items() if n.startswith("lmpc_solve_kernel<") and "float" not in n and n.rstrip().endswith("4, 0>"))
         prof_ms = pmc.get("_meta", {}).get("qp_kernel_ms", kernel_ms)
         cyc = prof_ms * 1e-3 * pmc.get("_meta", {}).get("clock_ghz", 2.3) * 1e9
         return {"valu_busy_frac": k["SQ_ACTIVE_INST_VALU"] * 4.0 / (cyc * 256 * 4),
