@@ -136,7 +136,7 @@ int launch_solve(lmpc_handle* h, const void* fn, const solve_args& a) {
   void* args[] = {(void*)&P,        (void*)&B,      (void*)&ws,      (void*)&a.x_ic, (void*)&a.u_ic, (void*)&a.T_ref,
                   (void*)&a.bl,     (void*)&a.br,   (void*)&a.vref,  (void*)&a.ss_x, (void*)&a.ss_j, (void*)&a.lam,
                   (void*)&a.X,      (void*)&a.U,    (void*)&a.dU,    (void*)&a.status, (void*)&a.iters, (void*)&a.kkt};
-  HIP_TRY(h, hipLaunchKernel(fn, dim3(a.B), dim3(64), args, a.lds_bytes, h->stream));
+  HIP_TRY(h, hipLaunchKernel(fn, dim3(8 * ((a.B + 7) / 8)), dim3(64), args, a.lds_bytes, h->stream));  // see the kernel: XCD-aware mapping
   return LMPC_OK;
 }
 
@@ -411,7 +411,7 @@ int lmpc_solve_batch_f32(lmpc_handle* h, int32_t batch, const float* x_ic, const
   float* nulo = nullptr;
   void* args[] = {&P, &B, &ws, &x_ic, &u_ic, &T_ref, &bound_left, &bound_right, &vel_ref, &nul, &nul, &nulo,
                   &X_optm, &U_optm, &dU_optm, &status, &iters, &kkt};
-  HIP_TRY(h, hipLaunchKernel(fn, dim3(batch), dim3(64), args, lds, h->stream));
+  HIP_TRY(h, hipLaunchKernel(fn, dim3(8 * ((batch + 7) / 8)), dim3(64), args, lds, h->stream));
   if (h->timing) HIP_TRY(h, hipEventRecord(h->ev[2], h->stream));
   return LMPC_OK;
 }

@@ -613,14 +613,19 @@ __global__ __launch_bounds__(64, ((KS == 0 && (KQ <= 4 || (sizeof(real) == 4 && 
     int* __restrict__ iters_out, real* __restrict__ kkt_out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];  // one symbol for every instantiation
   real* const lds = reinterpret_cast<real*>(lds_raw);
-  const int b = blockIdx.x;
+  // XCD-aware problem assignment: consecutive workgroups go round-robin to the 8 XCDs (each with its own L2), while
+  // consecutive problems share 64-byte lines in the [field][knot][batch] arrays.  Workgroup w takes problem
+  // (w mod 8) * ceil(B / 8) + w / 8, so each XCD owns a contiguous eighth of the batch and the 8-byte strided
+  // accesses of neighbouring problems merge in that XCD's L2 instead of reaching HBM as partial lines.
+  const int b = (int)(blockIdx.x & 7) * ((B + 7) >> 3) + (int)(blockIdx.x >> 3);
+  if (b >= B) return;
   const int lane = threadIdx.x;
   const int N = P.N, NS = N - 1;
   typedef typename vec2<real>::type real2;
   typedef ipm_limits<real> lim;
   const real inf = real(INFINITY), marg = real(P.marg), qsig = real(P.qsig), tol = lim::tol(P.tol);
   // single precision carries the abscissa relative to x_ic[0] (the QP is invariant to the shift: A(:, s) = e_s)
-  const real s_shift = sizeof(real) == 4 ? x_ic[blockIdx.x] : real(0);
+  const real s_shift = sizeof(real) == 4 ? x_ic[b] : real(0);
   Lds<real> L{lds, N};
   real* T = L.tail();
   real* ct = T + TL_CT;
