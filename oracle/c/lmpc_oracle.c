@@ -826,7 +826,7 @@ static int ipm_solve(prob_t* p, int* iters_out, double* kkt_out) {
     cost_gradient(p, w);
     newton_factor(p, w);
     double sigc = 0.0, alpha = 1.0;
-    int numerics_failed = 0;
+    int numerics_failed = 0, degenerate_stop = 0;
     for (int pass = 0; pass < 2; ++pass) {
       for (int i = 0; i < N; ++i)
         for (int sl = 0; sl < NSLOT; ++sl)
@@ -898,6 +898,13 @@ static int ipm_solve(prob_t* p, int* iters_out, double* kkt_out) {
         for (int j = 0; j < S; ++j) s += (p->tl[j] + amax * p->dtl[j]) * (p->ll[j] + amax * p->dll[j]);
         const double ratio = (s / m) / mu;
         sigc = ratio * ratio * ratio;
+        /* degenerate problem (no strict complementarity): late in the iteration the affine step stops making
+         * progress (mu_aff / mu > 0.4, against 1e-2 .. 1e-3 on a regular problem) and the remaining iterations only
+         * add the Riccati recursion's noise to an iterate that is O(sqrt(mu)) from the optimum anyway -- keep it */
+        if (mu <= 1e-8 && rdmax <= 1e-9 && ratio > 0.4) {
+          degenerate_stop = 1;
+          break;
+        }
       } else {
         alpha = tau * amax;
         if (alpha > 1.0) alpha = 1.0;
@@ -905,6 +912,10 @@ static int ipm_solve(prob_t* p, int* iters_out, double* kkt_out) {
     }
     if (numerics_failed) {
       status = (mu <= 10.0 * p->tol && rdmax <= 1e-9) ? LMPC_SOLVE_OPTIMAL : LMPC_SOLVE_MAX_ITER;
+      break;
+    }
+    if (degenerate_stop) {
+      status = LMPC_SOLVE_OPTIMAL;
       break;
     }
     primal_update(p, alpha);

@@ -226,11 +226,11 @@ __device__ __forceinline__ float rfma(float a, float b, float c) { return __buil
 template <typename real> struct ipm_limits;
 template <> struct ipm_limits<double> {
   static __device__ __forceinline__ double tol(double cfg) { return cfg; }
-  static constexpr double rd_ok = 1e-9, rd_infeasible = 1e-6, tiny = 1e-300;
+  static constexpr double rd_ok = 1e-9, rd_infeasible = 1e-6, tiny = 1e-300, degenerate_mu = 1e-8;
 };
 template <> struct ipm_limits<float> {
   static __device__ __forceinline__ float tol(double cfg) { return fmaxf((float)cfg, 2e-6f); }
-  static constexpr float rd_ok = 1e-4f, rd_infeasible = 1e-2f, tiny = 1e-30f;
+  static constexpr float rd_ok = 1e-4f, rd_infeasible = 1e-2f, tiny = 1e-30f, degenerate_mu = 0.0f;  // (rule off)
 };
 template <typename real> struct vec2;
 template <> struct vec2<double> { typedef double2 type; };
@@ -969,7 +969,7 @@ __global__ __launch_bounds__(64, ((KS == 0 && (KQ <= 4 || (sizeof(real) == 4 && 
     }
 
     real sigc = 0.0, alpha = 1.0, dsigma = 0.0, dts = 0.0, dlams = 0.0;
-    bool numerics_failed = false;
+    bool numerics_failed = false, degenerate_stop = false;
     real d_val[KQ];
     const int npass = ipm ? 2 : 1;
     for (int pass = 0; pass < npass; ++pass) {
@@ -1220,12 +1220,23 @@ __global__ __launch_bounds__(64, ((KS == 0 && (KQ <= 4 || (sizeof(real) == 4 && 
         if (has_sigma) sacc += (ts + amax * dts) * (lams + amax * dlams);
         const real ratio = (sacc * inv_m) / mu;
         sigc = uni(ratio * ratio * ratio);
+        // degenerate problem (no strict complementarity): late in the iteration the affine step stops making
+        // progress (mu_aff / mu > 0.4, against 1e-2 .. 1e-3 on a regular problem) and further iterations only add
+        // the recursion's noise to an iterate that is O(sqrt(mu)) from the optimum anyway -- keep it
+        if (mu <= lim::degenerate_mu && rdmax <= lim::rd_ok && ratio > real(0.4)) {
+          degenerate_stop = true;
+          break;
+        }
         wave_sync();
       }
     }
 
     if (numerics_failed) {
       status = (mu <= real(10) * tol && rdmax <= lim::rd_ok) ? LMPC_SOLVE_OPTIMAL : LMPC_SOLVE_MAX_ITER;
+      break;
+    }
+    if (degenerate_stop) {
+      status = LMPC_SOLVE_OPTIMAL;
       break;
     }
     // ======== primal update by the component owners ========

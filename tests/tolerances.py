@@ -10,8 +10,9 @@ polished, KKT-certified optimum:
   * degenerate problems (an input pinned by its box and its rate limit at once: no strict
     complementarity): an interior-point iterate is only O(sqrt(mu)) from the optimum there, and the
     Riccati recursion cannot take mu below ~1e-11 in fp64 (weights lam/t ~ 1e12 cancel in P), so a
-    few problems per thousand sit 1e-4 .. 2e-3 away in X, U (measured on 192 fresh problems:
-    max 1.7e-3, 99th percentile 2e-5, median 1e-10; scratch/acc_eval2.py).  They are bounded by
+    few problems per thousand sit 1e-4 .. 1e-3 away in X, U (measured on 1024 fresh problems:
+    max 5e-4, 99th percentile 5e-5, median 1e-10; scratch/acc_eval4.py).  The iteration stops on such a
+    problem as soon as the affine step stalls (mu_aff / mu > 0.4 at mu <= 1e-8) instead of adding noise.  They are bounded by
     TOL_DEGENERATE and, rigorously, by feasibility (1e-9 / 1e-8) and the objective gap
     (1e-7 relative) against the dense optimum, which every problem must meet.
 The dense oracle itself is accurate to ~1e-12.
