@@ -7,7 +7,7 @@ sys.path.insert(0, str(ROOT))
 from __graft_entry__ import load_package
 from oracle import cbind, params as OP, qp as OQ, scenario as OS
 pkg = load_package()
-so = sys.argv[1] if len(sys.argv) > 1 else str(ROOT / "scratch" / "_exp_oracle.so")
+so = sys.argv[1] if len(sys.argv) > 1 else str(ROOT / "oracle" / "_build" / "liblmpc_oracle.so")
 cbind._LIB = None
 _real = C.CDLL(so)
 cbind.lib = lambda: _real
