@@ -79,3 +79,23 @@ def test_device_table_samples_the_interpolants(tracks):
     assert tab["M"] == 512 and tab["L"] == tr.total_length
     for k, kr in (("curvature", "curvature"), ("bound_left", "left"), ("bound_right", "right"), ("vel", "vel")):
         assert np.abs(tab[k] - ref[kr]).max() < 1e-8
+
+
+def test_cpp_racing_trajectory_matches_the_restatement(tracks, tmp_path):
+    """The C++ host class (racing-lmpc-ros2_amd/host/racing_trajectory.cpp, the reference's class surface) against the
+    same restatement; compiled here with g++ (no GPU, no HIP)."""
+    import subprocess
+
+    _, _, orc = tracks
+    root = Path(__file__).resolve().parents[1]
+    host = root / "racing-lmpc-ros2_amd" / "host"
+    exe = tmp_path / "test_racing_trajectory"
+    subprocess.run(["g++", "-O2", "-std=c++17", f"-I{host}", "-o", str(exe), str(root / "tests" / "cpp" / "test_racing_trajectory.cpp"),
+                    str(host / "racing_trajectory.cpp")], check=True, timeout=300)
+    out = subprocess.run([str(exe), str(TRACK), "801"], capture_output=True, text=True, check=True, timeout=60).stdout.split("\n")
+    assert float(out[0]) == orc.L
+    tab = np.array([[float(v) for v in ln.split()] for ln in out[1:802]])
+    ref = orc.eval(tab[:, 0])
+    for col, k, tol in ((1, "x", 1e-10), (2, "y", 1e-10), (3, "vel", 1e-9), (4, "left", 1e-10), (5, "right", 1e-10), (6, "yaw", 1e-8), (7, "curvature", 1e-7)):
+        assert np.abs(tab[:, col] - ref[k]).max() < tol, k
+    assert np.abs(np.array([float(v) for v in out[802].split()])).max() < 1e-6
