@@ -10,7 +10,7 @@ from __future__ import annotations
 
 
 def run(solver, track: dict, x0, u0, steps: int, dt: float = 0.025, n_sub: int = 2, speed_scale: float = 0.9,
-        record_every: int = 0):
+        record_every: int = 0, restart_failed: bool = True):
     """x0 [6][B], u0 [2][B] (torch, device).  Returns final state and statistics (torch tensors on device)."""
     import torch
 
@@ -44,6 +44,12 @@ def run(solver, track: dict, x0, u0, steps: int, dt: float = 0.025, n_sub: int =
         worst_excess = torch.maximum(worst_excess, exc)
         u_prev = u_apply
         inp = solver.shift(trk, inp, out, dt, speed_scale=speed_scale)
+        if restart_failed and bool((~ok).any()):
+            # a car whose QP failed keeps a stale plan, and a stale plan makes the next QP fail too; restart those cars
+            # from a cold start at their current state, as re-launching the node would (racing_mpc_node.cpp:210-235)
+            cold = solver.prepare(trk, x, dt, speed_scale=speed_scale)
+            for key in ("X_ref", "U_ref", "T_ref", "bound_left", "bound_right", "curvatures", "vel_ref"):
+                inp[key] = torch.where(ok, inp[key], cold[key])
         if record_every and k % record_every == 0:
             trace.append(x.clone())
     return {"x": x, "distance": dist, "worst_excess": worst_excess, "n_fail": n_fail, "trace": trace}
