@@ -407,3 +407,39 @@ def test_single_precision_solve_on_the_iac_problem(pkg, golden):
     # rows of the QP hold to single precision
     u_lo, u_hi, _, _ = Q.effective_bounds(cfg, veh)
     assert (o32["U_optm"][:, :, ok] <= u_hi[:, None, None] + 1e-4).all() and (o32["U_optm"][:, :, ok] >= u_lo[:, None, None] - 1e-4).all()
+
+
+def test_c_abi_rejects_misuse_without_crashing(pkg):
+    """No exception crosses the C ABI: misuse comes back as a negative code with a message (errors)."""
+    import ctypes as C
+    import torch
+
+    lib = pkg.load_library()
+    solver = pkg.Solver(pkg.presets.barc_tracking_mpc(20), pkg.presets.barc_vehicle(), device=0)
+    h = solver._h
+    null = C.c_void_p(0)
+    # null pointers / negative batch
+    assert lib.lmpc_solve_batch(h, C.c_int32(4), *([null] * 9), C.c_double(1.0), null, null, *([null] * 7)) < 0
+    assert b"null pointer" in lib.lmpc_last_error(h)
+    assert lib.lmpc_linearize_batch(h, C.c_int32(-1), *([null] * 7)) < 0
+    assert lib.lmpc_ss_query_batch(h, C.c_int32(1), null, null, null, null) < 0
+    assert lib.lmpc_regress_batch(h, C.c_int32(1), null, null, null, null, null) < 0
+    # batch 0 is a no-op
+    x = torch.zeros(8, dtype=torch.float64, device="cuda")
+    p = C.c_void_p(x.data_ptr())
+    assert lib.lmpc_solve_batch(h, C.c_int32(0), *([p] * 9), C.c_double(1.0), null, null, p, p, p, null, p, p, null) == 0
+    # configurations that are not built are refused at creation, with a reason
+    bad = pkg.presets.barc_tracking_mpc(200)
+    with pytest.raises(pkg.LmpcError):
+        pkg.Solver(bad, pkg.presets.barc_vehicle(), device=0)
+    veh = pkg.presets.barc_vehicle()
+    veh["model_id"] = 1   # kinematic bicycle: selector kept, model not built
+    with pytest.raises(pkg.LmpcError):
+        pkg.Solver(pkg.presets.barc_tracking_mpc(20), veh, device=0)
+    # single precision refuses what it does not cover
+    lm = pkg.Solver(pkg.presets.barc_lmpc(20, 3), pkg.presets.barc_vehicle(), device=0)
+    assert lib.lmpc_solve_batch_f32(lm._h, C.c_int32(1), *([p] * 9), p, p, p, p, p, null) < 0
+    assert b"single precision" in lib.lmpc_last_error(lm._h)
+    # the handle still works after all that
+    veh2, cfg, s2, tr, xx, uu = make(pkg, "barc20", 8, 1)
+    assert (to_np(solver.solve(S.cold_start_inputs(cfg, veh2, tr, xx, uu, 0.025)))["status"] == 0).all()
