@@ -33,6 +33,11 @@
 
 #include "lmpc_device.h"
 
+// waves per SIMD asked of the compiler for the single-precision N <= 23 kernel (its 10 KB records allow 16 per CU):
+// measured 1.04 / 0.93 / 0.97 ms per 8192-batch at 2 / 3 / 4 -- the issue ceiling (LDS pipe, VALU) is ~12 % away
+#ifndef OCCF
+#define OCCF 3
+#endif
 #define NSLOT 11
 
 // Optional per-phase cycle accounting (make prof -> -DLMPC_PHASE_TIMING): one s_memtime read per
@@ -604,7 +609,7 @@ __device__ void feedback_rollout(const Lds<real>& L, int lane) {
 }
 
 template <typename real, int KQ, int KS>
-__global__ __launch_bounds__(64, ((KS == 0 && (KQ <= 4 || (sizeof(real) == 4 && KQ <= 7))) ? 2 : 1)) void lmpc_solve_kernel(
+__global__ __launch_bounds__(64, ((sizeof(real) == 4 && KQ <= 4 && KS == 0) ? OCCF : ((KS == 0 && (KQ <= 4 || (sizeof(real) == 4 && KQ <= 7))) ? 2 : 1))) void lmpc_solve_kernel(
     lmpc_params P, int B, const real* __restrict__ ws_lin, const real* __restrict__ x_ic,
     const real* __restrict__ u_ic, const real* __restrict__ T_ref, const real* __restrict__ bl,
     const real* __restrict__ br, const real* __restrict__ vref, const real* __restrict__ ss_x,
