@@ -61,3 +61,16 @@ def test_facade_lmpc_loads_laps_queries_and_records(golden, tmp_path):
     laps = [str(ROOT / "tests" / "golden" / "barc_ss" / f"ss_lap_{i}") for i in (1, 2, 3)]
     r = subprocess.run([str(exe), str(p), *laps, str(tmp_path) + "/rec_"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.strip().endswith("PASS"), (r.stdout[-2000:], r.stderr[-2000:])
+
+
+def test_c_abi_from_plain_cpp_without_python_buffers():
+    """bench_cabi: the reference's track file -> C++ RacingTrajectory -> device tables -> lmpc_prepare_batch ->
+    lmpc_solve_batch, all from a C++ program holding its own HIP buffers (no torch anywhere in that process)."""
+    exe = LIB / "bench_cabi"
+    assert exe.exists(), "run __graft_entry__.build() first"
+    track = ROOT / "tests" / "golden" / "barc_track" / "15_barc_optm.txt"
+    r = subprocess.run([str(exe), str(track), "4096", "20"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout, r.stderr)
+    f = r.stdout.split()
+    rate, solved = float(f[f.index("solves/s") - 1]), float(f[f.index("solved") + 1])
+    assert solved > 0.99 and rate > 1e6, r.stdout
