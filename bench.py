@@ -32,7 +32,7 @@ def measured_traffic_bytes():
     kernel's reads are 8-byte strided or L2/MALL-resident workspace lines, so the raw counter is reported."""
     try:
         pmc = json.load(open(ROOT / "profiles" / "r01_pmc.json"))
-        k = next(v for n, v in pmc.items() if n.startswith("lmpc_solve_kernel<") and "float" not in n and n.rstrip().endswith("4, 0>"))
+        k = next(v for n, v in pmc.items() if n.startswith("lmpc_solve_kernel<double, 4, 0"))
         return (k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0
     except Exception:
         return None
@@ -45,7 +45,7 @@ def engine_utilisation(kernel_ms):
     that profile run.  Reported next to the HBM figure because the path is not HBM-bound."""
     try:
         pmc = json.load(open(ROOT / "profiles" / "r01_pmc.json"))
-        k = next(v for n, v in pmc.items() if n.startswith("lmpc_solve_kernel<") and "float" not in n and n.rstrip().endswith("4, 0>"))
+        k = next(v for n, v in pmc.items() if n.startswith("lmpc_solve_kernel<double, 4, 0"))
         prof_ms = pmc.get("_meta", {}).get("qp_kernel_ms", kernel_ms)
         cyc = prof_ms * 1e-3 * pmc.get("_meta", {}).get("clock_ghz", 2.3) * 1e9
         return {"valu_busy_frac": k["SQ_ACTIVE_INST_VALU"] * 4.0 / (cyc * 256 * 4),
@@ -131,8 +131,10 @@ def main():
     ap.add_argument("--workload", choices=["tracking", "lmpc", "iac"], default="tracking",
                     help="tracking = BASELINE configs[1] (the quoted metric); lmpc = configs[2] (5-lap safe set); "
                          "iac = configs[3]'s problem (IAC/Putnam tracking, use --horizon 40 --batch 8192) in fp64")
-    ap.add_argument("--precision", choices=["f64", "f32"], default="f64",
-                    help="f32: lmpc_solve_batch_f32 (BASELINE configs[3] as quoted: --workload iac --horizon 40 --batch 8192 --precision f32)")
+    ap.add_argument("--precision", choices=["f64", "f32", "mixed"], default="f64",
+                    help="f32: lmpc_solve_batch_f32 (BASELINE configs[3] as quoted: --workload iac --horizon 40 --batch 8192 --precision f32); "
+                         "mixed: lmpc_solve_batch_mixed, fp64 arrays around an fp32 interior-point iteration (BASELINE configs[4]: "
+                         "--workload lmpc --batch 32768 --precision mixed)")
     ap.add_argument("--streams", type=int, default=3,
                     help="consecutive steps alternate between this many HIP streams (one handle, workspace and output buffer "
                          "each), so the tail of one batch overlaps the head of the next; 1 = strictly one batch at a time")
@@ -158,6 +160,7 @@ def main():
 
     pkg = load_package()
     f32 = args.precision == "f32"
+    mixed = args.precision == "mixed"
     N, B = args.horizon, args.batch
     lmpc = args.workload == "lmpc"
     iac = args.workload == "iac"
@@ -225,9 +228,9 @@ def main():
             sv.solve_f32(inp32, o)
         elif lmpc:
             ss_x, ss_j, _ = sv.ss_query(query)
-            sv.solve(inp, o, ss_x=ss_x, ss_j=ss_j)
+            sv.solve(inp, o, ss_x=ss_x, ss_j=ss_j, mixed=mixed)
         else:
-            sv.solve(inp, o)
+            sv.solve(inp, o, mixed=mixed)
         return o
 
     pending = [None] * S   # the gather in flight on each stream's buffers
@@ -322,12 +325,13 @@ def main():
             "metric": "QP solves/sec (nx=6,nu=2,N=%d)" % N, "value": value, "unit": "solves/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32" if f32 else "f64", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32" if f32 else ("f32 iteration, f64 arrays" if mixed else "f64"), "data": "synthetic",
             "config": {"workload": ("BARC LMPC with 5-lap safe set (160 points), batch=%d per GPU, N=%d, fp64: safe-set kNN kernel + "
                                     "QP kernel per step (BASELINE configs[2])" if lmpc else
                                     ("IAC Putnam tracking MPC, batch=%d per GPU, N=%d, fp32 (BASELINE configs[3])" if f32 else
                                      "IAC Putnam tracking MPC, batch=%d per GPU, N=%d, fp64 (problem of BASELINE configs[3])") if iac else
-                                    "BARC tracking MPC, batch=%d random x0 per GPU, N=%d, fp64 (BASELINE configs[1])") % (B, N),
+                                    "BARC tracking MPC, batch=%d random x0 per GPU, N=%d, fp64 (BASELINE configs[1])") % (B, N)
+                                   + (" -- mixed precision: fp32 Riccati / interior point between fp64 arrays (BASELINE configs[4])" if mixed else ""),
                        "batch_per_gpu": B, "horizon": N, "streams": S, "result_gather": "rccl all_gather (async)" if gather else "none"},
             "p50_solve_ms": float(np.percentile(lat, 50)), "p99_solve_ms": float(np.percentile(lat, 99)),
             "latency_samples": len(lat), "value_one_stream": one_stream_value,
@@ -335,7 +339,7 @@ def main():
             "solved_fraction": float((st == 0).mean()), "mean_ipm_iters": float(iters.mean()),
             "kernels_ms": {"linearize": float(np.mean(lin_ms)), "qp_solve": sol_avg},
             "launch": ({**solver.launch_info(), "lds_bytes_per_problem": solver.launch_info()["lds_bytes_per_problem"] // 2,
-                        "resident_problems_per_cu": None, "note": "fp32 records are half the fp64 size"} if f32 else solver.launch_info()),
+                        "resident_problems_per_cu": None, "note": "fp32 records are half the fp64 size"} if (f32 or mixed) else solver.launch_info()),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None if (lmpc or N != 20 or B != 4096) else measured_traffic_bytes(),

@@ -157,6 +157,23 @@ int lmpc_solve_batch(lmpc_handle* h, int32_t batch, const double* x_ic, const do
                      const double* ss_j, double* X_optm, double* U_optm, double* dU_optm,
                      double* convex_combi_optm, int32_t* status, int32_t* iters, double* kkt);
 
+/* Mixed precision: same arguments, layouts and fp64 arrays as lmpc_solve_batch, for the tracking problem.  In fp64:
+ * the linearisation (discrete_dynamics_jacobian), the error-dynamics regression onto it when
+ * lmpc_set_regression_laps is in effect, the centring of the abscissa on x_ic[0], the 2x2 pivots of the Riccati
+ * recursion, and the results.  In fp32: the stage records in LDS, the Riccati factor and sweeps and the interior-point
+ * rows -- half the LDS footprint, so twice the resident problems per CU where fp64 is capacity-bound (N = 40: 2.3x the
+ * fp64 rate).  Stopping rule and accuracy as lmpc_solve_batch_f32: fit for well-scaled problems (IAC: 99 % within
+ * 6e-4 of the fp64 solution in scaled units), NOT for the BARC problems, whose soft boundary needs complementarity
+ * below 1e-9.  learning = 1 returns LMPC_ERR_UNSUPPORTED (BASELINE configs[4] asks for a mixed
+ * KKT on the learning problem; the terminal block's condition number ~1e8 rules fp32 out -- measured).
+ * N <= 40. */
+int lmpc_solve_batch_mixed(lmpc_handle* h, int32_t batch, const double* x_ic, const double* u_ic,
+                           const double* X_ref, const double* U_ref, const double* T_ref,
+                           const double* bound_left, const double* bound_right, const double* curvatures,
+                           const double* vel_ref, double total_length, const double* ss_x,
+                           const double* ss_j, double* X_optm, double* U_optm, double* dU_optm,
+                           double* convex_combi_optm, int32_t* status, int32_t* iters, double* kkt);
+
 /* Single precision (BASELINE configs[3]: "IAC Putnam tracking MPC, N=40, ..., fp32"): the tracking problem with every
  * array in float and the interior point / Riccati recursion in fp32 (the linearisation is evaluated in fp64 and
  * rounded).  Same layouts and meaning as lmpc_solve_batch, no safe-set arguments; kkt [4][B] optional.  The abscissa

@@ -19,7 +19,8 @@ _ABI_SYMBOLS = ("lmpc_create", "lmpc_destroy", "lmpc_last_error", "lmpc_set_stre
                 "lmpc_linearize_batch", "lmpc_solve_batch", "lmpc_set_safe_set", "lmpc_ss_query_batch",
                 "lmpc_prepare_batch", "lmpc_reserve", "lmpc_query_launch", "lmpc_enable_timing",
                 "lmpc_last_kernel_ms", "lmpc_query_residency", "lmpc_solve_host", "lmpc_shift_batch",
-                "lmpc_plant_step_batch", "lmpc_set_regression_laps", "lmpc_regress_batch", "lmpc_ss_query_host", "lmpc_solve_batch_f32")
+                "lmpc_plant_step_batch", "lmpc_set_regression_laps", "lmpc_regress_batch", "lmpc_ss_query_host", "lmpc_solve_batch_f32",
+                "lmpc_solve_batch_mixed")
 
 
 class LmpcError(RuntimeError):
@@ -270,7 +271,8 @@ class Solver:
                 "iters": torch.empty((B,), dtype=torch.int32, device=self.device),
                 "kkt": torch.empty((4, B), **kw)}
 
-    def solve(self, inp: dict, out: dict | None = None, ss_x=None, ss_j=None):
+    def solve(self, inp: dict, out: dict | None = None, ss_x=None, ss_j=None, mixed: bool = False):
+        """lmpc_solve_batch, or with mixed=True lmpc_solve_batch_mixed (same fp64 arrays, fp32 interior-point iteration)."""
         self.use_current_stream()
         keys = ("x_ic", "u_ic", "X_ref", "U_ref", "T_ref", "bound_left", "bound_right", "curvatures", "vel_ref")
         a = [self._t(inp[k]) for k in keys]
@@ -279,11 +281,12 @@ class Solver:
             out = self.alloc_outputs(B)
         ss_x = None if ss_x is None else self._t(ss_x)
         ss_j = None if ss_j is None else self._t(ss_j)
-        rc = self.lib.lmpc_solve_batch(self._h, C.c_int32(B), *[_ptr(t) for t in a], C.c_double(float(inp["L"])),
-                                       _ptr(ss_x), _ptr(ss_j), _ptr(out["X_optm"]), _ptr(out["U_optm"]),
-                                       _ptr(out["dU_optm"]), _ptr(out.get("convex_combi_optm")),
-                                       _ptr(out["status"]), _ptr(out["iters"]), _ptr(out.get("kkt")))
-        self._check(rc, "lmpc_solve_batch")
+        fn = self.lib.lmpc_solve_batch_mixed if mixed else self.lib.lmpc_solve_batch
+        rc = fn(self._h, C.c_int32(B), *[_ptr(t) for t in a], C.c_double(float(inp["L"])),
+                _ptr(ss_x), _ptr(ss_j), _ptr(out["X_optm"]), _ptr(out["U_optm"]),
+                _ptr(out["dU_optm"]), _ptr(out.get("convex_combi_optm")),
+                _ptr(out["status"]), _ptr(out["iters"]), _ptr(out.get("kkt")))
+        self._check(rc, "lmpc_solve_batch_mixed" if mixed else "lmpc_solve_batch")
         out["_inputs_keepalive"] = a
         return out
 

@@ -23,10 +23,9 @@ __global__ void lmpc_shift_kernel(lmpc_params, int, lmpc_track, const double*, c
                                   const double*, const int*, double, double, double, double*, double*, double*, double*,
                                   double*, double*, double*);
 __global__ void lmpc_plant_kernel(lmpc_params, int, lmpc_track, double*, const double*, double, int);
-template <typename real, int KQ, int KS>
-__global__ void lmpc_solve_kernel(lmpc_params, int, const real*, const real*, const real*, const real*, const real*,
-                                  const real*, const real*, const real*, const real*, real*, real*, real*, real*, int*,
-                                  int*, real*);
+template <typename real, int KQ, int KS, typename io>
+__global__ void lmpc_solve_kernel(lmpc_params, int, const io*, const io*, const io*, const io*, const io*, const io*,
+                                  const io*, const io*, const io*, io*, io*, io*, io*, int*, int*, io*);
 __global__ void lmpc_ss_query_kernel(int, int, int, int, const int*, const int*, const double*, double, const double*,
                                      double*, double*, int*, double*);
 __global__ void lmpc_reg_residual_kernel(lmpc_vehicle, int, const int*, const double*, const double*, const double*,
@@ -103,9 +102,9 @@ struct solve_args {
   double* kkt;
 };
 
-template <int KQ, int KS>
+template <int KQ, int KS, typename real = double>
 const void* solve_fn() {
-  return reinterpret_cast<const void*>(&lmpc_solve_kernel<double, KQ, KS>);
+  return reinterpret_cast<const void*>(&lmpc_solve_kernel<real, KQ, KS, double>);
 }
 
 // the (KQ, KS) instantiations that exist: KQ = ceil(11 N / 64) rounded up to {2,4,7,11,14}, KS = safe-set points / 64
@@ -126,6 +125,12 @@ const void* pick_solve_fn(int kq, int ks) {
     if (kq == 7) return solve_fn<7, 3>();
   }
   return nullptr;
+}
+
+// fp32 interior-point iteration between fp64 arrays (lmpc_solve_batch_mixed): tracking problem, N <= 40
+const void* pick_mixed_fn(int kq, int ks) {
+  if (kq > 7 || ks != 0) return nullptr;
+  return kq <= 4 ? solve_fn<4, 0, float>() : solve_fn<7, 0, float>();
 }
 
 int launch_solve(lmpc_handle* h, const void* fn, const solve_args& a) {
@@ -328,17 +333,20 @@ int lmpc_linearize_batch(lmpc_handle* h, int32_t batch, const double* X_ref, con
   return LMPC_OK;
 }
 
-int lmpc_solve_batch(lmpc_handle* h, int32_t batch, const double* x_ic, const double* u_ic, const double* X_ref,
-                     const double* U_ref, const double* T_ref, const double* bound_left, const double* bound_right,
-                     const double* curvatures, const double* vel_ref, double total_length, const double* ss_x,
-                     const double* ss_j, double* X_optm, double* U_optm, double* dU_optm, double* convex_combi_optm,
-                     int32_t* status, int32_t* iters, double* kkt) {
+namespace {
+int solve_batch_fp64_arrays(lmpc_handle* h, bool mixed, int32_t batch, const double* x_ic, const double* u_ic,
+                            const double* X_ref, const double* U_ref, const double* T_ref, const double* bound_left,
+                            const double* bound_right, const double* curvatures, const double* vel_ref,
+                            double total_length, const double* ss_x, const double* ss_j, double* X_optm, double* U_optm,
+                            double* dU_optm, double* convex_combi_optm, int32_t* status, int32_t* iters, double* kkt) {
   if (!h) return LMPC_ERR_ARGUMENT;
   (void)total_length;  // abscissa alignment (racing_mpc.cpp:219-223) shifts s only; the QP is invariant to it
   if (batch < 0 || !x_ic || !u_ic || !X_ref || !U_ref || !T_ref || !bound_left || !bound_right || !curvatures ||
       !vel_ref || !X_optm || !U_optm || !dU_optm || !status || !iters)
     return fail(h, LMPC_ERR_ARGUMENT, "lmpc_solve_batch: null pointer or negative batch");
   if (h->P.learning && (!ss_x || !ss_j)) return fail(h, LMPC_ERR_ARGUMENT, "learning=1 needs ss_x and ss_j");
+  if (mixed && h->P.learning)
+    return fail(h, LMPC_ERR_UNSUPPORTED, "mixed precision is built for the tracking problem: the safe-set terminal block needs fp64");
   if (batch == 0) return LMPC_OK;
   HIP_TRY(h, hipSetDevice(h->device));
   if ((size_t)batch > h->ws_cap) {
@@ -356,11 +364,11 @@ int lmpc_solve_batch(lmpc_handle* h, int32_t batch, const double* x_ic, const do
     if (rc != LMPC_OK) return rc;
   }
   if (h->timing) HIP_TRY(h, hipEventRecord(h->ev[1], h->stream));
-  const void* fn = pick_solve_fn(kq_for(N), ks_for(h->P.S));
-  if (!fn) return fail(h, LMPC_ERR_UNSUPPORTED, "no kernel for this (N, num_ss_pts)");
+  const void* fn = mixed ? pick_mixed_fn(kq_for(N), ks_for(h->P.S)) : pick_solve_fn(kq_for(N), ks_for(h->P.S));
+  if (!fn) return fail(h, LMPC_ERR_UNSUPPORTED, mixed ? "the mixed-precision kernel is built for N <= 40" : "no kernel for this (N, num_ss_pts)");
   solve_args a{};
   a.B = batch;
-  a.lds_bytes = (size_t)lmpc_lds_doubles(N, h->P.learning) * sizeof(double);
+  a.lds_bytes = (size_t)lmpc_lds_doubles(N, h->P.learning) * (mixed ? sizeof(float) : sizeof(double));
   a.x_ic = x_ic; a.u_ic = u_ic; a.T_ref = T_ref; a.bl = bound_left; a.br = bound_right; a.vref = vel_ref;
   a.ss_x = h->P.learning ? ss_x : nullptr; a.ss_j = h->P.learning ? ss_j : nullptr;
   a.lam = h->P.learning ? convex_combi_optm : nullptr;
@@ -369,6 +377,27 @@ int lmpc_solve_batch(lmpc_handle* h, int32_t batch, const double* x_ic, const do
   if (rc != LMPC_OK) return rc;
   if (h->timing) HIP_TRY(h, hipEventRecord(h->ev[2], h->stream));
   return LMPC_OK;
+}
+}  // namespace
+
+int lmpc_solve_batch(lmpc_handle* h, int32_t batch, const double* x_ic, const double* u_ic, const double* X_ref,
+                     const double* U_ref, const double* T_ref, const double* bound_left, const double* bound_right,
+                     const double* curvatures, const double* vel_ref, double total_length, const double* ss_x,
+                     const double* ss_j, double* X_optm, double* U_optm, double* dU_optm, double* convex_combi_optm,
+                     int32_t* status, int32_t* iters, double* kkt) {
+  return solve_batch_fp64_arrays(h, false, batch, x_ic, u_ic, X_ref, U_ref, T_ref, bound_left, bound_right, curvatures,
+                                 vel_ref, total_length, ss_x, ss_j, X_optm, U_optm, dU_optm, convex_combi_optm, status,
+                                 iters, kkt);
+}
+
+int lmpc_solve_batch_mixed(lmpc_handle* h, int32_t batch, const double* x_ic, const double* u_ic, const double* X_ref,
+                           const double* U_ref, const double* T_ref, const double* bound_left, const double* bound_right,
+                           const double* curvatures, const double* vel_ref, double total_length, const double* ss_x,
+                           const double* ss_j, double* X_optm, double* U_optm, double* dU_optm,
+                           double* convex_combi_optm, int32_t* status, int32_t* iters, double* kkt) {
+  return solve_batch_fp64_arrays(h, true, batch, x_ic, u_ic, X_ref, U_ref, T_ref, bound_left, bound_right, curvatures,
+                                 vel_ref, total_length, ss_x, ss_j, X_optm, U_optm, dU_optm, convex_combi_optm, status,
+                                 iters, kkt);
 }
 
 int lmpc_solve_batch_f32(lmpc_handle* h, int32_t batch, const float* x_ic, const float* u_ic, const float* X_ref,
@@ -385,8 +414,8 @@ int lmpc_solve_batch_f32(lmpc_handle* h, int32_t batch, const float* x_ic, const
   HIP_TRY(h, hipSetDevice(h->device));
   const int N = h->P.N;
   const int kq = kq_for(N);
-  const void* fn = kq == 2 || kq == 4 ? reinterpret_cast<const void*>(&lmpc_solve_kernel<float, 4, 0>)
-                   : kq == 7          ? reinterpret_cast<const void*>(&lmpc_solve_kernel<float, 7, 0>)
+  const void* fn = kq == 2 || kq == 4 ? reinterpret_cast<const void*>(&lmpc_solve_kernel<float, 4, 0, float>)
+                   : kq == 7          ? reinterpret_cast<const void*>(&lmpc_solve_kernel<float, 7, 0, float>)
                                       : nullptr;
   if (!fn) return fail(h, LMPC_ERR_UNSUPPORTED, "single precision is built for N <= 40");
   if ((size_t)batch > h->ws_f32_cap) {

@@ -39,6 +39,11 @@
 #define OCCF 3
 #endif
 #define NSLOT 11
+// resident waves per SIMD the register allocation is sized for: the fp64 tracking kernels up to N = 23 and every fp32
+// kernel up to N = 40 run two (three for fp32, N <= 23); the fp64 LMPC and long-horizon kernels need the full file
+constexpr int lmpc_waves_per_simd(int real_bytes, int kq, int ks) {
+  return real_bytes == 4 ? ((kq <= 4 && ks == 0) ? OCCF : (kq <= 7 ? 2 : 1)) : ((ks == 0 && kq <= 4) ? 2 : 1);
+}
 
 // Optional per-phase cycle accounting (make prof -> -DLMPC_PHASE_TIMING): one s_memtime read per
 // phase boundary, per-wave totals written over kkt_out as [16][B] doubles (caller allocates 20 rows).
@@ -608,14 +613,17 @@ __device__ void feedback_rollout(const Lds<real>& L, int lane) {
   }
 }
 
-template <typename real, int KQ, int KS>
-__global__ __launch_bounds__(64, ((sizeof(real) == 4 && KQ <= 4 && KS == 0) ? OCCF : ((KS == 0 && (KQ <= 4 || (sizeof(real) == 4 && KQ <= 7))) ? 2 : 1))) void lmpc_solve_kernel(
-    lmpc_params P, int B, const real* __restrict__ ws_lin, const real* __restrict__ x_ic,
-    const real* __restrict__ u_ic, const real* __restrict__ T_ref, const real* __restrict__ bl,
-    const real* __restrict__ br, const real* __restrict__ vref, const real* __restrict__ ss_x,
-    const real* __restrict__ ss_j, real* __restrict__ lam_out, real* __restrict__ X_out,
-    real* __restrict__ U_out, real* __restrict__ dU_out, int* __restrict__ status_out,
-    int* __restrict__ iters_out, real* __restrict__ kkt_out) {
+// `real` is the arithmetic and LDS type, `io` the type of the arrays in HBM: <double, double> is the reference's
+// precision, <float, float> the single-precision path, <float, double> the mixed path (fp64 linearisation, regression,
+// safe-set centring and results around an fp32 interior-point iteration).
+template <typename real, int KQ, int KS, typename io>
+__global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void lmpc_solve_kernel(
+    lmpc_params P, int B, const io* __restrict__ ws_lin, const io* __restrict__ x_ic,
+    const io* __restrict__ u_ic, const io* __restrict__ T_ref, const io* __restrict__ bl,
+    const io* __restrict__ br, const io* __restrict__ vref, const io* __restrict__ ss_x,
+    const io* __restrict__ ss_j, io* __restrict__ lam_out, io* __restrict__ X_out,
+    io* __restrict__ U_out, io* __restrict__ dU_out, int* __restrict__ status_out,
+    int* __restrict__ iters_out, io* __restrict__ kkt_out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];  // one symbol for every instantiation
   real* const lds = reinterpret_cast<real*>(lds_raw);
   // XCD-aware problem assignment: consecutive workgroups go round-robin to the 8 XCDs (each with its own L2), while
@@ -630,7 +638,7 @@ __global__ __launch_bounds__(64, ((sizeof(real) == 4 && KQ <= 4 && KS == 0) ? OC
   typedef ipm_limits<real> lim;
   const real inf = real(INFINITY), marg = real(P.marg), qsig = real(P.qsig), tol = lim::tol(P.tol);
   // single precision carries the abscissa relative to x_ic[0] (the QP is invariant to the shift: A(:, s) = e_s)
-  const real s_shift = sizeof(real) == 4 ? x_ic[b] : real(0);
+  const io s_shift = sizeof(real) == 4 ? x_ic[b] : io(0);
   Lds<real> L{lds, N};
   real* T = L.tail();
   real* ct = T + TL_CT;
@@ -639,29 +647,29 @@ __global__ __launch_bounds__(64, ((sizeof(real) == 4 && KQ <= 4 && KS == 0) ? OC
 
   // ---------------- load: linearisation records, per-knot data, constant tables ----------------
   {
-    const real* wsb = ws_lin + (size_t)b * NS * LMPC_LIN_RECORD;
+    const io* wsb = ws_lin + (size_t)b * NS * LMPC_LIN_RECORD;
     for (int e = lane; e < NS * LMPC_LIN_RECORD; e += 64) {
       const int i = e / LMPC_LIN_RECORD, o = e - i * LMPC_LIN_RECORD;
       const int c = o / 6;
-      L.st(i)[o < 48 ? ST_ROW(c) + (o - c * 6) : ST_G + (o - 48)] = wsb[e];
+      L.st(i)[o < 48 ? ST_ROW(c) + (o - c * 6) : ST_G + (o - 48)] = real(wsb[e]);
     }
-    for (int i = lane; i < NS; i += 64) L.st(i)[ST_DT] = T_ref[(size_t)i * B + b];
+    for (int i = lane; i < NS; i += 64) L.st(i)[ST_DT] = real(T_ref[(size_t)i * B + b]);
     for (int i = lane; i < N; i += 64) {
       real* kn = L.kn(i);
-      kn[KN_QLIN] = P.learning ? real(0) : real(i == N - 1 ? P.qv_term : P.qv_stage) * vref[(size_t)i * B + b];
+      kn[KN_QLIN] = P.learning ? real(0) : real(i == N - 1 ? P.qv_term : P.qv_stage) * real(vref[(size_t)i * B + b]);
       kn[8] = 0.0;
       kn[9] = 0.0;
-      kn[KN_BHL] = bl[(size_t)i * B + b] - marg;
-      kn[KN_BHL + 1] = br[(size_t)i * B + b] + marg;
+      kn[KN_BHL] = real(bl[(size_t)i * B + b]) - marg;
+      kn[KN_BHL + 1] = real(br[(size_t)i * B + b]) + marg;
     }
     if (lane < 6) {
-      KN0[lane] = (lane == 0) ? x_ic[b] - s_shift : x_ic[(size_t)lane * B + b];
+      KN0[lane] = real((lane == 0) ? x_ic[b] - s_shift : x_ic[(size_t)lane * B + b]);
       ct[CT_QD + lane] = P.learning ? 0.0 : P.Qd[lane];
       ct[CT_QT + lane] = P.learning ? 0.0 : P.Qt[lane];
       ct[CT_HL + 2 * lane] = P.x_max[lane];
       ct[CT_HL + 2 * lane + 1] = P.x_min[lane];
     } else if (lane < 8) {
-      KN0[lane] = u_ic[(size_t)(lane - 6) * B + b];
+      KN0[lane] = real(u_ic[(size_t)(lane - 6) * B + b]);
       ct[CT_HL + 2 * lane] = P.u_hi[lane - 6];
       ct[CT_HL + 2 * lane + 1] = P.u_lo[lane - 6];
     } else if (lane < 10) {
@@ -729,8 +737,8 @@ __global__ __launch_bounds__(64, ((sizeof(real) == 4 && KQ <= 4 && KS == 0) ? OC
           pd = k == 0 ? 1 : -1;
         }
       } else {
-        hi = bl[(size_t)i * B + b] - marg;
-        lo = br[(size_t)i * B + b] + marg;
+        hi = real(bl[(size_t)i * B + b]) - marg;
+        lo = real(br[(size_t)i * B + b]) + marg;
         on = has_sigma || i >= 1;
       }
     }
@@ -756,15 +764,19 @@ __global__ __launch_bounds__(64, ((sizeof(real) == 4 && KQ <= 4 && KS == 0) ? OC
   const int S = P.S;
   SimplexRows<real, KS> sx;
   if constexpr (KS > 0) {
+    io c0[6];  // the differences are formed in the storage precision, the abscissa relative to the shift
 #pragma unroll
-    for (int k = 0; k < 6; ++k) sx.ss0[k] = ss_x[((size_t)k * S) * B + b];
+    for (int k = 0; k < 6; ++k) {
+      c0[k] = ss_x[((size_t)k * S) * B + b];
+      sx.ss0[k] = real(k == 0 ? c0[k] - s_shift : c0[k]);
+    }
 #pragma unroll
     for (int q = 0; q < KS; ++q) {
       const int j = lane + 64 * q;
       sx.on[q] = j < S;
 #pragma unroll
-      for (int k = 0; k < 6; ++k) sx.u[q][k] = sx.on[q] ? ss_x[((size_t)k * S + j) * B + b] - sx.ss0[k] : 0.0;
-      sx.j[q] = sx.on[q] ? ss_j[(size_t)j * B + b] : 0.0;
+      for (int k = 0; k < 6; ++k) sx.u[q][k] = sx.on[q] ? real(ss_x[((size_t)k * S + j) * B + b] - c0[k]) : real(0);
+      sx.j[q] = sx.on[q] ? real(ss_j[(size_t)j * B + b]) : real(0);
       sx.lm[q] = sx.on[q] ? 1.0 / S : 0.0;
       sx.t[q] = sx.on[q] ? 1.0 / S : 1.0;
       sx.l[q] = 0.0;
@@ -1302,18 +1314,18 @@ __global__ __launch_bounds__(64, ((sizeof(real) == 4 && KQ <= 4 && KS == 0) ? OC
   wave_sync();
   for (int e = lane; e < 6 * N; e += 64) {
     const int k = e / N, i = e - k * N;
-    X_out[(size_t)(k * N + i) * B + b] = L.kn(i)[k] + (k == 0 ? s_shift : real(0));
+    X_out[(size_t)(k * N + i) * B + b] = io(L.kn(i)[k]) + (k == 0 ? s_shift : io(0));
   }
   for (int e = lane; e < 2 * NS; e += 64) {
     const int k = e / NS, i = e - k * NS;
-    U_out[(size_t)(k * NS + i) * B + b] = L.kn(i + 1)[6 + k];
-    dU_out[(size_t)(k * NS + i) * B + b] = L.kn(i)[8 + k];
+    U_out[(size_t)(k * NS + i) * B + b] = io(L.kn(i + 1)[6 + k]);
+    dU_out[(size_t)(k * NS + i) * B + b] = io(L.kn(i)[8 + k]);
   }
   if constexpr (KS > 0) {
     if (lam_out) {
 #pragma unroll
       for (int q = 0; q < KS; ++q)
-        if (sx.on[q]) lam_out[(size_t)(lane + 64 * q) * B + b] = sx.lm[q];
+        if (sx.on[q]) lam_out[(size_t)(lane + 64 * q) * B + b] = io(sx.lm[q]);
     }
   }
   if (lane == 0) {
@@ -1321,46 +1333,43 @@ __global__ __launch_bounds__(64, ((sizeof(real) == 4 && KQ <= 4 && KS == 0) ? OC
     iters_out[b] = it;
 #ifdef LMPC_PHASE_TIMING
     if (kkt_out) {
-      for (int k = 0; k < 16; ++k) kkt_out[k * (size_t)B + b] = (real)pf.acc[k];
-      kkt_out[16 * (size_t)B + b] = (real)pf.w0;               // 100 MHz wall clock at start
-      kkt_out[17 * (size_t)B + b] = (real)wall_clock64();      // ... at end
+      for (int k = 0; k < 16; ++k) kkt_out[k * (size_t)B + b] = (io)pf.acc[k];
+      kkt_out[16 * (size_t)B + b] = (io)pf.w0;               // 100 MHz wall clock at start
+      kkt_out[17 * (size_t)B + b] = (io)wall_clock64();      // ... at end
       unsigned hwid, xcc;
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-      kkt_out[18 * (size_t)B + b] = (real)hwid;
-      kkt_out[19 * (size_t)B + b] = (real)(xcc & 0xf);
+      kkt_out[18 * (size_t)B + b] = (io)hwid;
+      kkt_out[19 * (size_t)B + b] = (io)(xcc & 0xf);
     }
 #else
     if (kkt_out) {
-      kkt_out[0 * (size_t)B + b] = last_step;
-      kkt_out[1 * (size_t)B + b] = rdmax;
-      kkt_out[2 * (size_t)B + b] = mu;
-      kkt_out[3 * (size_t)B + b] = sigma;
+      kkt_out[0 * (size_t)B + b] = io(last_step);
+      kkt_out[1 * (size_t)B + b] = io(rdmax);
+      kkt_out[2 * (size_t)B + b] = io(mu);
+      kkt_out[3 * (size_t)B + b] = io(sigma);
     }
 #endif
   }
 }
 
-template __global__ void lmpc_solve_kernel<double, 2, 0>(lmpc_params, int, const double*, const double*, const double*, const double*, const double*, const double*,
-    const double*, const double*, const double*, double*, double*, double*, double*, int*, int*, double*);
-template __global__ void lmpc_solve_kernel<double, 4, 0>(lmpc_params, int, const double*, const double*, const double*, const double*, const double*, const double*,
-    const double*, const double*, const double*, double*, double*, double*, double*, int*, int*, double*);
-template __global__ void lmpc_solve_kernel<double, 7, 0>(lmpc_params, int, const double*, const double*, const double*, const double*, const double*, const double*,
-    const double*, const double*, const double*, double*, double*, double*, double*, int*, int*, double*);
-template __global__ void lmpc_solve_kernel<double, 11, 0>(lmpc_params, int, const double*, const double*, const double*, const double*, const double*, const double*,
-    const double*, const double*, const double*, double*, double*, double*, double*, int*, int*, double*);
-template __global__ void lmpc_solve_kernel<double, 14, 0>(lmpc_params, int, const double*, const double*, const double*, const double*, const double*, const double*,
-    const double*, const double*, const double*, double*, double*, double*, double*, int*, int*, double*);
-template __global__ void lmpc_solve_kernel<double, 4, 2>(lmpc_params, int, const double*, const double*, const double*, const double*, const double*, const double*,
-    const double*, const double*, const double*, double*, double*, double*, double*, int*, int*, double*);
-template __global__ void lmpc_solve_kernel<double, 4, 3>(lmpc_params, int, const double*, const double*, const double*, const double*, const double*, const double*,
-    const double*, const double*, const double*, double*, double*, double*, double*, int*, int*, double*);
-template __global__ void lmpc_solve_kernel<double, 7, 2>(lmpc_params, int, const double*, const double*, const double*, const double*, const double*, const double*,
-    const double*, const double*, const double*, double*, double*, double*, double*, int*, int*, double*);
-template __global__ void lmpc_solve_kernel<double, 7, 3>(lmpc_params, int, const double*, const double*, const double*, const double*, const double*, const double*,
-    const double*, const double*, const double*, double*, double*, double*, double*, int*, int*, double*);
-// single precision (BASELINE configs[3]): tracking problems only
-template __global__ void lmpc_solve_kernel<float, 4, 0>(lmpc_params, int, const float*, const float*, const float*, const float*, const float*, const float*,
-    const float*, const float*, const float*, float*, float*, float*, float*, int*, int*, float*);
-template __global__ void lmpc_solve_kernel<float, 7, 0>(lmpc_params, int, const float*, const float*, const float*, const float*, const float*, const float*,
-    const float*, const float*, const float*, float*, float*, float*, float*, int*, int*, float*);
+#define LMPC_INSTANTIATE(REAL, KQ, KS, IO)                                                                              \
+  template __global__ void lmpc_solve_kernel<REAL, KQ, KS, IO>(lmpc_params, int, const IO*, const IO*, const IO*,        \
+                                                                const IO*, const IO*, const IO*, const IO*, const IO*,    \
+                                                                const IO*, IO*, IO*, IO*, IO*, int*, int*, IO*);
+LMPC_INSTANTIATE(double, 2, 0, double)
+LMPC_INSTANTIATE(double, 4, 0, double)
+LMPC_INSTANTIATE(double, 7, 0, double)
+LMPC_INSTANTIATE(double, 11, 0, double)
+LMPC_INSTANTIATE(double, 14, 0, double)
+LMPC_INSTANTIATE(double, 4, 2, double)
+LMPC_INSTANTIATE(double, 4, 3, double)
+LMPC_INSTANTIATE(double, 7, 2, double)
+LMPC_INSTANTIATE(double, 7, 3, double)
+LMPC_INSTANTIATE(float, 4, 0, float)
+LMPC_INSTANTIATE(float, 7, 0, float)
+// mixed: fp32 interior-point iteration between fp64 arrays.  Tracking only: the learning problem's terminal block
+// F = D^-1 + U Theta^-1 U' has a condition number ~1e8 late in the iteration, which fp32 cannot carry (measured:
+// median 1.5e-2 scaled error on the BARC LMPC problem with status "solved") -- DESIGN.md section 4
+LMPC_INSTANTIATE(float, 4, 0, double)
+LMPC_INSTANTIATE(float, 7, 0, double)

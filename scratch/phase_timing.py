@@ -11,19 +11,34 @@ capi.library_path = lambda: ROOT / "racing-lmpc-ros2_amd" / "lib" / "liblmpc_hip
 capi._LIB = None
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
-solver = pkg.Solver(pkg.presets.barc_tracking_mpc(N), pkg.presets.barc_vehicle(), 0)
+LMPC = len(sys.argv) > 3 and sys.argv[3] == "lmpc"
 tr = pkg.workloads.synthetic_track("barc")
-x, u = pkg.workloads.sample_initial_states("barc", B, tr["L"], [-0.01, -0.314159], [0.01, 0.314159], 0)
+kw = {}
+if LMPC:
+    laps = pkg.workloads.synthetic_laps(tr, 5)
+    solver = pkg.Solver(pkg.presets.barc_lmpc(N, 5), pkg.presets.barc_vehicle(), 0)
+    solver.set_safe_set(laps, tr["L"])
+    x, u = pkg.workloads.sample_states_near_laps(laps, B, tr["L"], seed=0)
+else:
+    solver = pkg.Solver(pkg.presets.barc_tracking_mpc(N), pkg.presets.barc_vehicle(), 0)
+    x, u = pkg.workloads.sample_initial_states("barc", B, tr["L"], [-0.01, -0.314159], [0.01, 0.314159], 0)
 inp = solver.prepare(tr, x.T.copy(), 0.025)
 inp["u_ic"] = torch.as_tensor(u.T.copy(), dtype=torch.float64, device="cuda")
+if LMPC:
+    s_last, s0, L = inp["X_ref"][0, -1], inp["x_ic"][0], tr["L"]
+    kk = (s0 - s_last).abs() + L / 2
+    query = torch.stack([s_last + (kk - torch.fmod(kk, L)) * torch.sign(s0 - s_last), inp["X_ref"][1, -1]]).contiguous()
+    ss_x, ss_j, _ = solver.ss_query(query)
+    kw = dict(ss_x=ss_x, ss_j=ss_j)
 out = solver.alloc_outputs(B)
 out["kkt"] = torch.zeros((20, B), dtype=torch.float64, device="cuda")
 for _ in range(3):
-    solver.solve(inp, out)
+    solver.solve(inp, out, **kw)
 torch.cuda.synchronize()
 k = out["kkt"].cpu().numpy()
 it = out["iters"].cpu().numpy()
-names = ["load", "init(factor+rollout)", "rows+reduce", "factor", "gradient", "solve", "schur+steps", "update/exit"] + ["x%d" % i for i in range(8, 16)]
+names = ["load", "init(factor+rollout)", "rows+reduce(+terminal block)", "factor", "riccati_solve (all)", "-", "schur+steps", "update/exit",
+         "  bwd sweep nrhs1", "  bwd sweep nrhs2", "  fwd sweep nrhs1", "  fwd sweep nrhs2", "gradient", "x13", "x14", "x15"]
 tot = k[:16].sum(0)
 print("mean iters %.2f; mean cycles/wave %.0f" % (it.mean(), tot.mean()))
 for n, v in zip(names, k[:16]):

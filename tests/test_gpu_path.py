@@ -409,6 +409,35 @@ def test_single_precision_solve_on_the_iac_problem(pkg, golden):
     assert (o32["U_optm"][:, :, ok] <= u_hi[:, None, None] + 1e-4).all() and (o32["U_optm"][:, :, ok] >= u_lo[:, None, None] - 1e-4).all()
 
 
+def test_mixed_precision_solve_on_the_iac_problem(pkg, golden):
+    """lmpc_solve_batch_mixed (fp64 arrays and linearisation around an fp32 Riccati / interior point) against the
+    certified optimum on the golden vectors and against the fp64 kernel on a batch.  Stated tolerance as for single
+    precision: 1e-3 scaled.  The learning problem is refused (its terminal block needs fp64)."""
+    import lmpc_scenario as LS
+    import torch
+
+    g = golden("qp_iac_tracking_n40")
+    veh, cfg, solver, tr, x, u = make(pkg, "iac40", 2048, 23)
+    o = to_np(solver.solve(g, mixed=True))
+    assert (o["status"] == 0).all() and o["X_optm"].dtype == np.float64
+    assert scaled_err(o["X_optm"], g["X_optm"], P.SCALE_X) < 1e-3 and scaled_err(o["U_optm"], g["U_optm"], P.SCALE_U) < 1e-3
+    inp = solver.prepare(tr, x.T.copy(), 0.025)
+    inp["u_ic"] = torch.as_tensor(u.T.copy(), dtype=torch.float64, device="cuda")
+    o64, om = to_np(solver.solve(inp)), to_np(solver.solve(inp, mixed=True))
+    ok = (o64["status"] == 0) & (om["status"] == 0)
+    assert ok.mean() > 0.995 and ((om["status"] == 0) | (o64["status"] != 0)).mean() > 0.998
+    e = np.abs((om["X_optm"] - o64["X_optm"]) / P.SCALE_X[:, None, None]).max(axis=(0, 1))[ok]
+    assert np.median(e) < 1e-4 and np.percentile(e, 99) < 2e-3 and e.max() < 5e-2
+    assert np.array_equal(om["X_optm"][0, 0], inp["x_ic"][0].cpu().numpy())  # x_0 = x_ic exactly, abscissa included
+
+    lm = pkg.Solver(pkg.presets.barc_lmpc(20, 3), pkg.presets.barc_vehicle(), device=0)
+    lm.set_safe_set(LS.load_laps(), LS.L_BARC_SS)
+    g = golden("qp_barc_lmpc_n20")
+    ss_x, ss_j, _ = lm.ss_query(g["query"])
+    with pytest.raises(pkg.LmpcError, match="tracking problem"):
+        lm.solve(g, ss_x=ss_x, ss_j=ss_j, mixed=True)
+
+
 def test_c_abi_rejects_misuse_without_crashing(pkg):
     """No exception crosses the C ABI: misuse comes back as a negative code with a message (errors)."""
     import ctypes as C
