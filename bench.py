@@ -149,11 +149,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # pre-flight hook for a one-GPU box (tests/test_gpu_path.py): all ranks share device 0 and rendezvous over gloo,
+    # so the N > 1 control flow (rank env, per-rank workload, barriers, max-over-ranks) runs without RCCL
+    shared_gpu = os.environ.get("LMPC_BENCH_SHARED_GPU") == "1"
+    if shared_gpu:
+        local = 0
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if shared_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU path)"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -275,7 +283,7 @@ def main():
         torch.cuda.synchronize()
         one_stream_value = B * args.steps / (time.perf_counter() - t1)
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if shared_gpu else dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 

@@ -472,3 +472,26 @@ def test_c_abi_rejects_misuse_without_crashing(pkg):
     # the handle still works after all that
     veh2, cfg, s2, tr, xx, uu = make(pkg, "barc20", 8, 1)
     assert (to_np(solver.solve(S.cold_start_inputs(cfg, veh2, tr, xx, uu, 0.025)))["status"] == 0).all()
+
+
+def test_bench_two_ranks_preflight_on_one_gpu():
+    """bench.py's N > 1 control flow as the driver launches it (torch.distributed.run, one rank per GPU), here with both
+    ranks on device 0 and gloo instead of RCCL (LMPC_BENCH_SHARED_GPU): rank environment, per-rank workloads, the
+    result gather, barriers, max-over-ranks timing and rank 0's single JSON line."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parents[1]
+    env = dict(os.environ, LMPC_BENCH_SHARED_GPU="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29531", str(root / "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--batch", "1024"]
+    r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["scaling"] == "weak" and d["value"] > 1e5
+    assert d["solved_fraction"] > 0.99 and "cpu_baseline" not in d
