@@ -384,6 +384,56 @@ def test_longer_horizons_match_the_twin(pkg, N):
     assert np.abs(pred - X[:, 1:])[:, :, ok].max() < 1e-7
 
 
+@pytest.mark.parametrize("N", [3, 11, 12, 23, 24, 41, 64, 65, 81])
+def test_horizons_at_the_row_layout_boundaries_match_the_twin(pkg, N):
+    """N = 3 is the smallest problem the ABI accepts and 81 the largest; the others sit either side of the points where
+    the rows-per-lane template parameter changes (11 N slots over 64 lanes: KQ = 2 | 4 | 7 | 11 | 14)."""
+    veh, cfg = P.barc_vehicle(), P.barc_tracking_mpc(N)
+    solver = pkg.Solver(pkg.presets.barc_tracking_mpc(N), pkg.presets.barc_vehicle(), device=0)
+    tr = pkg.workloads.synthetic_track("barc")
+    u_lo, u_hi, _, _ = Q.effective_bounds(cfg, veh)
+    x, u = pkg.workloads.sample_initial_states("barc", 24, tr["L"], u_lo, u_hi, 900 + N)
+    x[:, 3] = np.clip(x[:, 3], 1.6, 3.0)
+    inp = S.cold_start_inputs(cfg, veh, tr, x, u, 0.025)
+    out = to_np(solver.solve(inp))
+    twin = cbind.solve_batch(cfg, veh, inp)
+    assert out["X_optm"].shape == (6, N, 24) and out["U_optm"].shape == (2, N - 1, 24)
+    assert (out["status"] == twin["status"]).mean() > 0.9 and (out["status"] == 0).mean() > 0.85, (out["status"], twin["status"])
+    ok = (out["status"] == 0) & (twin["status"] == 0)
+    assert np.abs(out["iters"][ok] - twin["iters"][ok]).max() <= 1
+    e = np.abs((out["X_optm"] - twin["X_optm"]) / P.SCALE_X[:, None, None]).max(axis=(0, 1))[ok]
+    assert np.percentile(e, 90) < TOL_TWIN and e.max() < TOL_DEGENERATE
+    assert np.array_equal(out["X_optm"][:, 0, :], inp["x_ic"])          # x_0 = x_ic (racing_mpc.cpp:200-201)
+
+
+@pytest.mark.parametrize("N,n_laps", [(10, 3), (30, 3), (40, 5)])
+def test_lmpc_at_other_horizons_matches_the_twin(pkg, N, n_laps):
+    """The learning problem away from N = 20: KQ = 2 -> 4, 7 and both safe-set sizes (96 / 160 points)."""
+    import lmpc_scenario as LS
+    import torch
+
+    veh, cfg, tr, laps, inp, q = LS.make(32, 70 + N, N=N, n_laps=min(n_laps, 3))
+    cfg = P.barc_lmpc(N, n_laps)
+    stored = (laps * 2)[:n_laps]                                       # five laps: the three recorded ones, two repeated
+    solver = pkg.Solver(pkg.presets.barc_lmpc(N, n_laps), pkg.presets.barc_vehicle(), device=0)
+    solver.set_safe_set(stored, LS.L_BARC_SS)
+    ss_x, ss_j, nf = solver.ss_query(q)
+    S_pts = 32 * n_laps
+    rx, rj, rn = cbind.ss_query_batch(stored, LS.L_BARC_SS, S_pts, 32, q)
+    assert np.array_equal(ss_x.cpu().numpy(), rx) and np.array_equal(ss_j.cpu().numpy(), rj)
+    out = solver.alloc_outputs(32)
+    out["convex_combi_optm"] = torch.zeros((S_pts, 32), dtype=torch.float64, device="cuda")
+    o = to_np(solver.solve(inp, out, ss_x=ss_x, ss_j=ss_j))
+    twin = cbind.solve_batch(cfg, veh, inp, ss_x=rx, ss_j=rj)
+    assert (o["status"] == twin["status"]).mean() > 0.9 and (o["status"] == 0).mean() > 0.85, (o["status"], twin["status"])
+    ok = (o["status"] == 0) & (twin["status"] == 0)
+    assert np.abs(o["iters"][ok] - twin["iters"][ok]).max() <= 1
+    e = np.abs((o["X_optm"] - twin["X_optm"]) / P.SCALE_X[:, None, None]).max(axis=(0, 1))[ok]
+    assert np.percentile(e, 90) < TOL_TWIN and e.max() < TOL_DEGENERATE
+    lam = o["convex_combi_optm"][:, ok]
+    assert np.abs(lam.sum(0) - 1.0).max() < 1e-8 and lam.min() > -1e-10
+
+
 def test_single_precision_solve_on_the_iac_problem(pkg, golden):
     """BASELINE configs[3] as quoted (fp32): lmpc_solve_batch_f32 against the dense optimum on the golden vectors and
     against the fp64 kernel on a batch.  Stated tolerance for fp32: 1e-3 in scaled units -- the order
