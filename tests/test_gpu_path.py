@@ -312,6 +312,61 @@ def test_hard_boundary_without_slack(pkg):
         assert np.abs((out["X_optm"][:, :, b] - qp.split(yex)["X_optm"]) / P.SCALE_X[:, None]).max() < TOL_XU
 
 
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5])
+def test_randomised_configurations_against_the_dense_optimum(pkg, seed):
+    """Weights, coupling terms and boxes the shipped files never use (full 2x2 R / R_d, scaled q's, tight state box,
+    soft or hard boundary, horizons 8..20): every solved problem is checked against the dense optimum of the QP the
+    oracle assembles from the same configuration -- independent of the kernel and of its serial twin."""
+    import dataclasses
+
+    rng = np.random.default_rng(1000 + seed)
+    N = int(rng.choice([8, 14, 20]))
+    sc = lambda: float(10.0 ** rng.uniform(-1, 1))  # noqa: E731
+
+    def spd():
+        a, c = 0.01 * sc(), 0.01 * sc()
+        return np.array([[a, 0.6 * rng.uniform(-1, 1) * np.sqrt(a * c)], [0.0, c]])
+    R, R_d = spd(), spd()
+    R[1, 0], R_d[1, 0] = R[0, 1], R_d[0, 1]
+    base = P.barc_tracking_mpc(N)
+    kw = dict(q_contour=sc(), q_heading=sc(), q_vel=0.2 * sc(), q_vy=1e-3 * sc(), q_vyaw=1e-3 * sc(),
+              q_boundary=float(rng.choice([0.0, 5.0, 200.0])), R=R, R_d=R_d, margin=float(rng.uniform(0.02, 0.12)),
+              x_max=np.array([np.inf, np.inf, np.inf, rng.uniform(3.2, 6.0), rng.uniform(0.3, 1.0), rng.uniform(1.5, 3.0)]),
+              x_min=np.array([-np.inf, -np.inf, -np.inf, 0.1, -rng.uniform(0.3, 1.0), -rng.uniform(1.5, 3.0)]))
+    cfg = dataclasses.replace(base, **kw)
+    preset = pkg.presets.barc_tracking_mpc(N)
+    preset.update({k: (v.ravel().tolist() if isinstance(v, np.ndarray) else v) for k, v in kw.items()})
+    veh = P.barc_vehicle()
+    solver = pkg.Solver(preset, pkg.presets.barc_vehicle(), device=0)
+    tr = pkg.workloads.synthetic_track("barc")
+    u_lo, u_hi, _, _ = Q.effective_bounds(cfg, veh)
+    B = 16
+    x, u = pkg.workloads.sample_initial_states("barc", B, tr["L"], u_lo, u_hi, 77 + seed)
+    x[:, 3] = np.clip(x[:, 3], 1.0, 3.0)
+    x[:, 4] = np.clip(x[:, 4], -0.2, 0.2)
+    x[:, 5] = np.clip(x[:, 5], -1.0, 1.0)
+    if cfg.q_boundary == 0.0:
+        x[:, 1] = np.clip(x[:, 1], -0.05, 0.05)
+    inp = S.cold_start_inputs(cfg, veh, tr, x, u, 0.025)
+    out = to_np(solver.solve(inp))
+    per, n_dense_ok = [], 0
+    for b in range(B):
+        qp = Q.build_qp(cfg, veh, S.problem(inp, b))
+        yex, info = Q.solve_dense(qp)
+        if info["status"] != 0:
+            continue                      # infeasible for the dense solver too (hard boundary / tight box)
+        n_dense_ok += 1
+        assert out["status"][b] == 0, (b, out["status"][b], out["iters"][b])
+        y = Q.pack(qp, out["X_optm"][:, :, b], out["U_optm"][:, :, b], out["dU_optm"][:, :, b], sigma=out["kkt"][3, b])
+        assert np.abs(qp.A @ y - qp.b).max() < 1e-9 and (qp.C @ y - qp.d).max() < 1e-8
+        assert qp.objective(y) - qp.objective(yex) < 1e-7 * (1 + abs(qp.objective(yex)))
+        o = qp.split(yex)
+        per.append(max(np.abs((out["X_optm"][:, :, b] - o["X_optm"]) / P.SCALE_X[:, None]).max(),
+                       np.abs((out["U_optm"][:, :, b] - o["U_optm"]) / P.SCALE_U[:, None]).max()))
+    assert n_dense_ok >= B // 2, n_dense_ok
+    assert np.percentile(per, 80) < TOL_XU and max(per) < TOL_DEGENERATE, sorted(per)[-4:]
+
+
 def test_full_dynamics_sqp_closes_the_nonlinear_defect(pkg):
     """full_dynamics = true (racing_mpc.cpp:162-166): sequential QPs drive x_{i+1} - f_d(x_i, u_i, k_i, t_i) to zero;
     the single QP (linearised about the cold-start rollout) leaves a defect of the order of the linearisation error."""
