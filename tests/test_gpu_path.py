@@ -367,6 +367,50 @@ def test_randomised_configurations_against_the_dense_optimum(pkg, seed):
     assert np.percentile(per, 80) < TOL_XU and max(per) < TOL_DEGENERATE, sorted(per)[-4:]
 
 
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_lmpc_randomised_configurations_against_the_dense_optimum(pkg, seed):
+    """The learning problem with convex-hull slack weights, input weights and boundary cost the shipped file does not
+    use, 96 or 160 safe-set points, N = 12 / 20: checked against the dense optimum (objective, rows, simplex)."""
+    import dataclasses
+    import lmpc_scenario as LS
+    import torch
+
+    rng = np.random.default_rng(2000 + seed)
+    N, n_laps = int(rng.choice([12, 20])), int(rng.choice([3, 5]))
+    sc = lambda: float(10.0 ** rng.uniform(-0.7, 0.7))  # noqa: E731
+    kw = dict(q_boundary=float(rng.choice([100.0, 1000.0, 5000.0])), R=np.diag([0.1 * sc(), 0.1 * sc()]),
+              R_d=np.diag([0.1 * sc(), 0.1 * sc()]),
+              convex_hull_slack=np.array([40.0, 40.0, 4.0, 40.0, 40.0, 4.0]) * np.array([sc() for _ in range(6)]))
+    veh, _, tr, laps, inp, q = LS.make(12, 300 + seed, N=N, n_laps=3)
+    cfg = dataclasses.replace(P.barc_lmpc(N, n_laps), **kw)
+    preset = pkg.presets.barc_lmpc(N, n_laps)
+    preset.update({k: (v.ravel().tolist() if isinstance(v, np.ndarray) else v) for k, v in kw.items()})
+    stored = (laps * 2)[:n_laps]
+    solver = pkg.Solver(preset, pkg.presets.barc_vehicle(), device=0)
+    solver.set_safe_set(stored, LS.L_BARC_SS)
+    ss_x, ss_j, _ = solver.ss_query(q)
+    S_pts = 32 * n_laps
+    out = solver.alloc_outputs(12)
+    out["convex_combi_optm"] = torch.zeros((S_pts, 12), dtype=torch.float64, device="cuda")
+    o = to_np(solver.solve(inp, out, ss_x=ss_x, ss_j=ss_j))
+    sx, sj = ss_x.cpu().numpy(), ss_j.cpu().numpy()
+    per, n_ok = [], 0
+    for b in range(12):
+        qp = Q.build_qp(cfg, veh, S.problem(inp, b), ss_x=sx[:, :, b], ss_j=sj[:, b])
+        yex, info = Q.solve_dense(qp)
+        if info["status"] != 0:
+            continue
+        n_ok += 1
+        assert o["status"][b] == 0, (b, o["status"][b], o["iters"][b])
+        ex = qp.split(yex)
+        assert abs(o["convex_combi_optm"][:, b].sum() - 1.0) < 1e-9 and o["convex_combi_optm"][:, b].min() > -1e-10
+        # the terminal state is the convex combination up to the (penalised) hull slack: compare it and the trajectory
+        per.append(max(np.abs((o["X_optm"][:, :, b] - ex["X_optm"]) / P.SCALE_X[:, None]).max(),
+                       np.abs((o["U_optm"][:, :, b] - ex["U_optm"]) / P.SCALE_U[:, None]).max()))
+    assert n_ok >= 8, n_ok
+    assert np.percentile(per, 80) < TOL_XU and max(per) < TOL_DEGENERATE, sorted(per)[-4:]
+
+
 def test_full_dynamics_sqp_closes_the_nonlinear_defect(pkg):
     """full_dynamics = true (racing_mpc.cpp:162-166): sequential QPs drive x_{i+1} - f_d(x_i, u_i, k_i, t_i) to zero;
     the single QP (linearised about the cold-start rollout) leaves a defect of the order of the linearisation error."""
