@@ -120,9 +120,13 @@ const void* pick_solve_fn(int kq, int ks) {
   } else if (ks == 2) {
     if (kq <= 4) return solve_fn<4, 2>();
     if (kq == 7) return solve_fn<7, 2>();
+    if (kq == 11) return solve_fn<11, 2>();
+    if (kq == 14) return solve_fn<14, 2>();
   } else if (ks == 3) {
     if (kq <= 4) return solve_fn<4, 3>();
     if (kq == 7) return solve_fn<7, 3>();
+    if (kq == 11) return solve_fn<11, 3>();
+    if (kq == 14) return solve_fn<14, 3>();
   }
   return nullptr;
 }
@@ -178,8 +182,8 @@ int lmpc_create(const lmpc_config* cfg, const lmpc_vehicle* veh, int device, lmp
   if (cfg->N < 3 || kq_for(cfg->N) < 0) return fail(h, LMPC_ERR_ARGUMENT, "N must be in [3, 81]");
   if (cfg->learning && (cfg->num_ss_pts < 1 || cfg->num_ss_pts_per_lap < 1))
     return fail(h, LMPC_ERR_ARGUMENT, "learning needs num_ss_pts >= 1 and num_ss_pts_per_lap >= 1");
-  if (cfg->learning && (ks_for(cfg->num_ss_pts) < 0 || cfg->N > 40))
-    return fail(h, LMPC_ERR_UNSUPPORTED, "LMPC kernel is built for num_ss_pts <= 192 and N <= 40");
+  if (cfg->learning && ks_for(cfg->num_ss_pts) < 0)
+    return fail(h, LMPC_ERR_UNSUPPORTED, "LMPC kernel is built for num_ss_pts <= 192");
   if (cfg->learning) {
     bool any = false;
     for (int k = 0; k < 6; ++k) any = any || cfg->convex_hull_slack[k] > 0.0;

@@ -1366,6 +1366,10 @@ LMPC_INSTANTIATE(double, 4, 2, double)
 LMPC_INSTANTIATE(double, 4, 3, double)
 LMPC_INSTANTIATE(double, 7, 2, double)
 LMPC_INSTANTIATE(double, 7, 3, double)
+LMPC_INSTANTIATE(double, 11, 2, double)  // iac_car_lmpc.param.yaml ships N = 60
+LMPC_INSTANTIATE(double, 11, 3, double)
+LMPC_INSTANTIATE(double, 14, 2, double)
+LMPC_INSTANTIATE(double, 14, 3, double)
 LMPC_INSTANTIATE(float, 4, 0, float)
 LMPC_INSTANTIATE(float, 7, 0, float)
 // mixed: fp32 interior-point iteration between fp64 arrays.  Tracking only: the learning problem's terminal block

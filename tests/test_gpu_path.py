@@ -505,9 +505,10 @@ def test_horizons_at_the_row_layout_boundaries_match_the_twin(pkg, N):
     assert np.array_equal(out["X_optm"][:, 0, :], inp["x_ic"])          # x_0 = x_ic (racing_mpc.cpp:200-201)
 
 
-@pytest.mark.parametrize("N,n_laps", [(10, 3), (30, 3), (40, 5)])
+@pytest.mark.parametrize("N,n_laps", [(10, 3), (30, 3), (40, 5), (60, 3), (80, 5)])
 def test_lmpc_at_other_horizons_matches_the_twin(pkg, N, n_laps):
-    """The learning problem away from N = 20: KQ = 2 -> 4, 7 and both safe-set sizes (96 / 160 points)."""
+    """The learning problem away from N = 20: every row layout (iac_car_lmpc.param.yaml ships N = 60) and both safe-set
+    sizes (96 / 160 points)."""
     import lmpc_scenario as LS
     import torch
 
@@ -528,7 +529,12 @@ def test_lmpc_at_other_horizons_matches_the_twin(pkg, N, n_laps):
     ok = (o["status"] == 0) & (twin["status"] == 0)
     assert np.abs(o["iters"][ok] - twin["iters"][ok]).max() <= 1
     e = np.abs((o["X_optm"] - twin["X_optm"]) / P.SCALE_X[:, None, None]).max(axis=(0, 1))[ok]
-    assert np.percentile(e, 90) < TOL_TWIN and e.max() < TOL_DEGENERATE
+    if N <= 60:       # the shipped horizons (barc_lmpc 40, iac_car_lmpc 60)
+        assert np.percentile(e, 90) < TOL_TWIN and e.max() < TOL_DEGENERATE
+    else:             # N = 80: two seconds of an open-loop unstable model in one recursion; kernel and twin agree to
+        #               1e-8 on most problems and both drift to 1e-3 .. 1e-2 from the dense optimum on a few
+        #               (scratch/lmpc_n80_check.py, DESIGN.md "Numerics")
+        assert np.median(e) < 1e-6 and np.percentile(e, 75) < TOL_TWIN and e.max() < 5e-2
     lam = o["convex_combi_optm"][:, ok]
     assert np.abs(lam.sum(0) - 1.0).max() < 1e-8 and lam.min() > -1e-10
 
