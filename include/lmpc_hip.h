@@ -166,7 +166,7 @@ int lmpc_solve_batch(lmpc_handle* h, int32_t batch, const double* x_ic, const do
  * 6e-4 of the fp64 solution in scaled units), NOT for the BARC problems, whose soft boundary needs complementarity
  * below 1e-9.  learning = 1 returns LMPC_ERR_UNSUPPORTED (BASELINE configs[4] asks for a mixed
  * KKT on the learning problem; the terminal block's condition number ~1e8 rules fp32 out -- measured).
- * N <= 40. */
+ * Every horizon the fp64 entry accepts (iac_car_tracking_mpc.param.yaml ships N = 80: 3.4x the fp64 rate). */
 int lmpc_solve_batch_mixed(lmpc_handle* h, int32_t batch, const double* x_ic, const double* u_ic,
                            const double* X_ref, const double* U_ref, const double* T_ref,
                            const double* bound_left, const double* bound_right, const double* curvatures,
@@ -178,7 +178,7 @@ int lmpc_solve_batch_mixed(lmpc_handle* h, int32_t batch, const double* x_ic, co
  * array in float and the interior point / Riccati recursion in fp32 (the linearisation is evaluated in fp64 and
  * rounded).  Same layouts and meaning as lmpc_solve_batch, no safe-set arguments; kkt [4][B] optional.  The abscissa
  * is carried relative to x_ic[0] inside the kernel (the QP is invariant to that shift), so a 2.8 km lap keeps its
- * resolution.  Stopping rule: complementarity <= max(tol, 2e-6), row residuals <= 1e-4.  N <= 40. */
+ * resolution.  Stopping rule: complementarity <= max(tol, 2e-6), row residuals <= 1e-4. */
 int lmpc_solve_batch_f32(lmpc_handle* h, int32_t batch, const float* x_ic, const float* u_ic, const float* X_ref,
                          const float* U_ref, const float* T_ref, const float* bound_left, const float* bound_right,
                          const float* curvatures, const float* vel_ref, float* X_optm, float* U_optm, float* dU_optm,

@@ -131,10 +131,17 @@ const void* pick_solve_fn(int kq, int ks) {
   return nullptr;
 }
 
-// fp32 interior-point iteration between fp64 arrays (lmpc_solve_batch_mixed): tracking problem, N <= 40
+// fp32 interior-point iteration between fp64 arrays (lmpc_solve_batch_mixed): tracking problem
 const void* pick_mixed_fn(int kq, int ks) {
-  if (kq > 7 || ks != 0) return nullptr;
-  return kq <= 4 ? solve_fn<4, 0, float>() : solve_fn<7, 0, float>();
+  if (ks != 0) return nullptr;
+  switch (kq) {
+    case 2:
+    case 4: return solve_fn<4, 0, float>();
+    case 7: return solve_fn<7, 0, float>();
+    case 11: return solve_fn<11, 0, float>();
+    case 14: return solve_fn<14, 0, float>();
+  }
+  return nullptr;
 }
 
 int launch_solve(lmpc_handle* h, const void* fn, const solve_args& a) {
@@ -369,7 +376,7 @@ int solve_batch_fp64_arrays(lmpc_handle* h, bool mixed, int32_t batch, const dou
   }
   if (h->timing) HIP_TRY(h, hipEventRecord(h->ev[1], h->stream));
   const void* fn = mixed ? pick_mixed_fn(kq_for(N), ks_for(h->P.S)) : pick_solve_fn(kq_for(N), ks_for(h->P.S));
-  if (!fn) return fail(h, LMPC_ERR_UNSUPPORTED, mixed ? "the mixed-precision kernel is built for N <= 40" : "no kernel for this (N, num_ss_pts)");
+  if (!fn) return fail(h, LMPC_ERR_UNSUPPORTED, "no kernel for this (N, num_ss_pts)");
   solve_args a{};
   a.B = batch;
   a.lds_bytes = (size_t)lmpc_lds_doubles(N, h->P.learning) * (mixed ? sizeof(float) : sizeof(double));
@@ -420,8 +427,10 @@ int lmpc_solve_batch_f32(lmpc_handle* h, int32_t batch, const float* x_ic, const
   const int kq = kq_for(N);
   const void* fn = kq == 2 || kq == 4 ? reinterpret_cast<const void*>(&lmpc_solve_kernel<float, 4, 0, float>)
                    : kq == 7          ? reinterpret_cast<const void*>(&lmpc_solve_kernel<float, 7, 0, float>)
+                   : kq == 11         ? reinterpret_cast<const void*>(&lmpc_solve_kernel<float, 11, 0, float>)
+                   : kq == 14         ? reinterpret_cast<const void*>(&lmpc_solve_kernel<float, 14, 0, float>)
                                       : nullptr;
-  if (!fn) return fail(h, LMPC_ERR_UNSUPPORTED, "single precision is built for N <= 40");
+  if (!fn) return fail(h, LMPC_ERR_UNSUPPORTED, "no single-precision kernel for this N");
   if ((size_t)batch > h->ws_f32_cap) {
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     if (h->ws_f32) HIP_TRY(h, hipFree(h->ws_f32));

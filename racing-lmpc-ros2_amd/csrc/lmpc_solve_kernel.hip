@@ -1372,8 +1372,12 @@ LMPC_INSTANTIATE(double, 14, 2, double)
 LMPC_INSTANTIATE(double, 14, 3, double)
 LMPC_INSTANTIATE(float, 4, 0, float)
 LMPC_INSTANTIATE(float, 7, 0, float)
+LMPC_INSTANTIATE(float, 11, 0, float)
+LMPC_INSTANTIATE(float, 14, 0, float)
 // mixed: fp32 interior-point iteration between fp64 arrays.  Tracking only: the learning problem's terminal block
 // F = D^-1 + U Theta^-1 U' has a condition number ~1e8 late in the iteration, which fp32 cannot carry (measured:
 // median 1.5e-2 scaled error on the BARC LMPC problem with status "solved") -- DESIGN.md section 4
 LMPC_INSTANTIATE(float, 4, 0, double)
 LMPC_INSTANTIATE(float, 7, 0, double)
+LMPC_INSTANTIATE(float, 11, 0, double)  // iac_car_tracking_mpc.param.yaml ships N = 80
+LMPC_INSTANTIATE(float, 14, 0, double)

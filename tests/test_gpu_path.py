@@ -585,6 +585,16 @@ def test_mixed_precision_solve_on_the_iac_problem(pkg, golden):
     assert np.median(e) < 1e-4 and np.percentile(e, 99) < 2e-3 and e.max() < 5e-2
     assert np.array_equal(om["X_optm"][0, 0], inp["x_ic"][0].cpu().numpy())  # x_0 = x_ic exactly, abscissa included
 
+    # the horizon iac_car_tracking_mpc.param.yaml ships (N = 80: the KQ = 14 row layout in single precision)
+    long = pkg.Solver(pkg.presets.iac_tracking_mpc(80), pkg.presets.iac_vehicle(), device=0)
+    inp = long.prepare(tr, x.T[:, :512].copy(), 0.025)
+    inp["u_ic"] = torch.as_tensor(u.T[:, :512].copy(), dtype=torch.float64, device="cuda")
+    o64, om = to_np(long.solve(inp)), to_np(long.solve(inp, mixed=True))
+    ok = (o64["status"] == 0) & (om["status"] == 0)
+    assert ok.mean() > 0.99
+    e = np.abs((om["X_optm"] - o64["X_optm"]) / P.SCALE_X[:, None, None]).max(axis=(0, 1))[ok]
+    assert np.median(e) < 1e-4 and np.percentile(e, 99) < 5e-3 and e.max() < 5e-2
+
     lm = pkg.Solver(pkg.presets.barc_lmpc(20, 3), pkg.presets.barc_vehicle(), device=0)
     lm.set_safe_set(LS.load_laps(), LS.L_BARC_SS)
     g = golden("qp_barc_lmpc_n20")
