@@ -304,6 +304,16 @@ def main():
             lin_ms.append(a)
             sol_ms.append(b)
         solver.enable_timing(False)
+        ss_ms = []
+        if lmpc:  # the safe-set kernel alone (both kernels timed separately and together)
+            for k in range(60):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                solver.ss_query(query)
+                e1.record()
+                e1.synchronize()
+                if k >= 10:
+                    ss_ms.append(e0.elapsed_time(e1))
         # one car: the latency a single controller sees against its 25 ms period
         lat1 = []
         if not lmpc and not args.no_batch1:
@@ -345,7 +355,8 @@ def main():
             "latency_samples": len(lat), "value_one_stream": one_stream_value,
             "batch1_solve_ms": {"p50": float(np.percentile(lat1, 50)), "p99": float(np.percentile(lat1, 99)), "control_period_ms": 25.0} if lat1 else None,
             "solved_fraction": float((st == 0).mean()), "mean_ipm_iters": float(iters.mean()),
-            "kernels_ms": {"linearize": float(np.mean(lin_ms)), "qp_solve": sol_avg},
+            "kernels_ms": {"linearize": float(np.mean(lin_ms)), "qp_solve": sol_avg,
+                           **({"ss_query": float(np.mean(ss_ms))} if ss_ms else {})},
             "launch": ({**solver.launch_info(), "lds_bytes_per_problem": solver.launch_info()["lds_bytes_per_problem"] // 2,
                         "resident_problems_per_cu": None, "note": "fp32 records are half the fp64 size"} if (f32 or mixed) else solver.launch_info()),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -356,6 +367,15 @@ def main():
                                  "FP64-VALU issue / LDS-pipeline bound (DESIGN.md), HBM fraction is reported as required",
                          "engines": None if (lmpc or N != 20 or B != 4096) else engine_utilisation(sol_avg)},
         }
+        if ss_ms:
+            # safe-set query kernel: per query 2 doubles in, 7 S doubles out (ss_x [6][S], ss_j [S]); the lap store
+            # (5 laps x ~1320 unrolled points x 2 coordinates) is read once per query from L2, not from HBM
+            S_pts = cfgd["num_ss_pts"]
+            q_bytes = (2 + 7 * S_pts) * 8
+            t_ss = float(np.mean(ss_ms)) * 1e-3
+            res["ss_query_kernel"] = {"ms": t_ss * 1e3, "queries_per_s": B / t_ss, "algorithmic_bytes_per_query": q_bytes,
+                                      "achieved_GBps": q_bytes * B / t_ss / 1e9, "frac_of_hbm_peak": q_bytes * B / t_ss / 1e9 / HBM_PEAK_GBS,
+                                      "note": "one wave per query: 3n distances per lap in LDS, K rounds of a wave-wide arg-min per lap"}
         if not args.no_cpu_baseline and world == 1 and not lmpc and not iac:
             res["cpu_baseline"] = cpu_baseline(pkg, N, B)
         print(json.dumps(res))

@@ -10,8 +10,11 @@
 //   3n-point unrolled lap [x - L e_0, x, x + L e_0] nearest to the query in (s, e_y), nearest
 //   first (ties: lower unrolled index; CGAL's order for exact ties is unspecified); J of
 //   unrolled index c = rep * n + j is (n-1-j) + (1-rep)(n-1)  (:122,128).
-// The brute-force scan replaces CGAL's kd-tree: 3n distances per lap live in LDS, each lane keeps
-// the best of its strided share, and K rounds of a wave-wide arg-min pick the neighbours in order.
+// The brute-force scan replaces CGAL's kd-tree: one pass over the 3n unrolled points of a lap leaves each lane with
+// the two nearest of its strided share (all distances stay in LDS); the 64 lane minima are sorted across the wave
+// (bitonic network, lexicographic in (distance, index)) and, unless some lane's runner-up beats the K-th of them, lanes
+// 0..K-1 hold the lap's neighbours nearest first and write their points in parallel.  When a lane owns two winners
+// (a lap revisiting a place within 64 samples) K rounds of a wave-wide arg-min pick them one at a time instead.
 #include <hip/hip_runtime.h>
 
 #include <limits.h>
@@ -45,24 +48,77 @@ __global__ __launch_bounds__(64) void lmpc_ss_query_kernel(int B, int n_laps, in
     const int n = npts[l], n3 = 3 * n;
     const double* xl = x + (size_t)off[l] * 6;
     __syncthreads();
+    // one pass: distance of every unrolled point of the lane's strided share, kept in LDS for the (rare) rescan, and
+    // the share's two smallest in registers.  Neighbours are close in index and the share is strided by 64, so a lane
+    // seldom owns more than one of the K winners: its runner-up is promoted without touching LDS again.
+    double bestd = INFINITY, secd = INFINITY;
+    int besti = INT_MAX, seci = INT_MAX;  // seci: INT_MAX = the share has no further point, -1 = not known (rescan)
     for (int c = lane; c < n3; c += 64) {
       const int rep = c / n, j = c - rep * n;
       const double s = xl[(size_t)j * 6] + (rep - 1) * Lt;
       const double ds = s - qs, de = xl[(size_t)j * 6 + 1] - qe;
-      dist[c] = ds * ds + de * de;
-    }
-    __syncthreads();
-    double bestd = INFINITY;
-    int besti = INT_MAX;
-    for (int c = lane; c < n3; c += 64) {
-      const double d = dist[c];
+      const double d = ds * ds + de * de;
+      dist[c] = d;
       if (d < bestd) {
+        secd = bestd;
+        seci = besti;
         bestd = d;
         besti = c;
+      } else if (d < secd) {
+        secd = d;
+        seci = c;
       }
     }
-    const int take = K < n3 ? K : n3;
-    for (int q = 0; q < take && tot < S; ++q, ++tot) {
+    int take = K < n3 ? K : n3;
+    if (take > S - tot) take = S - tot;
+    // Fast path.  Sort the 64 lane minima (bitonic network over the lanes, lexicographic in (distance, index)): if no
+    // lane's runner-up beats the take-th of them, the first `take` lanes now hold the lap's neighbours nearest first,
+    // and every lane writes its own point.  Otherwise (a lane owning two of the winners: laps with repeated or
+    // crawling samples) the rounds below pick them one at a time.
+    if (take <= 64) {
+      double d = bestd;
+      int i = besti;
+#pragma unroll
+      for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+        for (int jj = k >> 1; jj > 0; jj >>= 1) {
+          const double od = __shfl_xor(d, jj, 64);
+          const int oi = __shfl_xor(i, jj, 64);
+          const bool other_less = od < d || (od == d && oi < i);
+          const bool keep_min = ((lane & jj) == 0) == ((lane & k) == 0);
+          if (keep_min ? other_less : !other_less) {
+            d = od;
+            i = oi;
+          }
+        }
+      }
+      const double td = __shfl(d, take - 1, 64);
+      const int ti = __shfl(i, take - 1, 64);
+      const bool beaten = seci >= 0 && seci != INT_MAX && (secd < td || (secd == td && seci < ti));
+      if (!__any(beaten) && ti != INT_MAX) {
+        const bool mine = lane < take;
+        const int ii = mine ? i : 0;
+        const int rep = ii / n, j = ii - rep * n;
+        const double jv = (double)(n - 1 - j) + (1 - rep) * (double)(n - 1);
+        if (tot == 0) j0 = __shfl(jv, 0, 64);
+        if (mine) {
+#pragma unroll
+          for (int k = 0; k < 6; ++k)
+            ss_x[((size_t)k * S + tot + lane) * B + b] = xl[(size_t)j * 6 + k] + (k == 0 ? (rep - 1) * Lt : 0.0);
+          ss_j[(size_t)(tot + lane) * B + b] = jv - j0;
+        }
+        // the last point written, as the padding below wants it: component k on lane k < 6, J - J0 on lane 6
+        const int il = __shfl(i, take - 1, 64);
+        const int repl = il / n, jl = il - repl * n;
+        if (lane < 6)
+          last = xl[(size_t)jl * 6 + lane] + (lane == 0 ? (repl - 1) * Lt : 0.0);
+        else if (lane == 6)
+          last = ((double)(n - 1 - jl) + (1 - repl) * (double)(n - 1)) - j0;
+        tot += take;
+        continue;
+      }
+    }
+    for (int q = 0; q < take; ++q, ++tot) {
       // wave-wide lexicographic arg-min of (distance, unrolled index) on the VALU: four row_ror steps give every
       // lane of a 16-lane row the row's winner, row_bcast15 / row_bcast31 fold the rows into lane 63
       double d = bestd;
@@ -85,15 +141,27 @@ __global__ __launch_bounds__(64) void lmpc_ss_query_kernel(int B, int n_laps, in
         last = jv - j0;
         ss_j[(size_t)tot * B + b] = last;
       }
-      if ((i & 63) == lane) {  // the winner's owner retires it and rescans its share
+      if ((i & 63) == lane) {  // the winner's owner retires it and moves on to its runner-up
         dist[i] = INFINITY;
-        bestd = INFINITY;
-        besti = INT_MAX;
-        for (int c = lane; c < n3; c += 64) {
-          const double dd = dist[c];
-          if (dd < bestd) {
-            bestd = dd;
-            besti = c;
+        if (seci >= 0) {
+          bestd = secd;
+          besti = seci;
+          secd = INFINITY;
+          seci = besti == INT_MAX ? INT_MAX : -1;
+        } else {  // second win in a row without a known runner-up: rescan the share for its two smallest
+          bestd = secd = INFINITY;
+          besti = seci = INT_MAX;
+          for (int c = lane; c < n3; c += 64) {
+            const double dd = dist[c];
+            if (dd < bestd) {
+              secd = bestd;
+              seci = besti;
+              bestd = dd;
+              besti = c;
+            } else if (dd < secd) {
+              secd = dd;
+              seci = c;
+            }
           }
         }
       }

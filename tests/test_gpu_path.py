@@ -173,6 +173,40 @@ def test_ss_query_matches_oracle(pkg):
         assert np.array_equal(ss_j, rj)
 
 
+def test_ss_query_awkward_laps_match_oracle(pkg):
+    """Laps that defeat the kernel's fast path (the 64 lane minima sorted across the wave): a lap that passes the same
+    place every 64 samples, so one lane owns several of the winners; as many neighbours per lap as lanes (K = 64); a
+    lap shorter than K; exact distance ties."""
+    rng = np.random.default_rng(12)
+    L = 10.0
+
+    def lap(n, s):
+        x = np.zeros((n, 6))
+        x[:, 0] = s
+        x[:, 1] = 0.05 * np.sin(np.arange(n) * 0.7)
+        x[:, 2:] = rng.normal(size=(n, 4))
+        return x
+    n = 448
+    looping = lap(n, 0.5 + 0.01 * (np.arange(n) % 64) + 1e-4 * (np.arange(n) // 64))   # revisits every 64 samples
+    tied = lap(200, np.repeat(np.linspace(0.0, 9.9, 100), 2))                         # pairs of identical (s, e_y)
+    tied[:, 1] = 0.0
+    short = lap(20, np.linspace(0.0, 9.0, 20))
+    normal = lap(400, np.linspace(0.0, 9.99, 400))
+    q = np.stack([rng.uniform(-1.0, L + 1.0, 300), rng.uniform(-0.2, 0.2, 300)])
+    q[:, :40] = np.stack([tied[::5, 0], np.zeros(40)])                                  # queries on top of the tied points
+    for laps, K, S in (([normal, looping], 32, 64), ([looping, normal, looping], 32, 96), ([normal, tied], 32, 64),
+                       ([normal, short, looping], 32, 96), ([looping, normal], 64, 128), ([short], 32, 32)):
+        cfg = pkg.presets.barc_lmpc(20, 3)
+        cfg.update(num_ss_pts=S, num_ss_pts_per_lap=K, max_lap_stored=len(laps))
+        solver = pkg.Solver(cfg, pkg.presets.barc_vehicle(), device=0)
+        solver.set_safe_set(laps, L)
+        ss_x, ss_j, nf = (t.cpu().numpy() for t in solver.ss_query(q))
+        rx, rj, rn = cbind.ss_query_batch(laps, L, S, K, q)
+        assert np.array_equal(nf, rn), (K, S)
+        assert np.array_equal(ss_j, rj), (K, S)
+        assert np.array_equal(ss_x, rx), (K, S)
+
+
 def test_lmpc_solve_matches_golden_and_twin(pkg, golden):
     """BASELINE config 3 path: safe-set query kernel -> LMPC QP kernel, against the certified optimum."""
     import lmpc_scenario as LS
