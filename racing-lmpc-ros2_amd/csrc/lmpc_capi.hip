@@ -633,7 +633,7 @@ int lmpc_ss_query_batch(lmpc_handle* h, int32_t batch, const double* query, doub
   if (lds > 160 * 1024) return fail(h, LMPC_ERR_UNSUPPORTED, "lap longer than 6826 samples");
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&lmpc_ss_query_kernel),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(lmpc_ss_query_kernel, dim3(batch), dim3(64), lds, h->stream, batch, h->ss_laps, h->cfg.num_ss_pts,
+  hipLaunchKernelGGL(lmpc_ss_query_kernel, dim3(8 * ((batch + 7) / 8)), dim3(64), lds, h->stream, batch, h->ss_laps, h->cfg.num_ss_pts,
                      h->cfg.num_ss_pts_per_lap, h->ss_npts, h->ss_off, h->ss_x, h->ss_L, query, ss_x, ss_j, n_found,
                      (double*)nullptr);
   HIP_TRY(h, hipGetLastError());
@@ -658,7 +658,7 @@ int lmpc_ss_query_host(lmpc_handle* h, const double* query, double* ss_x, double
   if (lds > 160 * 1024) return fail(h, LMPC_ERR_UNSUPPORTED, "lap longer than 6826 samples");
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&lmpc_ss_query_kernel),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(lmpc_ss_query_kernel, dim3(1), dim3(64), lds, h->stream, 1, h->ss_laps, S, h->cfg.num_ss_pts_per_lap,
+  hipLaunchKernelGGL(lmpc_ss_query_kernel, dim3(8), dim3(64), lds, h->stream, 1, h->ss_laps, S, h->cfg.num_ss_pts_per_lap,
                      h->ss_npts, h->ss_off, h->ss_x, h->ss_L, d, d + 2, d + 2 + 6 * (size_t)S, di, d + 2 + 7 * (size_t)S);
   HIP_TRY(h, hipGetLastError());
   std::vector<double> host(nd);

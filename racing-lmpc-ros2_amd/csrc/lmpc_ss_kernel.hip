@@ -39,7 +39,11 @@ __global__ __launch_bounds__(64) void lmpc_ss_query_kernel(int B, int n_laps, in
                                                            double* __restrict__ ss_j, int* __restrict__ n_found, double* __restrict__ j0_out) {
 #pragma clang fp contract(off)
   extern __shared__ __attribute__((aligned(16))) double dist[];
-  const int b = blockIdx.x, lane = threadIdx.x;
+  // XCD-aware query assignment (as in the QP kernel): consecutive workgroups go round-robin to the 8 XCDs, so workgroup
+  // w takes query (w mod 8) * ceil(B / 8) + w / 8 and the 8-byte results of neighbouring queries, which share 64-byte
+  // lines of the [field][point][batch] arrays, are merged in one XCD's L2 instead of reaching HBM as partial lines
+  const int b = (int)(blockIdx.x & 7) * ((B + 7) >> 3) + (int)(blockIdx.x >> 3), lane = threadIdx.x;
+  if (b >= B) return;
   const double qs = query[b], qe = query[(size_t)B + b];
   int tot = 0;
   double last = 0.0;  // lane k < 6: component k of the last point written; lane 6: its J - J0
