@@ -210,6 +210,7 @@ def main():
         for o in outs:
             o["convex_combi_optm"] = torch.zeros((cfgd["num_ss_pts"], B), dtype=torch.float64, device=dev)
         # query = last knot of the abscissa-aligned reference (racing_mpc.cpp:219-223,249-254)
+        ss_bufs = [solver.ss_query(inp["X_ref"][:2, -1].contiguous()) for _ in outs]   # one result buffer set per output slot
         s_last, s0, L = inp["X_ref"][0, -1], inp["x_ic"][0], tr["L"]
         kk = (s0 - s_last).abs() + L / 2
         query = torch.stack([s_last + (kk - torch.fmod(kk, L)) * torch.sign(s0 - s_last), inp["X_ref"][1, -1]]).contiguous()
@@ -235,7 +236,7 @@ def main():
         if f32:
             sv.solve_f32(inp32, o)
         elif lmpc:
-            ss_x, ss_j, _ = sv.ss_query(query)
+            ss_x, ss_j, _ = sv.ss_query(query, out=ss_bufs[k % len(ss_bufs)])
             sv.solve(inp, o, ss_x=ss_x, ss_j=ss_j, mixed=mixed)
         else:
             sv.solve(inp, o, mixed=mixed)
@@ -309,7 +310,7 @@ def main():
             for k in range(60):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                solver.ss_query(query)
+                solver.ss_query(query, out=ss_bufs[0])
                 e1.record()
                 e1.synchronize()
                 if k >= 10:

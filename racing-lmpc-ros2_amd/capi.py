@@ -390,16 +390,21 @@ class Solver:
         self._check(rc, "lmpc_regress_batch")
         return A, Bm, g
 
-    def ss_query(self, query):
+    def ss_query(self, query, out=None):
+        """lmpc_ss_query_batch.  `out` = (ss_x [6][S][B], ss_j [S][B], n_found [B]) reuses the caller's buffers (the
+        kernel writes every entry of a query that found at least one point); otherwise zero-filled ones are allocated."""
         torch = self._torch
         self.use_current_stream()
         q = self._t(query)
         B = q.shape[1]
         S = int(self.config["num_ss_pts"])
         kw = dict(dtype=torch.float64, device=self.device)
-        ss_x = torch.zeros((6, S, B), **kw)
-        ss_j = torch.zeros((S, B), **kw)
-        nf = torch.zeros((B,), dtype=torch.int32, device=self.device)
+        if out is not None:
+            ss_x, ss_j, nf = out
+        else:
+            ss_x = torch.zeros((6, S, B), **kw)
+            ss_j = torch.zeros((S, B), **kw)
+            nf = torch.zeros((B,), dtype=torch.int32, device=self.device)
         rc = self.lib.lmpc_ss_query_batch(self._h, C.c_int32(B), _ptr(q), _ptr(ss_x), _ptr(ss_j), _ptr(nf))
         self._check(rc, "lmpc_ss_query_batch")
         return ss_x, ss_j, nf
