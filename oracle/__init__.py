@@ -21,5 +21,7 @@ oracle against.  What pins it instead:
   * the k-NN query is a brute-force sort (oracle/safe_set.py);
   * the reference's recorded BARC laps (its only data fixtures on this path,
     src/mpc/racing_mpc/test_data/barc_ss) are replayed through the dynamics as
-    a plausibility check (tests/test_oracle_dynamics.py).
+    a plausibility check (tests/test_oracle_dynamics.py);
+  * the parameter sets every test and bench line runs on (presets / oracle.params) are compared with the reference's
+    shipped *.param.yaml files whenever its checkout is present (tests/test_ros_params.py).
 """

@@ -166,3 +166,23 @@ def test_presets_equal_the_reference_shipped_files(pkg):
         params = rp.load_ros_params(REF_PARAM / "racing_mpc" / f"{name}.param.yaml")
         assert params["racing_mpc.n"] == n
         assert rp.mpc_config_from_params(params) == preset(n), name
+
+
+def test_oracle_parameter_sets_equal_the_package_presets(pkg):
+    """oracle.params (what the golden vectors and the twin run on) and presets.py (what the HIP path runs on) are two
+    transcriptions of the same files: field by field equal, so the check against the shipped YAML covers both."""
+    import dataclasses
+
+    import numpy as np
+    from oracle import params as OP
+
+    for a, b in ((OP.barc_vehicle(), pkg.presets.barc_vehicle()), (OP.iac_vehicle(), pkg.presets.iac_vehicle())):
+        for k, v in dataclasses.asdict(a).items():
+            assert v == b[k], k
+    for a, b in ((OP.barc_tracking_mpc(60), pkg.presets.barc_tracking_mpc(60)), (OP.barc_lmpc(40, 3), pkg.presets.barc_lmpc(40, 3)),
+                 (OP.barc_lmpc(20, 5), pkg.presets.barc_lmpc(20, 5)), (OP.iac_tracking_mpc(80), pkg.presets.iac_tracking_mpc(80))):
+        for k, v in dataclasses.asdict(a).items():
+            if isinstance(v, np.ndarray):
+                assert np.array_equal(v.ravel(), np.asarray(b[k], dtype=float).ravel()), k
+            else:
+                assert float(v) == float(b[k]), k
