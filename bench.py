@@ -17,6 +17,10 @@ from pathlib import Path
 
 import numpy as np
 
+# RCCL / CUDA-tensor sharing between the ranks of one node needs dmabuf IPC on this driver (the launcher exports it
+# already; kept here so a bare `python -m torch.distributed.run ... bench.py` works too)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 from __graft_entry__ import load_package  # noqa: E402
