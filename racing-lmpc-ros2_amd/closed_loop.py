@@ -10,8 +10,16 @@ from __future__ import annotations
 
 
 def run(solver, track: dict, x0, u0, steps: int, dt: float = 0.025, n_sub: int = 2, speed_scale: float = 0.9,
-        record_every: int = 0, restart_failed: bool = True):
-    """x0 [6][B], u0 [2][B] (torch, device).  Returns final state and statistics (torch tensors on device)."""
+        record_every: int = 0, restart_failed: bool = True, graph: bool = False):
+    """x0 [6][B], u0 [2][B] (torch, device).  Returns final state and statistics (torch tensors on device).
+
+    One control period = solve, apply the first input of the plan (on failure: of the shifted previous plan,
+    racing_mpc_node.cpp:322-332), plant step, statistics, warm-start shift; a car whose QP failed is re-prepared from a
+    cold start at its current state, as re-launching the node would (racing_mpc_node.cpp:210-235) -- a stale plan would
+    make the next QP fail too.  Nothing in a period reads device data on the host.
+
+    graph=True captures the period once as a HIP graph and replays it: a period is ~25 small launches around the QP
+    kernel, and eager dispatch (~2 ms of host time) costs more than the 0.9 ms the GPU needs for them."""
     import torch
 
     trk = solver.device_track(track)
@@ -25,33 +33,56 @@ def run(solver, track: dict, x0, u0, steps: int, dt: float = 0.025, n_sub: int =
     worst_excess = torch.zeros(B, dtype=torch.float64, device=x.device)  # max lateral excursion beyond the track edge
     n_fail = torch.zeros(B, dtype=torch.int64, device=x.device)
     half_b = float(solver.vehicle["b"]) / 2.0
+    keys = ("X_ref", "U_ref", "T_ref", "bound_left", "bound_right", "curvatures", "vel_ref")
     trace = []
-    for k in range(steps):
+
+    def period():
         inp["x_ic"] = x
         inp["u_ic"] = u_prev
         solver.solve(inp, out)
         ok = out["status"] == 0
-        n_fail += (~ok).to(torch.int64)
-        # first input of the plan; on failure the shifted previous plan's first input (racing_mpc_node.cpp:322-332)
+        n_fail.add_((~ok).to(torch.int64))
         u_apply = torch.where(ok[None, :], out["U_optm"][:, 0, :], inp["U_ref"][:, 0, :]).contiguous()
         s_before = x[0].clone()
         solver.plant_step(trk, x, u_apply, dt / n_sub, n_sub)
         ds = x[0] - s_before
-        dist += torch.where(ds < -L / 2, ds + L, ds)
-        bl = inp["bound_left"][0]
-        br = inp["bound_right"][0]
-        exc = torch.maximum(x[1] + half_b - bl, br - (x[1] - half_b))
-        worst_excess = torch.maximum(worst_excess, exc)
-        u_prev = u_apply
-        inp = solver.shift(trk, inp, out, dt, speed_scale=speed_scale)
-        if restart_failed and bool((~ok).any()):
-            # a car whose QP failed keeps a stale plan, and a stale plan makes the next QP fail too; restart those cars
-            # from a cold start at their current state, as re-launching the node would (racing_mpc_node.cpp:210-235)
+        dist.add_(torch.where(ds < -L / 2, ds + L, ds))
+        exc = torch.maximum(x[1] + half_b - inp["bound_left"][0], inp["bound_right"][0] - (x[1] - half_b))
+        torch.maximum(worst_excess, exc, out=worst_excess)
+        u_prev.copy_(u_apply)
+        nxt = solver.shift(trk, inp, out, dt, speed_scale=speed_scale)
+        if restart_failed:
             cold = solver.prepare(trk, x, dt, speed_scale=speed_scale)
-            for key in ("X_ref", "U_ref", "T_ref", "bound_left", "bound_right", "curvatures", "vel_ref"):
-                inp[key] = torch.where(ok, inp[key], cold[key])
-        if record_every and k % record_every == 0:
-            trace.append(x.clone())
+            for key in keys:
+                inp[key].copy_(torch.where(ok, nxt[key], cold[key]))
+        else:
+            for key in keys:
+                inp[key].copy_(nxt[key])
+
+    if not graph:
+        for k in range(steps):
+            period()
+            if record_every and k % record_every == 0:
+                trace.append(x.clone())
+    else:
+        if record_every:
+            raise ValueError("record_every is not available with graph=True")
+        done = 0
+        side = torch.cuda.Stream(device=x.device)
+        side.wait_stream(torch.cuda.current_stream(x.device))
+        with torch.cuda.stream(side):           # warm-up outside the capture: workspace allocation, lazy initialisation
+            if steps > 0:
+                period()
+                done = 1
+        torch.cuda.current_stream(x.device).wait_stream(side)
+        if steps > done:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                period()
+            done += 1                               # (the capture does not execute; the first replay is that period)
+            g.replay()
+            for _ in range(steps - done):
+                g.replay()
     return {"x": x, "distance": dist, "worst_excess": worst_excess, "n_fail": n_fail, "trace": trace}
 
 

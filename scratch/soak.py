@@ -12,7 +12,7 @@ s0 = rng.uniform(0, tab["L"], B)
 x0 = np.stack([s0, rng.uniform(-0.08, 0.08, B), rng.normal(0, 0.03, B), rng.uniform(0.6, 0.95, B) * np.interp(s0, np.arange(1024) * tab["L"] / 1024, tab["vel"]), np.zeros(B), np.zeros(B)])
 t0 = time.time()
 steps = int(3.2 * tab["L"] / 3.0 / 0.025)
-res = pkg.closed_loop.run(solver, tab, torch.as_tensor(x0, device="cuda"), torch.zeros((2, B), dtype=torch.float64, device="cuda"), steps=steps, speed_scale=0.9)
+res = pkg.closed_loop.run(solver, tab, torch.as_tensor(x0, device="cuda"), torch.zeros((2, B), dtype=torch.float64, device="cuda"), steps=steps, speed_scale=0.9, graph=True)
 torch.cuda.synchronize()
 dt = time.time() - t0
 d = res["distance"].cpu().numpy(); e = res["worst_excess"].cpu().numpy(); f = res["n_fail"].cpu().numpy()

@@ -294,6 +294,25 @@ def test_closed_loop_two_laps_inside_the_track(pkg):
     assert nf.mean() < 0.01 * 1100, nf.mean()   # < 1 % failed solves per car
 
 
+def test_closed_loop_as_a_hip_graph_equals_the_eager_loop(pkg):
+    """closed_loop.run(graph=True): the control period captured once as a HIP graph (solve, plant, statistics, shift,
+    cold restart of failed cars) and replayed -- bit-identical to launching the same period eagerly."""
+    import torch
+    tr = pkg.workloads.synthetic_track("barc")
+    rng = np.random.default_rng(5)
+    B = 256
+    x0 = np.stack([rng.uniform(0, tr["L"], B), rng.uniform(-0.1, 0.1, B), rng.normal(0, 0.03, B),
+                   rng.uniform(1.2, 2.5, B), np.zeros(B), np.zeros(B)])
+    res = []
+    for graph in (False, True):
+        solver = pkg.Solver(pkg.presets.barc_tracking_mpc(20), pkg.presets.barc_vehicle(), device=0)
+        res.append(pkg.closed_loop.run(solver, tr, torch.as_tensor(x0, device="cuda"),
+                                       torch.zeros((2, B), dtype=torch.float64, device="cuda"), steps=120, graph=graph))
+    for key in ("x", "distance", "worst_excess", "n_fail"):
+        assert torch.equal(res[0][key], res[1][key]), key
+    assert float(res[1]["distance"].min()) > 0.5
+
+
 def test_lmpc_experiment_lap_times_improve(pkg):
     """The reference's LMPC experiment (sim_barc_lmpc) on the device: two laps under the tracking MPC fill the safe
     set through SafeSetRecorder / SafeSetManager, then the learning MPC drives 64 cars sharing car 0's set, every
