@@ -713,3 +713,19 @@ def test_bench_two_ranks_preflight_on_one_gpu():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 6 and d["scaling"] == "weak" and d["value"] > 1e5
     assert d["solved_fraction"] > 0.99 and "cpu_baseline" not in d
+
+
+def test_solver_built_from_parameter_files_solves_like_the_preset(pkg, golden, tmp_path):
+    """ROS 2 parameter files (this repository's own, in the reference's format) -> ros_params -> lmpc_create: the same
+    solution, bit for bit, as the preset the golden vectors were generated with."""
+    import test_ros_params as T
+
+    g = golden("qp_barc_tracking_n20")
+    f = tmp_path / "mpc.param.yaml"
+    f.write_text(T.mpc_text(pkg.presets.barc_tracking_mpc(60), 60, T.LOAD))
+    params = pkg.ros_params.load_ros_params(f, *T.vehicle_files(tmp_path, pkg.presets.barc_vehicle()))
+    a = pkg.Solver(pkg.ros_params.mpc_config_from_params(params, horizon=20), pkg.ros_params.vehicle_from_params(params), device=0)
+    b = pkg.Solver(pkg.presets.barc_tracking_mpc(20), pkg.presets.barc_vehicle(), device=0)
+    oa, ob = to_np(a.solve(g)), to_np(b.solve(g))
+    for k in ("X_optm", "U_optm", "dU_optm", "status", "iters"):
+        assert np.array_equal(oa[k], ob[k]), k
