@@ -34,3 +34,10 @@ for i in range(N - 2, -1, -1):
     if i % 10 == 0 or i > N - 6:
         cl = np.abs(np.linalg.eigvals(Ab - Bb @ K))
         print(f"i={i}: |P| {np.abs(Pm).max():.2e} cond(H) {np.linalg.cond(H):.1e} |K| {np.abs(K).max():.2e} closed-loop |eig| max {cl.max():.3f}  min eig P {np.linalg.eigvalsh(Pm).min():.2e}")
+
+# the unstable mode at stage 40: right / left eigenvectors and how the inputs reach it
+import scipy.linalg as sl
+w, vl, vr = sl.eig(A[40], left=True, right=True)
+k = int(np.argmax(np.abs(w)))
+print("eig", w[k], "right vec (s, ey, epsi, vx, vy, om)", np.real(vr[:, k]).round(3), "left vec", np.real(vl[:, k]).round(3))
+print("left' B (reach of u_lon, steer):", (np.real(vl[:, k]) @ B[40]).round(3), " left' B over stages 30..45:", [float(np.abs(np.real(sl.eig(A[i], left=True, right=False)[1][:, int(np.argmax(np.abs(sl.eig(A[i])[0])))]) @ B[i]).max().round(2)) for i in range(30, 46, 3)])
