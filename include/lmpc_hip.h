@@ -260,6 +260,14 @@ int lmpc_prepare_batch(lmpc_handle* h, int32_t batch, const lmpc_track* track, c
                        double* U_ref, double* T_ref, double* bound_left, double* bound_right,
                        double* curvatures, double* vel_ref);
 
+/* The same cold start for the problems whose last solve failed only (status[b] != 0), in place: the arrays of the
+ * others are left as they are.  What re-launching the node does for one car (racing_mpc_node.cpp:210-235), for a
+ * closed-loop batch that keeps going without a host round trip: call it on the output of lmpc_shift_batch.         */
+int lmpc_prepare_failed_batch(lmpc_handle* h, int32_t batch, const lmpc_track* track, const double* x_ic,
+                              const int32_t* status, double dt, double speed_scale, double speed_limit,
+                              double* X_ref, double* U_ref, double* T_ref, double* bound_left,
+                              double* bound_right, double* curvatures, double* vel_ref);
+
 /* Warm-start shift of RacingMPCNode::on_step_timer (racing_mpc_node.cpp:245-254, 261-292): the previous
  * solution moves one knot forward, the last input is repeated, the last state is rolled out with the model
  * and the references are re-sampled at the shifted abscissa.  Per problem, `status` (may be NULL) selects the

@@ -20,7 +20,7 @@ _ABI_SYMBOLS = ("lmpc_create", "lmpc_destroy", "lmpc_last_error", "lmpc_set_stre
                 "lmpc_prepare_batch", "lmpc_reserve", "lmpc_query_launch", "lmpc_enable_timing",
                 "lmpc_last_kernel_ms", "lmpc_query_residency", "lmpc_solve_host", "lmpc_shift_batch",
                 "lmpc_plant_step_batch", "lmpc_set_regression_laps", "lmpc_regress_batch", "lmpc_ss_query_host", "lmpc_solve_batch_f32",
-                "lmpc_solve_batch_mixed")
+                "lmpc_solve_batch_mixed", "lmpc_prepare_failed_batch")
 
 
 class LmpcError(RuntimeError):
@@ -198,6 +198,21 @@ class Solver:
         out["x_ic"] = x_ic
         out["L"] = float(track["L"])
         return out
+
+    def prepare_failed(self, track: dict, x_ic, status, inp: dict, dt: float, speed_scale: float = 1.0,
+                       speed_limit: float | None = None):
+        """lmpc_prepare_failed_batch: cold start, in place in `inp`, of the problems with status != 0."""
+        self.use_current_stream()
+        ct = self._ctrack(track)
+        if speed_limit is None:
+            speed_limit = float(self.config["x_max"][3])
+        x_ic = self._t(x_ic)
+        rc = self.lib.lmpc_prepare_failed_batch(self._h, C.c_int32(x_ic.shape[1]), C.byref(ct), _ptr(x_ic), _ptr(status),
+                                                C.c_double(dt), C.c_double(speed_scale), C.c_double(speed_limit),
+                                                *[_ptr(inp[k]) for k in ("X_ref", "U_ref", "T_ref", "bound_left",
+                                                                         "bound_right", "curvatures", "vel_ref")])
+        self._check(rc, "lmpc_prepare_failed_batch")
+        return inp
 
     def _ctrack(self, track: dict):
         tabs = {k: self._t(track[k]) for k in ("curvature", "bound_left", "bound_right", "vel")}

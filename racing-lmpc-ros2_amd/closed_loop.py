@@ -52,12 +52,9 @@ def run(solver, track: dict, x0, u0, steps: int, dt: float = 0.025, n_sub: int =
         u_prev.copy_(u_apply)
         nxt = solver.shift(trk, inp, out, dt, speed_scale=speed_scale)
         if restart_failed:
-            cold = solver.prepare(trk, x, dt, speed_scale=speed_scale)
-            for key in keys:
-                inp[key].copy_(torch.where(ok, nxt[key], cold[key]))
-        else:
-            for key in keys:
-                inp[key].copy_(nxt[key])
+            solver.prepare_failed(trk, x, out["status"], nxt, dt, speed_scale=speed_scale)
+        for key in keys:
+            inp[key].copy_(nxt[key])
 
     if not graph:
         for k in range(steps):

@@ -17,7 +17,7 @@
 
 template <bool WS_LAYOUT, typename io>
 __global__ void lmpc_linearize_kernel(lmpc_params, int, const io*, const io*, const io*, const io*, io*, io*, io*);
-__global__ void lmpc_prepare_kernel(lmpc_params, int, lmpc_track, const double*, double, double, double, double*,
+__global__ void lmpc_prepare_kernel(lmpc_params, int, lmpc_track, const double*, const int*, double, double, double, double*,
                                     double*, double*, double*, double*, double*, double*);
 __global__ void lmpc_shift_kernel(lmpc_params, int, lmpc_track, const double*, const double*, const double*,
                                   const double*, const int*, double, double, double, double*, double*, double*, double*,
@@ -523,20 +523,38 @@ int lmpc_solve_host(lmpc_handle* h, const double* x_ic, const double* u_ic, cons
   return LMPC_OK;
 }
 
-int lmpc_prepare_batch(lmpc_handle* h, int32_t batch, const lmpc_track* track, const double* x_ic, double dt,
-                       double speed_scale, double speed_limit, double* X_ref, double* U_ref, double* T_ref,
-                       double* bound_left, double* bound_right, double* curvatures, double* vel_ref) {
+namespace {
+int prepare_impl(lmpc_handle* h, const char* who, int32_t batch, const lmpc_track* track, const double* x_ic,
+                 const int32_t* status, double dt, double speed_scale, double speed_limit, double* X_ref, double* U_ref,
+                 double* T_ref, double* bound_left, double* bound_right, double* curvatures, double* vel_ref) {
   if (!h) return LMPC_ERR_ARGUMENT;
   if (batch < 0 || !track || !x_ic || !X_ref || !U_ref || !T_ref || !bound_left || !bound_right || !curvatures ||
       !vel_ref || !track->curvature || !track->bound_left || !track->bound_right || !track->vel || track->M < 2 ||
       !(track->L > 0.0) || !(dt > 0.0))
-    return fail(h, LMPC_ERR_ARGUMENT, "lmpc_prepare_batch: bad argument");
+    return fail(h, LMPC_ERR_ARGUMENT, std::string(who) + ": bad argument");
   if (batch == 0) return LMPC_OK;
   HIP_TRY(h, hipSetDevice(h->device));
   hipLaunchKernelGGL(lmpc_prepare_kernel, dim3((batch + 255) / 256), dim3(256), 0, h->stream, h->P, batch, *track, x_ic,
-                     dt, speed_scale, speed_limit, X_ref, U_ref, T_ref, bound_left, bound_right, curvatures, vel_ref);
+                     status, dt, speed_scale, speed_limit, X_ref, U_ref, T_ref, bound_left, bound_right, curvatures, vel_ref);
   HIP_TRY(h, hipGetLastError());
   return LMPC_OK;
+}
+}  // namespace
+
+int lmpc_prepare_batch(lmpc_handle* h, int32_t batch, const lmpc_track* track, const double* x_ic, double dt,
+                       double speed_scale, double speed_limit, double* X_ref, double* U_ref, double* T_ref,
+                       double* bound_left, double* bound_right, double* curvatures, double* vel_ref) {
+  return prepare_impl(h, "lmpc_prepare_batch", batch, track, x_ic, nullptr, dt, speed_scale, speed_limit, X_ref, U_ref,
+                      T_ref, bound_left, bound_right, curvatures, vel_ref);
+}
+
+int lmpc_prepare_failed_batch(lmpc_handle* h, int32_t batch, const lmpc_track* track, const double* x_ic,
+                              const int32_t* status, double dt, double speed_scale, double speed_limit, double* X_ref,
+                              double* U_ref, double* T_ref, double* bound_left, double* bound_right, double* curvatures,
+                              double* vel_ref) {
+  if (h && !status) return fail(h, LMPC_ERR_ARGUMENT, "lmpc_prepare_failed_batch: status is NULL");
+  return prepare_impl(h, "lmpc_prepare_failed_batch", batch, track, x_ic, status, dt, speed_scale, speed_limit, X_ref,
+                      U_ref, T_ref, bound_left, bound_right, curvatures, vel_ref);
 }
 
 static bool track_ok(const lmpc_track* t) {

@@ -205,9 +205,11 @@ __global__ __launch_bounds__(256) void lmpc_plant_kernel(lmpc_params P, int B, l
   for (int k = 0; k < 6; ++k) x_io[(size_t)k * B + b] = x[k];
 }
 
-// One thread per problem: zero-input rollout of the reference, then reference sampling.
+// One thread per problem: zero-input rollout of the reference, then reference sampling.  With `status` (may be
+// NULL) only the problems whose last solve failed (status != 0) are prepared; the arrays of the others are not touched.
 __global__ __launch_bounds__(256) void lmpc_prepare_kernel(lmpc_params P, int B, lmpc_track trk,
-                                                           const double* __restrict__ x_ic, double dt,
+                                                           const double* __restrict__ x_ic,
+                                                           const int* __restrict__ status, double dt,
                                                            double speed_scale, double speed_limit,
                                                            double* __restrict__ X_ref, double* __restrict__ U_ref,
                                                            double* __restrict__ T_ref, double* __restrict__ bl,
@@ -215,6 +217,7 @@ __global__ __launch_bounds__(256) void lmpc_prepare_kernel(lmpc_params P, int B,
                                                            double* __restrict__ vref) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
+  if (status && status[b] == 0) return;
   const int N = P.N, NS = N - 1;
   double x[6], xn[6];
 #pragma unroll
