@@ -270,6 +270,18 @@ def test_shift_and_plant_match_node_and_simulator(pkg):
     want = S.plant_step(veh, tr, x, o["U_optm"][:, 0, :].T, 0.0125, 2)
     assert np.abs(xs.cpu().numpy().T - want).max() <= 1e-11 * max(1.0, np.abs(want).max())
     assert (xs[0] >= 0).all() and (xs[0] < tr["L"]).all()
+    # cold restart of the failed problems only, in place (lmpc_prepare_failed_batch): the marked ones equal a cold
+    # start at the new state, the others keep their shifted references bit for bit
+    status = torch.zeros(300, dtype=torch.int32, device="cuda")
+    status[::7] = 2
+    status[3::50] = 1
+    sh = solver.shift(tr, inp, out, 0.025, speed_scale=0.9)
+    before = {k: sh[k].clone() for k in ("X_ref", "U_ref", "T_ref", "bound_left", "bound_right", "curvatures", "vel_ref")}
+    cold = solver.prepare(tr, xs, 0.025, speed_scale=0.9)
+    solver.prepare_failed(tr, xs, status, sh, 0.025, speed_scale=0.9)
+    bad = status != 0
+    for k in before:
+        assert torch.equal(sh[k][..., ~bad], before[k][..., ~bad]) and torch.equal(sh[k][..., bad], cold[k][..., bad]), k
 
 
 def test_closed_loop_two_laps_inside_the_track(pkg):
