@@ -265,6 +265,11 @@ def main():
                 pending[j] = None
         torch.cuda.synchronize()
 
+    # every stream's handle once, untimed: first-launch costs (code object load, workspace growth, RCCL channel setup)
+    # belong to initialisation whatever --warmup is
+    for k in range(S):
+        step(k)
+    drain()
     for k in range(args.warmup):
         step(k)
     drain()
