@@ -1,4 +1,4 @@
-// lmpc_solve_kernel.hip -- the batched QP solve of RacingMPC::solve on gfx950 (CDNA4), fp64.
+// lmpc_solve_kernel.hip -- the batched QP solve of RacingMPC::solve on gfx950 (CDNA4): fp64, and the same source in fp32.
 //
 // What it replaces: opti_.solve_limited() on the "conic"/OSQP problem built in
 //   src/mpc/racing_mpc/src/racing_mpc.cpp:106-201 (constraints), :442-477 (tracking cost),
