@@ -31,6 +31,8 @@
 // shared boundary slack sigma (one scalar coupling all knots) by a Schur complement.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "lmpc_device.h"
 
 // waves per SIMD asked of the compiler for the single-precision N <= 23 kernel (its 10 KB records allow 16 per CU):
@@ -215,6 +217,60 @@ __device__ __forceinline__ real wave_min(real x) {
 template <int NV, typename real>
 __device__ __forceinline__ void wave_sum_n(real (&v)[NV]) {
   wave_reduce_n<op_sum, NV>(v);
+}
+
+// Exchange with the partner lane that differs in bit BIT of the lane number (and, for bits 2 and 3, in the bits below:
+// the row mirrors are the involutions DPP offers there) -- every pairing used by wave_sum_split below.
+template <int BIT>
+__device__ __forceinline__ double pair_exchange(double x) {
+  if constexpr (BIT == 5) return __shfl_xor(x, 32, 64);
+  if constexpr (BIT == 4)  // ds_swizzle, bit mode: and 0x1f, or 0, xor 0x10
+    return __hiloint2double(__builtin_amdgcn_ds_swizzle(__double2hiint(x), 0x401F), __builtin_amdgcn_ds_swizzle(__double2loint(x), 0x401F));
+  if constexpr (BIT == 3) return dpp_move<0x140, 0xf>(x, 0.0);  // row_mirror
+  if constexpr (BIT == 2) return dpp_move<0x141, 0xf>(x, 0.0);  // row_half_mirror
+  if constexpr (BIT == 1) return dpp_move<0x4E, 0xf>(x, 0.0);   // quad_perm [2,3,0,1]
+  return dpp_move<0xB1, 0xf>(x, 0.0);                            // quad_perm [1,0,3,2]
+}
+template <int BIT>
+__device__ __forceinline__ float pair_exchange(float x) { return (float)pair_exchange<BIT>((double)x); }
+
+// Many sums at once, for NV up to 32 (the safe-set block reduces 35 per iteration): instead of NV full reductions, each
+// step pairs the lanes across one bit of the lane number and SPLITS the values between the partners -- the lane with
+// the bit clear keeps the lower half (adding its partner's contributions), the other the upper half -- so the work
+// halves with every step: P/2 + P/4 + ... exchanges for P values instead of 6 P.  After log2 P steps lane l holds the
+// partial total of value l >> (6 - log2 P) over its group; plain pairwise sums over the remaining bits finish it.
+template <int NV, typename real>
+__device__ __forceinline__ void wave_sum_split(real (&v)[NV], int lane) {
+  constexpr int P = NV <= 2 ? 2 : NV <= 4 ? 4 : NV <= 8 ? 8 : NV <= 16 ? 16 : 32;
+  constexpr int LOGP = P == 2 ? 1 : P == 4 ? 2 : P == 8 ? 3 : P == 16 ? 4 : 5;
+  static_assert(NV <= 32, "wave_sum_split handles up to 32 values");
+  real a[P];
+#pragma unroll
+  for (int k = 0; k < P; ++k) a[k] = k < NV ? v[k] : real(0);
+  auto split = [&](auto bit_c, auto half_c) {
+    constexpr int BIT = decltype(bit_c)::value, H = decltype(half_c)::value;
+    const bool up = (lane >> BIT) & 1;
+#pragma unroll
+    for (int k = 0; k < H; ++k) {
+      const real keep = up ? a[k + H] : a[k];
+      const real send = up ? a[k] : a[k + H];
+      a[k] = keep + pair_exchange<BIT>(send);
+    }
+  };
+  auto fold = [&](auto bit_c) {
+    constexpr int BIT = decltype(bit_c)::value;
+    a[0] = a[0] + pair_exchange<BIT>(a[0]);
+  };
+  using std::integral_constant;
+  // bits 5, 4, 3, 2, 1 carry the splits while more than one value is left; the rest are plain sums
+  if constexpr (LOGP >= 1) split(integral_constant<int, 5>{}, integral_constant<int, P / 2>{}); else fold(integral_constant<int, 5>{});
+  if constexpr (LOGP >= 2) split(integral_constant<int, 4>{}, integral_constant<int, P / 4>{}); else fold(integral_constant<int, 4>{});
+  if constexpr (LOGP >= 3) split(integral_constant<int, 3>{}, integral_constant<int, (P / 8 > 0 ? P / 8 : 1)>{}); else fold(integral_constant<int, 3>{});
+  if constexpr (LOGP >= 4) split(integral_constant<int, 2>{}, integral_constant<int, (P / 16 > 0 ? P / 16 : 1)>{}); else fold(integral_constant<int, 2>{});
+  if constexpr (LOGP >= 5) split(integral_constant<int, 1>{}, integral_constant<int, 1>{}); else fold(integral_constant<int, 1>{});
+  fold(integral_constant<int, 0>{});
+#pragma unroll
+  for (int k = 0; k < NV; ++k) v[k] = lane_bcast(a[0], k << (6 - LOGP));
 }
 
 // 1/x: hardware v_rcp seed + one Newton step (full accuracy for normal x); replaces the ~12-instruction IEEE
@@ -823,7 +879,7 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
     for (int q = 0; q < KS; ++q)
 #pragma unroll
       for (int k = 0; k < 6; ++k) ul[k] += sx.u[q][k] * sx.lm[q];
-    wave_sum_n<6>(ul);
+    wave_sum_split<6>(ul, lane);
     if (lane < 6) {
       real e = 0.0;
 #pragma unroll
@@ -892,8 +948,22 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
           av[6] += itf;
           av[13] += sx.lm[q];
         }
-        wave_sum_n<21>(tt);
-        wave_sum_n<14>(av);
+        {  // 35 sums: 32 through the splitting butterfly, the last three on their own
+          real red[32], red3[3] = {av[11], av[12], av[13]};
+#pragma unroll
+          for (int k = 0; k < 21; ++k) red[k] = tt[k];
+#pragma unroll
+          for (int k = 0; k < 11; ++k) red[21 + k] = av[k];
+          wave_sum_split<32>(red, lane);
+          wave_sum_split<3>(red3, lane);
+#pragma unroll
+          for (int k = 0; k < 21; ++k) tt[k] = red[k];
+#pragma unroll
+          for (int k = 0; k < 11; ++k) av[k] = red[21 + k];
+          av[11] = red3[0];
+          av[12] = red3[1];
+          av[13] = red3[2];
+        }
         sx.r1 = 1.0 - av[13];
         real F[36], Fi[36], Fia[6];
         {
@@ -1005,7 +1075,7 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
 #pragma unroll
             for (int k = 0; k < 6; ++k) bs[k] += sx.u[q][k] * w;
           }
-          wave_sum_n<7>(bs);
+          wave_sum_split<7>(bs, lane);
           sbl = bs[6];
           real Fib[6], aFib = 0.0;
 #pragma unroll
@@ -1129,7 +1199,7 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
 #pragma unroll
           for (int k = 0; k < 6; ++k) gs[k] += sx.u[q][k] * w;
         }
-        wave_sum_n<7>(gs);
+        wave_sum_split<7>(gs, lane);
         real Fig[6], aFig = 0.0;
 #pragma unroll
         for (int r = 0; r < 6; ++r) {
