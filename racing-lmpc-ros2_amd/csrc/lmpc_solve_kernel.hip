@@ -348,16 +348,17 @@ __device__ __forceinline__ void spd_inv6(const real (&F)[36], real (&Fi)[36]) {
 
 // LMPC simplex row j: gradient of the (eps-eliminated) terminal cost wrt lambda_j including the row's
 // barrier coefficient, bl_j = ss_j - cf_j - u_j'E eps; also returns 1/max(theta_j, floor).
+// (ee = E eps of this iteration, wave-uniform)
 template <typename real>
 __device__ __forceinline__ real simplex_bl(real lm, real t, real l, real pprod, real ssj, const real (&u)[6],
-                                             real smu, real pm, const real* ct, const real* T, real& itf) {
+                                             real smu, real pm, const real (&ee)[6], real& itf) {
   const real it_ = frcp(t);
   const real th = l * it_;
   itf = frcp(fmax(th, TH_L_MIN));
   const real cf = th * (-lm + t) + (smu - pm * pprod) * it_;
   real ue = 0.0;
 #pragma unroll
-  for (int k = 0; k < 6; ++k) ue += u[k] * ct[CT_E + k] * T[TL_EPS + k];
+  for (int k = 0; k < 6; ++k) ue += u[k] * ee[k];
   return ssj - cf - ue;
 }
 
@@ -1057,6 +1058,11 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
 
     real sigc = 0.0, alpha = 1.0, dsigma = 0.0, dts = 0.0, dlams = 0.0;
     bool numerics_failed = false, degenerate_stop = false;
+    real eeps[6] = {0, 0, 0, 0, 0, 0};  // E eps of this iterate (safe-set block), in scalar registers
+    if constexpr (KS > 0) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) eeps[k] = uni(ct[CT_E + k] * T[TL_EPS + k]);
+    }
     real d_val[KQ];
     const int npass = ipm ? 2 : 1;
     for (int pass = 0; pass < npass; ++pass) {
@@ -1070,7 +1076,7 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
 #pragma unroll
           for (int q = 0; q < KS; ++q) {
             real itf;
-            const real w = sx.on[q] ? simplex_bl(sx.lm[q], sx.t[q], sx.l[q], sx.p[q], sx.j[q], sx.u[q], smu, pm, ct, T, itf) * itf : 0.0;
+            const real w = sx.on[q] ? simplex_bl(sx.lm[q], sx.t[q], sx.l[q], sx.p[q], sx.j[q], sx.u[q], smu, pm, eeps, itf) * itf : 0.0;
             bs[6] += w;
 #pragma unroll
             for (int k = 0; k < 6; ++k) bs[k] += sx.u[q][k] * w;
@@ -1188,7 +1194,7 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
 #pragma unroll
         for (int q = 0; q < KS; ++q) {
           real itf;
-          real r = -simplex_bl(sx.lm[q], sx.t[q], sx.l[q], sx.p[q], sx.j[q], sx.u[q], smu, pm, ct, T, itf);
+          real r = -simplex_bl(sx.lm[q], sx.t[q], sx.l[q], sx.p[q], sx.j[q], sx.u[q], smu, pm, eeps, itf);
 #pragma unroll
           for (int k = 0; k < 6; ++k) r += sx.u[q][k] * e[k];
           r = sx.on[q] ? r : 0.0;
