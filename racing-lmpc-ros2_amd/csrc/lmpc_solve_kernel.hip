@@ -443,6 +443,8 @@ __device__ void riccati_factor(const Lds<real>& L, int lane, const real* PT) {
       ac[k] = st[ST_ROW(c) + k];
     }
   }
+  // the input-rate weights are the same at every stage: scalar registers, not an LDS read per stage
+  const real sv00 = uni(ct[CT_SV + 0]), sv01 = uni(ct[CT_SV + 1]), sv11 = uni(ct[CT_SV + 3]);
   wave_sync();
   for (int i = N - 2; i >= 0; --i) {
     real* st = L.st(i);
@@ -454,7 +456,6 @@ __device__ void riccati_factor(const Lds<real>& L, int lane, const real* PT) {
     ISSUE_ORDER();
     // phase-3 operands of this stage, queued behind the P row
     const real t = st[ST_DT], thr = kn[KN_R0 + r], ey = kn[KN_EY], thv0 = kn[KN_R0 + 8], thv1 = kn[KN_R0 + 9];
-    const real sv00 = ct[CT_SV + 0], sv01 = ct[CT_SV + 1], sv11 = ct[CT_SV + 3];
     ISSUE_ORDER();
     real w = (r >= 6) ? pown : 0.0;
 #pragma unroll
