@@ -29,33 +29,33 @@ ALGO_BYTES_PER_SOLVE = (13 * 20 + 5) * 8 + (10 * 20 - 4) * 8 + 8  # 3696 B at N 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
 
 
-def measured_traffic_bytes():
+def measured_traffic_bytes(pmc_file="r01_pmc.json", kernel="lmpc_solve_kernel<double, 4, 0"):
     """HBM bytes per launch of the QP kernel from the committed rocprofv3 PMC passes of this same command
     (profiles/r01_pmc.json: FETCH_SIZE and WRITE_SIZE are reported in KiB, collected in separate --pmc runs).
     The gfx950 FETCH_SIZE x2 correction of MI355X_MICROARCH.md applies to wide coalesced streams only; this
     kernel's reads are 8-byte strided or L2/MALL-resident workspace lines, so the raw counter is reported."""
     try:
-        pmc = json.load(open(ROOT / "profiles" / "r01_pmc.json"))
-        k = next(v for n, v in pmc.items() if n.startswith("lmpc_solve_kernel<double, 4, 0"))
+        pmc = json.load(open(ROOT / "profiles" / pmc_file))
+        k = next(v for n, v in pmc.items() if n.startswith(kernel))
         return (k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0
     except Exception:
         return None
 
 
-def engine_utilisation(kernel_ms):
+def engine_utilisation(kernel_ms, pmc_file="r01_pmc.json", kernel="lmpc_solve_kernel<double, 4, 0"):
     """What actually bounds the QP kernel: busy fractions of the FP64 VALU and of the LDS pipeline from the same
     committed PMC passes (SQ_ACTIVE_INST_VALU is in 4-cycle units summed over waves, one VALU per SIMD, 4 SIMDs x
     256 CUs; SQ_LDS_IDX_ACTIVE in cycles summed over the 256 CU-local LDS pipelines), against the kernel duration of
     that profile run.  Reported next to the HBM figure because the path is not HBM-bound."""
     try:
-        pmc = json.load(open(ROOT / "profiles" / "r01_pmc.json"))
-        k = next(v for n, v in pmc.items() if n.startswith("lmpc_solve_kernel<double, 4, 0"))
+        pmc = json.load(open(ROOT / "profiles" / pmc_file))
+        k = next(v for n, v in pmc.items() if n.startswith(kernel))
         prof_ms = pmc.get("_meta", {}).get("qp_kernel_ms", kernel_ms)
         cyc = prof_ms * 1e-3 * pmc.get("_meta", {}).get("clock_ghz", 2.3) * 1e9
         return {"valu_busy_frac": k["SQ_ACTIVE_INST_VALU"] * 4.0 / (cyc * 256 * 4),
                 "lds_busy_frac": k["SQ_LDS_IDX_ACTIVE"] / (cyc * 256),
                 "valu_insts_per_solve": k["SQ_INSTS_VALU"] / k["SQ_WAVES"], "lds_insts_per_solve": k["SQ_INSTS_LDS"] / k["SQ_WAVES"],
-                "source": "profiles/r01_pmc.json (rocprofv3 --pmc, batch 4096, N 20)"}
+                "source": "profiles/%s (rocprofv3 --pmc, batch 4096, N 20)" % pmc_file}
     except Exception:
         return None
 
@@ -349,6 +349,8 @@ def main():
         if lmpc:
             algo_bytes += (7 + 1) * 160 * 8  # + ss_x, ss_j in and lambda out (13 936 B at S = 160)
         achieved = algo_bytes * B / (sol_avg * 1e-3) / 1e9
+        # committed PMC passes of this command: tracking, or the learning problem with 160 safe-set points
+        pmc_sel = ("r01_pmc_lmpc.json", "lmpc_solve_kernel<double, 4, 3") if lmpc else ("r01_pmc.json", "lmpc_solve_kernel<double, 4, 0")
         res = {
             "metric": "QP solves/sec (nx=6,nu=2,N=%d)" % N, "value": value, "unit": "solves/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -371,11 +373,11 @@ def main():
                         "resident_problems_per_cu": None, "note": "fp32 records are half the fp64 size"} if (f32 or mixed) else solver.launch_info()),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None if (lmpc or N != 20 or B != 4096) else measured_traffic_bytes(),
+                         "traffic": None if (N != 20 or B != 4096 or iac or f32 or mixed) else measured_traffic_bytes(*pmc_sel),
                          "algorithmic_bytes_per_solve": algo_bytes,
                          "note": "algorithmic bytes x batch / lmpc_solve_kernel time; the kernel is "
                                  "FP64-VALU issue / LDS-pipeline bound (DESIGN.md), HBM fraction is reported as required",
-                         "engines": None if (lmpc or N != 20 or B != 4096) else engine_utilisation(sol_avg)},
+                         "engines": None if (N != 20 or B != 4096 or iac or f32 or mixed) else engine_utilisation(sol_avg, *pmc_sel)},
         }
         if ss_ms:
             # safe-set query kernel: per query 2 doubles in, 7 S doubles out (ss_x [6][S], ss_j [S]); the lap store
