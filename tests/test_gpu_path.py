@@ -570,7 +570,7 @@ def test_horizons_at_the_row_layout_boundaries_match_the_twin(pkg, N):
     assert np.array_equal(out["X_optm"][:, 0, :], inp["x_ic"])          # x_0 = x_ic (racing_mpc.cpp:200-201)
 
 
-@pytest.mark.parametrize("N,n_laps", [(10, 3), (30, 3), (40, 5), (60, 3), (80, 5)])
+@pytest.mark.parametrize("N,n_laps", [(10, 3), (30, 3), (40, 5), (60, 3), (80, 5), (20, 1), (20, 6)])
 def test_lmpc_at_other_horizons_matches_the_twin(pkg, N, n_laps):
     """The learning problem away from N = 20: every row layout (iac_car_lmpc.param.yaml ships N = 60) and both safe-set
     sizes (96 / 160 points)."""
@@ -579,7 +579,8 @@ def test_lmpc_at_other_horizons_matches_the_twin(pkg, N, n_laps):
 
     veh, cfg, tr, laps, inp, q = LS.make(32, 70 + N, N=N, n_laps=min(n_laps, 3))
     cfg = P.barc_lmpc(N, n_laps)
-    stored = (laps * 2)[:n_laps]                                       # five laps: the three recorded ones, two repeated
+    stored = (laps * 2)[:n_laps]                                       # up to six laps: the three recorded ones, repeated
+    # (n_laps = 1 / 6: the smallest and the largest safe set the kernel is instantiated for, 32 and 192 points)
     solver = pkg.Solver(pkg.presets.barc_lmpc(N, n_laps), pkg.presets.barc_vehicle(), device=0)
     solver.set_safe_set(stored, LS.L_BARC_SS)
     ss_x, ss_j, nf = solver.ss_query(q)
