@@ -195,7 +195,8 @@ def test_ss_query_awkward_laps_match_oracle(pkg):
     q = np.stack([rng.uniform(-1.0, L + 1.0, 300), rng.uniform(-0.2, 0.2, 300)])
     q[:, :40] = np.stack([tied[::5, 0], np.zeros(40)])                                  # queries on top of the tied points
     for laps, K, S in (([normal, looping], 32, 64), ([looping, normal, looping], 32, 96), ([normal, tied], 32, 64),
-                       ([normal, short, looping], 32, 96), ([looping, normal], 64, 128), ([short], 32, 32)):
+                       ([normal, short, looping], 32, 96), ([looping, normal], 64, 128), ([short], 32, 32),
+                       ([normal, looping], 32, 50), ([tied, normal], 32, 80), ([normal], 32, 96)):   # truncated / padded sets
         cfg = pkg.presets.barc_lmpc(20, 3)
         cfg.update(num_ss_pts=S, num_ss_pts_per_lap=K, max_lap_stored=len(laps))
         solver = pkg.Solver(cfg, pkg.presets.barc_vehicle(), device=0)
