@@ -121,6 +121,7 @@ def cpu_baseline(pkg, N, batch, seconds_target=12.0):
         list(ex.map(work, range(cores)))
     dt = time.perf_counter() - t0
     return {"value": reps * B / dt, "unit": "solves/s", "cores": cores, "kind": "port",
+            "single_thread_solve_ms": per * 1e3,   # one thread, one problem at a time (the first 32 problems, untimed cores idle)
             "sample": f"{reps} x {B} problems of the bench workload ({per_thread} per thread per call), static split "
                       f"over {cores} host threads, oracle/c/lmpc_oracle.c -O3 ({dt:.1f} s wall)"}
 
