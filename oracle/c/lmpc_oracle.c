@@ -700,10 +700,10 @@ static void primal_update(prob_t* p, double alpha) {
  * barrier weights lam/t into the cost-to-go, which limits the attainable stationarity once
  * lam/t exceeds ~1e12; the returned point is typically within 1e-8 (scaled) of the optimum
  * and within 1e-3 in the worst case, the same order as OSQP's eps = 1e-3 in the reference.    */
-static int ipm_solve(prob_t* p, int* iters_out, double* kkt_out) {
+static int ipm_solve(prob_t* p, work_t* w, int* iters_out, double* kkt_out) {
   const int N = p->N, S = p->S;
   const double tau = 0.995, mu0 = 0.1, thr_frac = 0.5;
-  work_t* w = calloc(1, sizeof(work_t));
+  memset(w, 0, sizeof(work_t)); /* (the caller owns the allocation: one per range, not one mmap per solve) */
   /* ---- initial point: the minimiser of the cost over the dynamics alone (no inequality
    * rows, sigma = 0).  The linearised model can be open-loop unstable (|eig A| > 1 at low speed
    * with dt = 25 ms), so the trajectory is first rolled out under the stabilising Riccati
@@ -948,7 +948,6 @@ static int ipm_solve(prob_t* p, int* iters_out, double* kkt_out) {
     kkt_out[2] = mu;
     kkt_out[3] = p->sigma;
   }
-  free(w);
   *iters_out = it;
   return status;
 }
@@ -1059,6 +1058,12 @@ int lmpc_oracle_solve_range(const lmpc_config* cfg, const lmpc_vehicle* veh, int
   if (N < 3 || N > NMAX) return LMPC_ERR_ARGUMENT;
   if (cfg->learning && (cfg->num_ss_pts < 1 || cfg->num_ss_pts > SMAX)) return LMPC_ERR_ARGUMENT;
   prob_t* p = malloc(sizeof(prob_t));
+  work_t* w = malloc(sizeof(work_t));
+  if (!p || !w) {
+    free(p);
+    free(w);
+    return LMPC_ERR_RUNTIME;
+  }
   for (int b = b0; b < b1; ++b) {
     setup_problem(p, cfg, veh, B, b, x_ic, u_ic, X_ref, U_ref, T_ref, bound_left, bound_right,
                   curvatures, vel_ref, ss_x, ss_j);
@@ -1068,9 +1073,9 @@ int lmpc_oracle_solve_range(const lmpc_config* cfg, const lmpc_vehicle* veh, int
       st = LMPC_SOLVE_INFEASIBLE;
       /* still report the rollout so the buffers are defined */
       p->max_iter = 0;
-      ipm_solve(p, &it, kk);
+      ipm_solve(p, w, &it, kk);
     } else {
-      st = ipm_solve(p, &it, kk);
+      st = ipm_solve(p, w, &it, kk);
     }
     for (int i = 0; i < N; ++i)
       for (int k = 0; k < 6; ++k) X_optm[(size_t)(k * N + i) * B + b] = p->z[i][k];
@@ -1087,6 +1092,7 @@ int lmpc_oracle_solve_range(const lmpc_config* cfg, const lmpc_vehicle* veh, int
       for (int k = 0; k < 4; ++k) kkt[(size_t)k * B + b] = kk[k];
   }
   free(p);
+  free(w);
   return LMPC_OK;
 }
 
