@@ -192,10 +192,23 @@ def main():
                                                              "launch of the QP kernel at the bench batch size)")
     args = ap.parse_args()
 
+    # --gpus is authoritative.  Under a launcher (WORLD_SIZE set) it must agree with the world the launcher made; started
+    # bare with --gpus N > 1 the script re-executes itself under torch.distributed.run (one rank per GPU, rendezvous on
+    # 127.0.0.1), so `python bench.py --gpus 8` cannot silently measure one GPU.
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+                                  "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:])
+
     import torch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     local = int(os.environ.get("LOCAL_RANK", "0"))
     # pre-flight hook for a one-GPU box (tests/test_gpu_path.py): all ranks share device 0 and rendezvous over gloo,
     # so the N > 1 control flow (rank env, per-rank workload, barriers, max-over-ranks) runs without RCCL
@@ -211,8 +224,20 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU path)"
+    if not shared_gpu:
+        assert local < torch.cuda.device_count(), f"rank {rank}: LOCAL_RANK {local} but {torch.cuda.device_count()} visible GPUs"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    assert torch.cuda.current_device() == local
+    # which physical device every rank sits on (one distinct GPU per rank unless the one-GPU preflight shares device 0)
+    props = torch.cuda.get_device_properties(local)
+    me = {"rank": rank, "device": local, "uuid": str(getattr(props, "uuid", "")), "name": props.name}
+    ranks_seen = [me]
+    if world > 1:
+        ranks_seen = [None] * world
+        dist.all_gather_object(ranks_seen, me)
+        if not shared_gpu:
+            assert len({(r["device"], r["uuid"]) for r in ranks_seen}) == world, f"ranks share a GPU: {ranks_seen}"
 
     pkg = load_package()
     f32 = args.precision == "f32"
@@ -406,7 +431,8 @@ def main():
                                      "IAC Putnam tracking MPC, batch=%d per GPU, N=%d, fp64 (problem of BASELINE configs[3])") if iac else
                                     "BARC tracking MPC, batch=%d random x0 per GPU, N=%d, fp64 (BASELINE configs[1])") % (B, N)
                                    + (" -- mixed precision: fp32 Riccati / interior point between fp64 arrays (BASELINE configs[4])" if mixed else ""),
-                       "batch_per_gpu": B, "horizon": N, "streams": S, "result_gather": "rccl all_gather (async)" if gather else "none"},
+                       "batch_per_gpu": B, "horizon": N, "streams": S, "result_gather": "rccl all_gather (async)" if gather else "none",
+                       "ranks_seen": ranks_seen},
             "p50_solve_ms": float(np.percentile(lat, 50)), "p99_solve_ms": float(np.percentile(lat, 99)),
             "latency_samples": len(lat), "value_one_stream": one_stream_value,
             "batch1_solve_ms": {"p50": float(np.percentile(lat1, 50)), "p99": float(np.percentile(lat1, 99)), "control_period_ms": 25.0} if lat1 else None,

@@ -245,7 +245,7 @@ static void riccati_factor(prob_t* p, const double* PT) {
   for (int r = 0; r < 8; ++r)
     for (int c = 0; c < 8; ++c) {
       double e = Qz_entry(p, N - 1, r, c) + (r == c ? p->Thz[N - 1][r] : 0.0);
-      if (PT && r < 6 && c < 6) e += PT[r * 6 + c];
+      if (PT && r < 6 && c < 6) e += PT[r <= c ? r * 6 + c : c * 6 + r]; /* upper triangle, mirrored */
       P[r * 8 + c] = e;
     }
   for (int i = N - 2; i >= 0; --i) {
@@ -276,11 +276,19 @@ static void riccati_factor(prob_t* p, const double* PT) {
       p->K[i][0 * 8 + c] = Hi[0] * g0 + Hi[1] * g1;
       p->K[i][1 * 8 + c] = Hi[2] * g0 + Hi[3] * g1;
     }
-    if (i >= 1)
+    if (i >= 1) {
       for (int r = 0; r < 8; ++r)
-        for (int c = 0; c < 8; ++c)
+        for (int c = r; c < 8; ++c)
           P[r * 8 + c] = Qz_entry(p, i, r, c) + (r == c ? p->Thz[i][r] : 0.0) + Y[r * 8 + c] -
                          t * (Y[6 * 8 + r] * p->K[i][0 * 8 + c] + Y[7 * 8 + r] * p->K[i][1 * 8 + c]);
+      /* The upper triangle is the cost-to-go; the lower one mirrors it.  Rounding makes the two computed halves differ,
+       * and that antisymmetric part is NOT contracted by the recursion: it is multiplied by Abar'(.)Abar, i.e. by the
+       * OPEN-loop dynamics, whose RK4 map has |eig| up to ~15-25 below 1 m/s -- left alone it reaches 1e17 within
+       * twenty stages and the Newton directions are noise (N >= 40 cold starts at low speed).  Exact symmetry removes it:
+       * the symmetric error is damped by the closed loop like the cost-to-go itself. */
+      for (int r = 0; r < 8; ++r)
+        for (int c = r + 1; c < 8; ++c) P[c * 8 + r] = P[r * 8 + c];
+    }
   }
 }
 

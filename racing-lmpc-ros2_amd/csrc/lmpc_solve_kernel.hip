@@ -424,10 +424,19 @@ __device__ void riccati_factor(const Lds<real>& L, int lane, const real* PT) {
     real e = qz_entry(ct, true, r, c);
     const real th = kn[KN_R0 + r] + (r == 1 ? kn[KN_EY] : real(0));
     if (diag) e += th;
-    if (HAS_PT && r < 6 && c < 6) e += PT[r * 6 + c];  // LMPC: safe-set block condensed onto x_T
+    // LMPC: safe-set block condensed onto x_T; its upper triangle is the block (see the symmetry note in the loop)
+    if (HAS_PT && r < 6 && c < 6) e += PT[r <= c ? r * 6 + c : c * 6 + r];
     pown = e;
     MP[r * MROW + c] = e;
   }
+  // The upper triangle (lanes r <= c) is the cost-to-go; those lanes store their element at (r, c) AND (c, r), the others
+  // store to a dead cell.  Why: the two computed halves differ by rounding, and that antisymmetric part is not contracted by
+  // the recursion -- it is multiplied by Abar'(.)Abar, the OPEN-loop dynamics, whose RK4 map has |eig| up to ~15-25 below
+  // 1 m/s, so within twenty stages it reaches 1e17 and the Newton directions are noise (every low-speed cold start at
+  // N >= 40 was lost to this).  An exactly symmetric P only carries symmetric error, which the closed loop damps.
+  const bool upper = r <= c;
+  real* const p_dst0 = upper ? MP + r * MROW + c : MW + r * MROW + c;
+  real* const p_dst1 = upper ? MP + c * MROW + r : MW + r * MROW + c;
   // where this lane's share of the stage results goes: lanes 0..15 K_j[c] (j = r), 16..18 Hinv, the
   // rest to their own (dead) W cell
   const int res_off = lane < 16 ? ST_ROW(c) + 6 + r : (lane == 18 ? ST_HI11 : ST_HI + (lane - 16));
@@ -453,6 +462,7 @@ __device__ void riccati_factor(const Lds<real>& L, int lane, const real* PT) {
     real pr[6];
 #pragma unroll
     for (int k = 0; k < 6; ++k) pr[k] = MP[c * MROW + k];
+    pown = MP[r * MROW + c];  // the symmetrised element (lanes below the diagonal did not compute it)
     ISSUE_ORDER();
     // phase-3 operands of this stage, queued behind the P row
     const real t = st[ST_DT], thr = kn[KN_R0 + r], ey = kn[KN_EY], thv0 = kn[KN_R0 + 8], thv1 = kn[KN_R0 + 9];
@@ -505,8 +515,8 @@ __device__ void riccati_factor(const Lds<real>& L, int lane, const real* PT) {
     real pn = qmid + y - t * (y6r * k0c + y7r * k1c);
     const real th = thr + (r == 1 ? ey : real(0));
     if (diag) pn += th;
-    pown = pn;
-    MP[r * MROW + c] = pn;  // (not used after stage 0)
+    *p_dst0 = pn;  // (not used after stage 0)
+    *p_dst1 = pn;
     const real res = lane < 8 ? k0c : (lane < 16 ? k1c : (lane == 16 ? hi00 : (lane == 17 ? hi01 : hi11)));
     *(res_on ? st + res_off : res_junk) = res;
     wave_sync();

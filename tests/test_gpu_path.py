@@ -708,10 +708,12 @@ def test_c_abi_rejects_misuse_without_crashing(pkg):
     assert (to_np(solver.solve(S.cold_start_inputs(cfg, veh2, tr, xx, uu, 0.025)))["status"] == 0).all()
 
 
-def test_bench_two_ranks_preflight_on_one_gpu():
-    """bench.py's N > 1 control flow as the driver launches it (torch.distributed.run, one rank per GPU), here with both
-    ranks on device 0 and gloo instead of RCCL (LMPC_BENCH_SHARED_GPU): rank environment, per-rank workloads, the
-    result gather, barriers, max-over-ranks timing and rank 0's single JSON line."""
+@pytest.mark.parametrize("launcher", ["torch.distributed.run", "self-spawn"])
+def test_bench_two_ranks_preflight_on_one_gpu(launcher):
+    """bench.py's N > 1 control flow, here with both ranks on device 0 and gloo instead of RCCL (LMPC_BENCH_SHARED_GPU):
+    rank environment, per-rank workloads, the result gather, barriers, max-over-ranks timing and rank 0's single JSON
+    line.  Once as the driver launches it (torch.distributed.run, one rank per GPU) and once bare --
+    `python bench.py --gpus 2` -- where the script has to spawn its own ranks: --gpus is authoritative either way."""
     import json
     import os
     import subprocess
@@ -720,8 +722,14 @@ def test_bench_two_ranks_preflight_on_one_gpu():
 
     root = Path(__file__).resolve().parents[1]
     env = dict(os.environ, LMPC_BENCH_SHARED_GPU="1", MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29531", str(root / "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--batch", "1024"]
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    tail = [str(root / "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--batch", "1024"]
+    if launcher == "self-spawn":
+        cmd = [sys.executable] + tail
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", "29531"] + tail
     r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -729,6 +737,21 @@ def test_bench_two_ranks_preflight_on_one_gpu():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 6 and d["scaling"] == "weak" and d["value"] > 1e5
     assert d["solved_fraction"] > 0.99 and "cpu_baseline" not in d
+    assert [r_["rank"] for r_ in d["config"]["ranks_seen"]] == [0, 1]
+
+
+def test_bench_refuses_a_world_that_disagrees_with_gpus():
+    """`--gpus 2` under a launcher that made one rank is an error, not a one-GPU number labelled n_gpus = 1."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parents[1]
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env, cwd=root,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "--gpus 2" in (r.stderr + r.stdout)
 
 
 def test_solver_built_from_parameter_files_solves_like_the_preset(pkg, golden, tmp_path):
