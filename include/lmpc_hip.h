@@ -92,7 +92,7 @@ typedef struct lmpc_config {
   int32_t num_ss_pts_per_lap; /* K                                                          */
   int32_t max_lap_stored;
   int32_t max_iter;           /* interior-point iteration cap (<=0: default 40)             */
-  double tol;                 /* complementarity tolerance (<=0: default 1e-11)             */
+  double tol;                 /* complementarity tolerance (<=0: default 1e-13)             */
   double margin;
   double q_contour, q_heading, q_vel, q_vy, q_vyaw, q_boundary;
   double R[4];                /* row-major 2x2                                              */

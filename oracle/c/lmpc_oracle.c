@@ -28,6 +28,13 @@
  * z_i = [x_i; u_{i-1}] (8), input v_i = dU_i (2); the shared boundary slack (one
  * scalar coupling all knots, racing_mpc.cpp:533) is eliminated by a Schur complement.
  * The HIP kernel implements the same algorithm; this file is its serial twin.
+ *
+ * The row  sigma >= 0  (racing_mpc.cpp:536) is NOT carried by the iteration: it is redundant.  For any
+ * feasible point with sigma < 0, replacing sigma by 0 keeps every boundary row  +-e_y - sigma <= b  satisfied
+ * (they only loosen) and lowers the cost q_boundary sigma^2, so the optimum of the QP without the row has
+ * sigma >= 0 and is the optimum of the reference's QP (oracle/qp.py keeps the row; tests compare against it).
+ * Carried, the row is degenerate whenever the track boundary is inactive (sigma* = 0 with multiplier 0), which
+ * is the usual case, and an interior-point iterate then approaches like sqrt(mu): two to three extra iterations.
  */
 #include <math.h>
 #include <stdint.h>
@@ -210,11 +217,10 @@ typedef struct {
   /* iterate */
   double z[NMAX][8], v[NMAX][2], sigma;
   double t[NMAX][NSLOT][2], lam[NMAX][NSLOT][2];
-  double ts, lams; /* sigma >= 0 row */
   double lmb[SMAX], tl[SMAX], ll[SMAX]; /* LMPC: simplex weights, their slacks and multipliers */
   /* Newton step */
   double dz[NMAX][8], dv[NMAX][2], dsigma;
-  double dtt[NMAX][NSLOT][2], dlam[NMAX][NSLOT][2], dts, dlams;
+  double dtt[NMAX][NSLOT][2], dlam[NMAX][NSLOT][2];
   double dlmb[SMAX], dtl[SMAX], dll[SMAX];
   /* assembled Newton data */
   double Thz[NMAX][8], Thv[NMAX][2], csig[NMAX], hsig;
@@ -239,7 +245,7 @@ static inline double Qz_entry(const prob_t* p, int i, int r, int c) {
  * Backward sweep on z = [x; u_prev] (8), v = dU (2):
  *   Y = Abar' P Abar,  H = Sv + Thv + t^2 Y_uu,  G = t Y[6:8,:],  K = H^-1 G,
  *   P <- Qz + Thz + Y - G' K.        (stage 0 only needs H^-1: dz_0 = 0)                      */
-static void riccati_factor(prob_t* p, const double* PT) {
+static void riccati_factor(prob_t* p, const double* PT, int joseph) {
   const int N = p->N;
   double P[64], W[64], Y[64];
   for (int r = 0; r < 8; ++r)
@@ -276,7 +282,38 @@ static void riccati_factor(prob_t* p, const double* PT) {
       p->K[i][0 * 8 + c] = Hi[0] * g0 + Hi[1] * g1;
       p->K[i][1 * 8 + c] = Hi[2] * g0 + Hi[3] * g1;
     }
-    if (i >= 1) {
+    if (i >= 1 && joseph) {
+      /* Stabilised ("Joseph") form  P <- Qz + Thz + Phi' P Phi + K' (Sv + Thv) K,  Phi = Abar - Bbar K: the same matrix
+       * as below in exact arithmetic, but a sum of positive semidefinite products.  Y - G'K subtracts two numbers of the
+       * size of the largest barrier weight (1e10..1e13 late in the iteration) to leave one of the size of the cost, and
+       * the Newton directions lose those digits; here the cancellation happens inside Phi, BEFORE the multiplication by
+       * P.  Costs a second pair of 8x8 products, so it is used only for the last iterations (mu <= JOSEPH_MU). */
+      double Phi[64], W2[64];
+      for (int k = 0; k < 8; ++k)
+        for (int c = 0; c < 8; ++c) {
+          if (k < 6)
+            Phi[k * 8 + c] = abar(p, i, k, c) - t * (p->B[i][k * 2] * p->K[i][c] + p->B[i][k * 2 + 1] * p->K[i][8 + c]);
+          else
+            Phi[k * 8 + c] = (k == c ? 1.0 : 0.0) - t * p->K[i][(k - 6) * 8 + c];
+        }
+      for (int r = 0; r < 8; ++r)
+        for (int c = 0; c < 8; ++c) {
+          double acc = 0.0;
+          for (int k = 0; k < 8; ++k) acc += Phi[k * 8 + r] * P[c * 8 + k]; /* P symmetric: P[k][c] read as P[c][k] */
+          W2[r * 8 + c] = acc;
+        }
+      const double v00 = p->Sv[0] + p->Thv[i][0], v01 = p->Sv[1], v11 = p->Sv[3] + p->Thv[i][1];
+      for (int r = 0; r < 8; ++r)
+        for (int c = r; c < 8; ++c) {
+          double acc = 0.0;
+          for (int k = 0; k < 8; ++k) acc += W2[r * 8 + k] * Phi[k * 8 + c];
+          const double k0r = p->K[i][r], k1r = p->K[i][8 + r], k0c = p->K[i][c], k1c = p->K[i][8 + c];
+          Y[r * 8 + c] = Qz_entry(p, i, r, c) + (r == c ? p->Thz[i][r] : 0.0) + acc + k0r * (v00 * k0c + v01 * k1c) +
+                         k1r * (v01 * k0c + v11 * k1c);
+        }
+      for (int r = 0; r < 8; ++r)
+        for (int c = r; c < 8; ++c) P[c * 8 + r] = P[r * 8 + c] = Y[r * 8 + c];
+    } else if (i >= 1) {
       for (int r = 0; r < 8; ++r)
         for (int c = r; c < 8; ++c)
           P[r * 8 + c] = Qz_entry(p, i, r, c) + (r == c ? p->Thz[i][r] : 0.0) + Y[r * 8 + c] -
@@ -367,6 +404,8 @@ typedef struct {
  * unchanged.  Measured on BARC LMPC problems: 1e-3 gives 1e-9 agreement with the dense optimum,
  * 1e-6 gives 1e-5, none stalls at mu ~ 1e-8. */
 #define TH_L_MIN 1e-3
+/* complementarity below which the factorisation switches to the stabilised form (riccati_factor) */
+#define JOSEPH_MU 1e-8
 
 static void sym_inv6(const double* F, double* Fi) { /* Cholesky inverse of SPD 6x6 */
   double Lc[36] = {0};
@@ -490,7 +529,6 @@ typedef double rows_t[NMAX][NSLOT][2];
 
 typedef struct {
   rows_t th, cf, rd;
-  double ths, cfs, rds;             /* sigma >= 0 row                                          */
   double thl[SMAX], cfl[SMAX], rdl[SMAX], r1, eps_T[6]; /* LMPC terminal rows                  */
   double gz[NMAX][8], gv[NMAX][2], gsig; /* gradient of the cost at the iterate                */
   double az[NMAX][8], av[NMAX][2];
@@ -532,8 +570,7 @@ static inline double row_res(const prob_t* p, int i, int sl, int sd) {
 }
 
 /* reduced-gradient stationarity residual for multipliers lam (adjoint sweep) */
-static double stationarity(const prob_t* p, const work_t* w, const rows_t lam, double lams,
-                           const double* ll) {
+static double stationarity(const prob_t* p, const work_t* w, const rows_t lam, const double* ll) {
   const int N = p->N, S = p->S;
   double pi[8] = {0}, wv[8], rg = 0.0, gs = w->gsig;
   for (int i = N - 1; i >= 0; --i) {
@@ -570,10 +607,7 @@ static double stationarity(const prob_t* p, const work_t* w, const rows_t lam, d
       for (int r = 0; r < 8; ++r) pi[r] = gzl[r] + wv[r];
     }
   }
-  if (p->has_sigma) {
-    gs -= lams;
-    if (fabs(gs) > rg) rg = fabs(gs);
-  }
+  if (p->has_sigma && fabs(gs) > rg) rg = fabs(gs);
   if (S) {
     double rl[SMAX], nu = 0;
     for (int j = 0; j < S; ++j) {
@@ -590,7 +624,7 @@ static double stationarity(const prob_t* p, const work_t* w, const rows_t lam, d
 }
 
 /* Hessian side: weights -> diagonal additions, sigma coupling; factorise. */
-static void newton_factor(prob_t* p, work_t* w) {
+static void newton_factor(prob_t* p, work_t* w, int joseph) {
   const int N = p->N, S = p->S;
   p->hsig = p->qsig;
   for (int i = 0; i < N; ++i) {
@@ -615,12 +649,11 @@ static void newton_factor(prob_t* p, work_t* w) {
       }
     }
   }
-  if (p->has_sigma) p->hsig += w->ths;
   double PT[36] = {0};
   if (S && !w->frozen_lambda) term_factor(p, &w->tm, w->thl, PT);
   if (S && w->frozen_lambda)
     for (int k = 0; k < 6; ++k) PT[k * 6 + k] = p->chs2[k];
-  riccati_factor(p, S ? PT : NULL);
+  riccati_factor(p, S ? PT : NULL, joseph);
   w->ce = 0.0;
   if (p->has_sigma) {
     for (int i = 0; i < N; ++i) {
@@ -657,7 +690,6 @@ static void newton_solve(prob_t* p, work_t* w) {
       }
     }
   }
-  if (p->has_sigma) qsg -= w->cfs;
   if (S && !w->frozen_lambda) {
     double pT[6];
     for (int j = 0; j < S; ++j) {
@@ -703,11 +735,12 @@ static void primal_update(prob_t* p, double alpha) {
 }
 
 /* Solve the QP with a Mehrotra predictor-corrector interior-point method.  The iteration
- * stops when the average complementarity mu <= tol (default 1e-11) and every row residual is
- * below 1e-9.  Accuracy note (DESIGN.md "numerics"): the plain Riccati recursion folds the
- * barrier weights lam/t into the cost-to-go, which limits the attainable stationarity once
- * lam/t exceeds ~1e12; the returned point is typically within 1e-8 (scaled) of the optimum
- * and within 1e-3 in the worst case, the same order as OSQP's eps = 1e-3 in the reference.    */
+ * stops when the average complementarity mu <= tol (default 1e-13) and every row residual is
+ * below 1e-9.  Accuracy (DESIGN.md "numerics"): the cost-to-go is kept exactly symmetric and the last
+ * iterations (mu <= JOSEPH_MU) factorise in the stabilised form, so the Newton directions stay accurate
+ * down to mu ~ 1e-14; against the dense optimum the returned point is within 1e-6 (scaled) wherever strict
+ * complementarity holds with a margin >= 1e-4 (oracle/qp.py strict_complementarity) and within ~1e-5 on
+ * degenerate problems, where any interior point is O(sqrt(mu)) away.                                 */
 static int ipm_solve(prob_t* p, work_t* w, int* iters_out, double* kkt_out) {
   const int N = p->N, S = p->S;
   const double tau = 0.995, mu0 = 0.1, thr_frac = 0.5;
@@ -719,7 +752,6 @@ static int ipm_solve(prob_t* p, work_t* w, int* iters_out, double* kkt_out) {
    * point lands on the minimiser exactly (the cost is quadratic).                              */
   memset(w->th, 0, sizeof(w->th));
   memset(w->cf, 0, sizeof(w->cf));
-  w->ths = w->cfs = 0.0;
   for (int j = 0; j < S; ++j) {
     p->lmb[j] = 1.0 / S;
     w->thl[j] = 1.0;
@@ -727,7 +759,7 @@ static int ipm_solve(prob_t* p, work_t* w, int* iters_out, double* kkt_out) {
   }
   p->sigma = 0.0;
   w->frozen_lambda = 1;
-  newton_factor(p, w);
+  newton_factor(p, w, 0);
   for (int i = 0; i < N - 1; ++i) {
     for (int a = 0; a < 2; ++a) {
       double acc = 0.0;
@@ -764,18 +796,13 @@ static int ipm_solve(prob_t* p, work_t* w, int* iters_out, double* kkt_out) {
         ++m;
       }
     }
-  if (p->has_sigma) {
-    p->ts = 0.1;
-    p->lams = mu0 / p->ts;
-    ++m;
-  }
   for (int j = 0; j < S; ++j) {
     p->tl[j] = p->lmb[j];
     p->ll[j] = mu0 / p->tl[j];
     ++m;
   }
   int status = LMPC_SOLVE_MAX_ITER, it = 0;
-  double mu = 0.0, rdmax = 0.0, rd_check = 0.0, mu_prev = INFINITY;
+  double mu = 0.0, rdmax = 0.0, rd_check = 0.0;
 
   /* ================= phase 1: interior point ================= */
   for (it = 0; it <= p->max_iter; ++it) {
@@ -791,12 +818,6 @@ static int ipm_solve(prob_t* p, work_t* w, int* iters_out, double* kkt_out) {
           musum += p->t[i][sl][sd] * p->lam[i][sl][sd];
           w->th[i][sl][sd] = p->lam[i][sl][sd] / p->t[i][sl][sd];
         }
-    if (p->has_sigma) {
-      w->rds = -p->sigma + p->ts;
-      if (fabs(w->rds) > rdmax) rdmax = fabs(w->rds);
-      musum += p->ts * p->lams;
-      w->ths = p->lams / p->ts;
-    }
     for (int j = 0; j < S; ++j) {
       w->rdl[j] = -p->lmb[j] + p->tl[j];
       if (fabs(w->rdl[j]) > rdmax) rdmax = fabs(w->rdl[j]);
@@ -812,13 +833,6 @@ static int ipm_solve(prob_t* p, work_t* w, int* iters_out, double* kkt_out) {
       status = LMPC_SOLVE_OPTIMAL;
       break;
     }
-    /* accuracy floor: with the rows feasible, a complementarity that has stopped halving within two decades of
-     * the tolerance is as small as the Riccati recursion can make it (weights lam/t ~ 1e12 cancel in P) */
-    if (rdmax <= 1e-9 && mu <= 100.0 * p->tol && mu > 0.5 * mu_prev) {
-      status = LMPC_SOLVE_OPTIMAL;
-      break;
-    }
-    mu_prev = mu;
     /* primal infeasibility: the row residual contracts by (1 - alpha) per iteration on a feasible problem; if it
      * has not lost a tenth over five iterations while still large (step lengths stuck below ~2 %), give up.  (A
      * tighter test -- "not halved" -- rejects feasible problems with a slow start: IAC at 60 m/s into a corner
@@ -832,9 +846,9 @@ static int ipm_solve(prob_t* p, work_t* w, int* iters_out, double* kkt_out) {
     }
     if (it == p->max_iter) break;
     cost_gradient(p, w);
-    newton_factor(p, w);
+    newton_factor(p, w, mu <= JOSEPH_MU);
     double sigc = 0.0, alpha = 1.0;
-    int numerics_failed = 0, degenerate_stop = 0;
+    int numerics_failed = 0;
     for (int pass = 0; pass < 2; ++pass) {
       for (int i = 0; i < N; ++i)
         for (int sl = 0; sl < NSLOT; ++sl)
@@ -844,10 +858,6 @@ static int ipm_solve(prob_t* p, work_t* w, int* iters_out, double* kkt_out) {
             if (pass == 1) c += (sigc * mu - p->dtt[i][sl][sd] * p->dlam[i][sl][sd]) / p->t[i][sl][sd];
             w->cf[i][sl][sd] = c;
           }
-      if (p->has_sigma) {
-        w->cfs = w->ths * w->rds;
-        if (pass == 1) w->cfs += (sigc * mu - p->dts * p->dlams) / p->ts;
-      }
       for (int j = 0; j < S; ++j) {
         w->cfl[j] = w->thl[j] * w->rdl[j];
         if (pass == 1) w->cfl[j] += (sigc * mu - p->dtl[j] * p->dll[j]) / p->tl[j];
@@ -883,12 +893,6 @@ static int ipm_solve(prob_t* p, work_t* w, int* iters_out, double* kkt_out) {
             if (dl_ < 0 && -lam / dl_ < amax) amax = -lam / dl_;
           }
         }
-      if (p->has_sigma) {
-        p->dts = -w->rds + p->dsigma;
-        p->dlams = -p->lams + w->cfs - w->ths * w->rds - w->ths * p->dts;
-        if (p->dts < 0 && -p->ts / p->dts < amax) amax = -p->ts / p->dts;
-        if (p->dlams < 0 && -p->lams / p->dlams < amax) amax = -p->lams / p->dlams;
-      }
       for (int j = 0; j < S; ++j) {
         p->dtl[j] = -w->rdl[j] + p->dlmb[j];
         p->dll[j] = -p->ll[j] + w->cfl[j] - w->thl[j] * w->rdl[j] - w->thl[j] * p->dtl[j];
@@ -902,17 +906,9 @@ static int ipm_solve(prob_t* p, work_t* w, int* iters_out, double* kkt_out) {
             for (int sd = 0; sd < 2; ++sd)
               if (p->act[i][sl][sd])
                 s += (p->t[i][sl][sd] + amax * p->dtt[i][sl][sd]) * (p->lam[i][sl][sd] + amax * p->dlam[i][sl][sd]);
-        if (p->has_sigma) s += (p->ts + amax * p->dts) * (p->lams + amax * p->dlams);
         for (int j = 0; j < S; ++j) s += (p->tl[j] + amax * p->dtl[j]) * (p->ll[j] + amax * p->dll[j]);
         const double ratio = (s / m) / mu;
         sigc = ratio * ratio * ratio;
-        /* degenerate problem (no strict complementarity): late in the iteration the affine step stops making
-         * progress (mu_aff / mu > 0.4, against 1e-2 .. 1e-3 on a regular problem) and the remaining iterations only
-         * add the Riccati recursion's noise to an iterate that is O(sqrt(mu)) from the optimum anyway -- keep it */
-        if (mu <= 1e-8 && rdmax <= 1e-9 && ratio > 0.4) {
-          degenerate_stop = 1;
-          break;
-        }
       } else {
         alpha = tau * amax;
         if (alpha > 1.0) alpha = 1.0;
@@ -920,10 +916,6 @@ static int ipm_solve(prob_t* p, work_t* w, int* iters_out, double* kkt_out) {
     }
     if (numerics_failed) {
       status = (mu <= 10.0 * p->tol && rdmax <= 1e-9) ? LMPC_SOLVE_OPTIMAL : LMPC_SOLVE_MAX_ITER;
-      break;
-    }
-    if (degenerate_stop) {
-      status = LMPC_SOLVE_OPTIMAL;
       break;
     }
     primal_update(p, alpha);
@@ -934,10 +926,6 @@ static int ipm_solve(prob_t* p, work_t* w, int* iters_out, double* kkt_out) {
             p->t[i][sl][sd] += alpha * p->dtt[i][sl][sd];
             p->lam[i][sl][sd] += alpha * p->dlam[i][sl][sd];
           }
-    if (p->has_sigma) {
-      p->ts += alpha * p->dts;
-      p->lams += alpha * p->dlams;
-    }
     for (int j = 0; j < S; ++j) {
       p->tl[j] += alpha * p->dtl[j];
       p->ll[j] += alpha * p->dll[j];
@@ -948,7 +936,7 @@ static int ipm_solve(prob_t* p, work_t* w, int* iters_out, double* kkt_out) {
   double rg = 0.0, viol = rdmax;
   if (status != LMPC_SOLVE_INFEASIBLE) {
     cost_gradient(p, w);
-    rg = stationarity(p, w, p->lam, p->lams, p->ll);
+    rg = stationarity(p, w, p->lam, p->ll);
   }
   if (kkt_out) {
     kkt_out[0] = rg;
@@ -975,7 +963,7 @@ static void setup_problem(prob_t* p, const lmpc_config* cfg, const lmpc_vehicle*
   p->has_sigma = cfg->q_boundary > 0.0;
   p->S = cfg->learning ? cfg->num_ss_pts : 0;
   p->max_iter = cfg->max_iter > 0 ? cfg->max_iter : 40;
-  p->tol = cfg->tol > 0 ? cfg->tol : 1e-11;
+  p->tol = cfg->tol > 0 ? cfg->tol : 1e-13;
   for (int i = 0; i < N - 1; ++i) {
     double x[6], u[2], xp[6];
     for (int k = 0; k < 6; ++k) x[k] = X_ref[(size_t)(k * N + i) * B + b];

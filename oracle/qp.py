@@ -349,6 +349,32 @@ def kkt_certificate(qp: DenseQP, y: np.ndarray, act_tol: float = 1e-5) -> dict:
     }
 
 
+def strict_complementarity(qp: DenseQP, y: np.ndarray, lam: np.ndarray) -> float:
+    """min over the inequality rows of max(lam_j, slack_j) at the dense optimum (physical units): the margin by
+    which strict complementarity holds.  An interior-point iterate with complementarity mu sits ~ mu / margin from
+    the optimum in the rows that attain the minimum (and ~ sqrt(mu) when the margin is zero), so this number -- not
+    the solver under test -- decides which problems can be held to the contract tolerance; tests label a problem
+    DEGENERATE when it is below DEGENERATE_MARGIN.
+
+    The row  -sigma <= 0  is left out when it is decoupled: sigma* = 0 with every boundary row inactive (multiplier
+    0).  It is then degenerate by construction (sigma* = 0 and, by stationarity 2 q sigma = sum of the boundary
+    multipliers + its own, multiplier 0) in every problem that stays inside the track, but sigma enters nothing
+    else, so X, U, dU do not depend on how that row is resolved."""
+    slack = qp.d - qp.C @ y
+    keep = np.ones(qp.C.shape[0], dtype=bool)
+    if qp.has_sigma:
+        nnz = (qp.C != 0.0).sum(axis=1)
+        on_sig = qp.C[:, qp.isig] != 0.0
+        sig_row = on_sig & (nnz == 1)
+        boundary = on_sig & (nnz == 2)
+        if abs(y[qp.isig]) <= 1e-12 and not (lam[boundary] > 1e-12).any():
+            keep &= ~sig_row
+    return float(np.maximum(lam, slack)[keep].min())
+
+
+DEGENERATE_MARGIN = 1e-4
+
+
 def pack(qp: DenseQP, X, U, dU, sigma=None, lam=None, eps=None) -> np.ndarray:
     """Inverse of DenseQP.split (sigma/eps recomputed optimally if omitted)."""
     N = qp.N

@@ -208,7 +208,7 @@ int lmpc_create(const lmpc_config* cfg, const lmpc_vehicle* veh, int device, lmp
   P.learning = cfg->learning ? 1 : 0;
   P.S = cfg->learning ? cfg->num_ss_pts : 0;
   P.max_iter = cfg->max_iter > 0 ? cfg->max_iter : 40;
-  P.tol = cfg->tol > 0.0 ? cfg->tol : 1e-11;
+  P.tol = cfg->tol > 0.0 ? cfg->tol : 1e-13;
   const double qd[6] = {0.0, cfg->q_contour, cfg->q_heading, cfg->q_vel, cfg->q_vy, cfg->q_vyaw};
   const double qt[6] = {0.0, cfg->q_contour, cfg->q_heading, cfg->q_vel, 0.0, 0.0};
   for (int k = 0; k < 6; ++k) {

@@ -292,11 +292,11 @@ __device__ __forceinline__ float rfma(float a, float b, float c) { return __buil
 template <typename real> struct ipm_limits;
 template <> struct ipm_limits<double> {
   static __device__ __forceinline__ double tol(double cfg) { return cfg; }
-  static constexpr double rd_ok = 1e-9, rd_infeasible = 1e-6, tiny = 1e-300, degenerate_mu = 1e-8;
+  static constexpr double rd_ok = 1e-9, rd_infeasible = 1e-6, tiny = 1e-300;
 };
 template <> struct ipm_limits<float> {
   static __device__ __forceinline__ float tol(double cfg) { return fmaxf((float)cfg, 2e-6f); }
-  static constexpr float rd_ok = 1e-4f, rd_infeasible = 1e-2f, tiny = 1e-30f, degenerate_mu = 0.0f;  // (rule off)
+  static constexpr float rd_ok = 1e-4f, rd_infeasible = 1e-2f, tiny = 1e-30f;
 };
 template <typename real> struct vec2;
 template <> struct vec2<double> { typedef double2 type; };
@@ -408,7 +408,15 @@ __device__ __forceinline__ real qz_entry(const real* ct, bool terminal, int r, i
 // own element of P / W in a register, everything that does not depend on the chain (model rows, barrier
 // weights) is fetched one stage ahead, and the three exchanges per stage (P, W, Y rows through LDS) are
 // the only waits; the 2x2 inverse starts from v_readlane copies of Y_uu while the Y rows are in flight.
-template <bool HAS_PT, typename real>
+//
+// JOSEPH selects the stabilised form of the cost-to-go update, P <- Qz + Thz + Phi' P Phi + K' (Sv + Thv) K with
+// Phi = Abar - Bbar K: the same matrix in exact arithmetic, but a sum of positive semidefinite products.  The plain form
+// Y - G'K subtracts two numbers of the size of the largest barrier weight (1e10 .. 1e13 late in the iteration) to leave
+// one of the size of the cost, and the Newton directions lose those digits (the former "mu ~ 1e-11 floor"); here the
+// cancellation happens inside Phi, before the multiplication by P.  It costs a second pair of 8x8 products (8-term,
+// Phi has no identity block), so the iteration uses it only once mu <= JOSEPH_MU: about two factorisations per solve.
+#define JOSEPH_MU 1e-8
+template <bool HAS_PT, bool JOSEPH, typename real>
 __device__ void riccati_factor(const Lds<real>& L, int lane, const real* PT) {
   const int N = L.N, r = lane >> 3, c = lane & 7;
   real* T = L.tail();
@@ -485,7 +493,7 @@ __device__ void riccati_factor(const Lds<real>& L, int lane, const real* PT) {
     const real y6r = MY[6 * MROW + r], y7r = MY[7 * MROW + r];
     const real y6c = MY[6 * MROW + c], y7c = MY[7 * MROW + c];
     AFTER_VALUE(y);
-    {  // phase-1/2 operands of the next stage (their registers are dead by now), queued behind the Y rows
+    if constexpr (!JOSEPH) {  // phase-1/2 operands of the next stage (their registers are dead by now), queued behind the Y rows
       const real* stn = L.st(i > 0 ? i - 1 : 0);
 #pragma unroll
       for (int k = 0; k < 6; ++k) {
@@ -512,7 +520,62 @@ __device__ void riccati_factor(const Lds<real>& L, int lane, const real* PT) {
     const real g0 = t * y6c, g1 = t * y7c;
     const real k0c = hi00 * g0 + hi01 * g1;
     const real k1c = hi01 * g0 + hi11 * g1;
-    real pn = qmid + y - t * (y6r * k0c + y7r * k1c);
+    real pn;
+    if constexpr (JOSEPH) {
+      // the gain at this lane's ROW index as well: K[:, r] from Y[6:8, r], the same expression lane (., r) evaluates
+      const real g0r = t * y6r, g1r = t * y7r;
+      const real k0r = hi00 * g0r + hi01 * g1r;
+      const real k1r = hi01 * g0r + hi11 * g1r;
+      // columns r and c of Phi (overwriting the columns of Abar they are made from); B = Abar[:, 6:8] as broadcast reads
+      {
+        real b0[6], b1[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+          b0[k] = st[ST_ROW(6) + k];
+          b1[k] = st[ST_ROW(7) + k];
+        }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+          ar[k] -= t * (b0[k] * k0r + b1[k] * k1r);
+          ac[k] -= t * (b0[k] * k0c + b1[k] * k1c);
+        }
+      }
+      const real fr6 = (r == 6 ? real(1) : real(0)) - t * k0r, fr7 = (r == 7 ? real(1) : real(0)) - t * k1r;
+      const real fc6 = (c == 6 ? real(1) : real(0)) - t * k0c, fc7 = (c == 7 ? real(1) : real(0)) - t * k1c;
+      // W2 = Phi' P (P symmetric: P[k][c] read as P[c][k]), exchanged through the W matrix (its phase-2 reads are done)
+      real w2 = 0.0;
+      {
+        real pc[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) pc[k] = MP[c * MROW + k];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) w2 += ar[k] * pc[k];
+        w2 += fr6 * pc[6] + fr7 * pc[7];
+      }
+      MW[r * MROW + c] = w2;
+      wave_sync();
+      real y2 = 0.0;
+      {
+        real w2r[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) w2r[k] = MW[r * MROW + k];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) y2 += w2r[k] * ac[k];
+        y2 += w2r[6] * fc6 + w2r[7] * fc7;
+      }
+      {  // operands of the next stage
+        const real* stn = L.st(i > 0 ? i - 1 : 0);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+          ar[k] = stn[ST_ROW(r) + k];
+          ac[k] = stn[ST_ROW(c) + k];
+        }
+      }
+      const real v00 = sv00 + thv0, v11 = sv11 + thv1;
+      pn = qmid + y2 + k0r * (v00 * k0c + sv01 * k1c) + k1r * (sv01 * k0c + v11 * k1c);
+    } else {
+      pn = qmid + y - t * (y6r * k0c + y7r * k1c);
+    }
     const real th = thr + (r == 1 ? ey : real(0));
     if (diag) pn += th;
     *p_dst0 = pn;  // (not used after stage 0)
@@ -853,7 +916,7 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
       m_rows += sx.on[q] ? 1.0 : 0.0;
     }
   }
-  const real m_tot = wave_sum(m_rows) + (has_sigma ? real(1) : real(0));
+  const real m_tot = wave_sum(m_rows);
   const real inv_m = uni(real(1) / m_tot);
 
   // knot-0 feasibility: the state box applies to x_0 = x_ic (racing_mpc.cpp:147,201)
@@ -871,7 +934,10 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
     feasible = wave_min(ok ? 1.0 : 0.0) > 0.5;
   }
 
-  real sigma = 0.0, ts = 0.1, lams = 0.0;
+  // The row sigma >= 0 (racing_mpc.cpp:536) is redundant and not carried: replacing a negative sigma by 0 loosens every
+  // boundary row and lowers q_boundary sigma^2, so the QP without the row has the same optimum.  Carried, it is a
+  // degenerate row whenever the boundary is inactive (sigma* = 0, multiplier 0) and costs two to three iterations.
+  real sigma = 0.0;
 
   // ---------------- start point: minimiser of the cost over the dynamics alone ----------------
 #pragma unroll
@@ -883,7 +949,7 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
     if (lane < 36) T[TL_PT + lane] = (lane % 7 == 0) ? ct[CT_E + lane / 7] : 0.0;
   }
   wave_sync();
-  riccati_factor<(KS > 0)>(L, lane, T + TL_PT);
+  riccati_factor<(KS > 0), false>(L, lane, T + TL_PT);
   feedback_rollout(L, lane);
   if constexpr (KS > 0) {
     real ul[6] = {0, 0, 0, 0, 0, 0};
@@ -906,7 +972,7 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
 
   const real tau = 0.995, mu0 = 0.1, thr_frac = 0.5;
   int status = LMPC_SOLVE_MAX_ITER, it = 0;
-  real mu = 0.0, mu_prev = inf, rdmax = 0.0, rd_check = 0.0, last_step = 0.0, hsig = 0.0, ce = 0.0;
+  real mu = 0.0, rdmax = 0.0, rd_check = 0.0, last_step = 0.0, hsig = 0.0, ce = 0.0;
   const int max_iter = feasible ? P.max_iter : 0;
 
   // it == -1 is the start-point Newton step (all row weights zero, full step); it >= 0 the
@@ -1028,11 +1094,7 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
         hsig = qsig + red[1];
       }
       rdmax = wave_max(rdl);
-      if (has_sigma) {
-        musum += ts * lams;
-        rdmax = fmax(rdmax, fabs(-sigma + ts));
-        hsig = uni(hsig + lams / ts);
-      }
+      hsig = uni(hsig);
       mu = uni(musum * inv_m);
       if (!(mu == mu) || !(rdmax == rdmax)) {
         status = LMPC_SOLVE_INFEASIBLE;
@@ -1042,13 +1104,6 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
         status = LMPC_SOLVE_OPTIMAL;
         break;
       }
-      // accuracy floor: with the rows feasible, a complementarity that has stopped halving within two decades
-      // of the tolerance is as small as the Riccati recursion can make it (weights lam/t ~ 1e12 cancel in P)
-      if (rdmax <= lim::rd_ok && mu <= real(100) * tol && mu > real(0.5) * mu_prev) {
-        status = LMPC_SOLVE_OPTIMAL;
-        break;
-      }
-      mu_prev = mu;
       // primal infeasibility: on a feasible problem the row residual contracts by (1 - alpha) per iteration; not
       // losing a tenth over five iterations while still large (step lengths stuck below ~2 %) ends the solve (this
       // also bounds the straggler that would otherwise hold its CU slot for max_iter iterations).  "Not halved" is
@@ -1063,12 +1118,15 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
       if (it == max_iter) break;
       wave_sync();
       PT_MARK(2)
-      riccati_factor<(KS > 0)>(L, lane, T + TL_PT);
+      if (sizeof(real) == 8 && mu <= real(JOSEPH_MU))  // (single precision stops at mu ~ 2e-6)
+        riccati_factor<(KS > 0), (sizeof(real) == 8)>(L, lane, T + TL_PT);
+      else
+        riccati_factor<(KS > 0), false>(L, lane, T + TL_PT);
       PT_MARK(3)
     }
 
-    real sigc = 0.0, alpha = 1.0, dsigma = 0.0, dts = 0.0, dlams = 0.0;
-    bool numerics_failed = false, degenerate_stop = false;
+    real sigc = 0.0, alpha = 1.0, dsigma = 0.0;
+    bool numerics_failed = false;
     real eeps[6] = {0, 0, 0, 0, 0, 0};  // E eps of this iterate (safe-set block), in scalar registers
     if constexpr (KS > 0) {
 #pragma unroll
@@ -1175,7 +1233,6 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
         for (int q = 0; q < KQ; ++q) d_val[q] = dz0[q];
         break;
       }
-      real cfs = 0.0;
       if (has_sigma) {
         real red[3] = {0.0, 0.0, sgsum};  // c'dz (this rhs), c'e (Schur vector), sum of boundary coefficients
         {
@@ -1191,9 +1248,7 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
         }
         wave_sum_n<3>(red);
         if (pass == 0) ce = red[1];
-        const real its = frcp(ts);
-        cfs = lams * its * (-sigma + ts) + (smu - pm * dts * dlams) * its;
-        const real qsg = qsig * sigma - red[2] - cfs;
+        const real qsg = qsig * sigma - red[2];
         dsigma = uni(-(qsg + red[0]) / (hsig + ce));
       }
       if constexpr (KS > 0) {
@@ -1282,12 +1337,6 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
         numerics_failed = true;
         break;
       }
-      if (has_sigma) {
-        const real th = lams / ts, rds = -sigma + ts;
-        dts = uni(-rds + dsigma);
-        dlams = uni(-lams + cfs - th * rds - th * dts);
-        rmax = fmax(rmax, fmax(-dts / ts, -dlams / lams));
-      }
       const real amax = uni(real(1) / rmax);
       if (pass == 1) alpha = uni(fmin(real(1), tau * amax));
       real sacc = 0.0;
@@ -1321,26 +1370,14 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
       }
       if (pass == 0) {
         sacc = wave_sum(sacc);
-        if (has_sigma) sacc += (ts + amax * dts) * (lams + amax * dlams);
         const real ratio = (sacc * inv_m) / mu;
         sigc = uni(ratio * ratio * ratio);
-        // degenerate problem (no strict complementarity): late in the iteration the affine step stops making
-        // progress (mu_aff / mu > 0.4, against 1e-2 .. 1e-3 on a regular problem) and further iterations only add
-        // the recursion's noise to an iterate that is O(sqrt(mu)) from the optimum anyway -- keep it
-        if (mu <= lim::degenerate_mu && rdmax <= lim::rd_ok && ratio > real(0.4)) {
-          degenerate_stop = true;
-          break;
-        }
         wave_sync();
       }
     }
 
     if (numerics_failed) {
       status = (mu <= real(10) * tol && rdmax <= lim::rd_ok) ? LMPC_SOLVE_OPTIMAL : LMPC_SOLVE_MAX_ITER;
-      break;
-    }
-    if (degenerate_stop) {
-      status = LMPC_SOLVE_OPTIMAL;
       break;
     }
     // ======== primal update by the component owners ========
@@ -1356,11 +1393,7 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
     wave_sync();
     if (ipm) {
       last_step = wave_max(stepmax);
-      if (has_sigma) {
-        sigma = uni(sigma + alpha * dsigma);
-        ts = uni(ts + alpha * dts);
-        lams = uni(lams + alpha * dlams);
-      }
+      if (has_sigma) sigma = uni(sigma + alpha * dsigma);
     } else {
       // ---- slacks and multipliers at the start point: t = max(slack, 0.5 range), lam = mu0 / t ----
       real val[KQ];
@@ -1385,8 +1418,6 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
         }
       }
       sigma = 0.0;
-      ts = 0.1;
-      lams = has_sigma ? mu0 / ts : 0.0;
       if constexpr (KS > 0) {
 #pragma unroll
         for (int q = 0; q < KS; ++q) sx.l[q] = sx.on[q] ? mu0 / sx.t[q] : 0.0;

@@ -15,7 +15,7 @@ def work(args):
     y, info = Q.solve_dense(qp)
     ex = qp.split(y)
     slack = qp.d - qp.C @ y
-    sc = float(np.maximum(info["lam"], slack).min())
+    sc = Q.strict_complementarity(qp, y, info["lam"])
     return b, info["status"], bool(info.get("polished")), ex["X_optm"], ex["U_optm"], ex["dU_optm"], sc
 
 if __name__ == "__main__":
@@ -40,9 +40,13 @@ if __name__ == "__main__":
             res = pool.map(work, [(N, b, kind) for b in range(B)])
         pickle.dump(res, open(cache, "wb"))
     tol = float(os.environ.get("TWIN_TOL", "0"))
+    if os.environ.get("TWIN_LIB"):
+        import ctypes
+        cbind._LIB = ctypes.CDLL(os.environ["TWIN_LIB"])
+        if not tol: tol = 1e-11
     if tol:
         o = cbind.solve_batch(cfg, veh, inp, tol=tol)
-        print("twin tol", tol, "status", np.bincount(o["status"], minlength=3), "mean iters", o["iters"].mean())
+        print("twin tol", tol, "status", np.bincount(o["status"], minlength=3), "mean iters", o["iters"].mean(), "hist", np.bincount(o["iters"]))
     ex_ = np.zeros(B); eu_ = np.zeros(B); sc_ = np.zeros(B); dst = np.zeros(B, int)
     for b, st, pol, X, U, dU, sc in res:
         ex_[b] = (np.abs(o["X_optm"][:, :, b] - X) / P.SCALE_X[:, None]).max()

@@ -143,10 +143,11 @@ class Riccati:
         return dz, dv
 
 
-def ipm(st, Solver, max_iter=60, tol=1e-11, verbose=False, start="lq", trace=None):
+def ipm(st, Solver, max_iter=60, tol=1e-11, verbose=False, start="lq", trace=None, sig_row=True):
     N = st.N
+    SR = 1.0 if (st.has_sigma and sig_row) else 0.0
     act_u = np.isfinite(st.hi); act_l = np.isfinite(st.lo)
-    m = act_u.sum() + act_l.sum() + (1 if st.has_sigma else 0)
+    m = act_u.sum() + act_l.sum() + SR
     z = np.zeros((N, 8)); v = np.zeros((N - 1, 2))
     z[0] = st.z0
 
@@ -176,7 +177,7 @@ def ipm(st, Solver, max_iter=60, tol=1e-11, verbose=False, start="lq", trace=Non
     rng = np.maximum(np.nan_to_num(rng, nan=1.0, posinf=1.0), 1e-3)
     tu = np.where(act_u, np.maximum(st.hi - sv, 0.5 * rng), 1.0); tl = np.where(act_l, np.maximum(sv - st.lo, 0.5 * rng), 1.0)
     lu = np.where(act_u, 0.1 / tu, 0.0); ll = np.where(act_l, 0.1 / tl, 0.0)
-    sigma, ts, lams = 0.0, 0.1, (1.0 if st.has_sigma else 0.0)
+    sigma, ts, lams = 0.0, 0.1, SR
     status = 1
     hiF = np.where(act_u, st.hi, 0.0); loF = np.where(act_l, st.lo, 0.0)
     for it in range(max_iter + 1):
@@ -184,8 +185,8 @@ def ipm(st, Solver, max_iter=60, tol=1e-11, verbose=False, start="lq", trace=Non
         sg = np.zeros((N, NSLOT)); sg[:, 10] = sigma if st.has_sigma else 0.0
         rdu = np.where(act_u, sv - sg + tu - hiF, 0.0); rdl = np.where(act_l, -sv - sg + tl + loF, 0.0)
         thu = lu / tu; thl = ll / tl
-        mu = ((lu * tu).sum() + (ll * tl).sum() + ts * lams * st.has_sigma) / m
-        rd = max(np.abs(rdu).max(), np.abs(rdl).max(), abs(-sigma + ts) if st.has_sigma else 0.0)
+        mu = ((lu * tu).sum() + (ll * tl).sum() + ts * lams * SR) / m
+        rd = max(np.abs(rdu).max(), np.abs(rdl).max(), abs(-sigma + ts) if SR else 0.0)
         # dynamics residual
         dyn = max(np.abs(z[i + 1] - st.Ab[i] @ z[i] - st.Bb[i] @ v[i] - st.gb[i]).max() for i in range(N - 1))
         if verbose:
@@ -203,7 +204,7 @@ def ipm(st, Solver, max_iter=60, tol=1e-11, verbose=False, start="lq", trace=Non
         Hz[:, 1, 1] += th[:, 10]
         Hv[:, 0, 0] += th[:N - 1, 8]; Hv[:, 1, 1] += th[:N - 1, 9]
         csig = (thl[:, 10] - thu[:, 10]) if st.has_sigma else np.zeros(N)
-        hsig = st.qsig + th[:, 10].sum() + lams / ts if st.has_sigma else 1.0
+        hsig = st.qsig + th[:, 10].sum() + SR * lams / ts if st.has_sigma else 1.0
         f = Solver(st, Hz, Hv)
         if trace is not None:
             trace.append((Hz, Hv, f))
@@ -224,7 +225,7 @@ def ipm(st, Solver, max_iter=60, tol=1e-11, verbose=False, start="lq", trace=Non
             dz, dv = f.solve(qz, qv)
             dsig = 0.0
             if st.has_sigma:
-                cfs = lams / ts * (-sigma + ts) + (smu - pas * dts * dlams) / ts
+                cfs = SR * (lams / ts * (-sigma + ts) + (smu - pas * dts * dlams) / ts)
                 qsg = st.qsig * sigma - (cu[:, 10] + cl[:, 10]).sum() - cfs
                 dsig = -(qsg + (csig[1:] * dz[1:, 1]).sum()) / (hsig + ce)
                 dz = dz + dsig * ez; dv = dv + dsig * ev
@@ -238,14 +239,14 @@ def ipm(st, Solver, max_iter=60, tol=1e-11, verbose=False, start="lq", trace=Non
                 neg = d_ < 0
                 if neg.any():
                     amax = min(amax, float((-t_[neg] / d_[neg]).min()))
-            if st.has_sigma:
+            if SR:
                 dts = -(-sigma + ts) + dsig
                 dlams = -lams + cfs - lams / ts * (-sigma + ts) - lams / ts * dts
                 if dts < 0: amax = min(amax, -ts / dts)
                 if dlams < 0: amax = min(amax, -lams / dlams)
             if pas == 0:
                 s = ((tu + amax * dtu) * (lu + amax * dlu)).sum() + ((tl + amax * dtl) * (ll + amax * dll)).sum()
-                if st.has_sigma: s += (ts + amax * dts) * (lams + amax * dlams)
+                if SR: s += (ts + amax * dts) * (lams + amax * dlams)
                 sigc = ((s / m) / mu) ** 3
                 pu = dtu * dlu; pl = dtl * dll
         alpha = min(1.0, 0.995 * amax)
@@ -254,7 +255,7 @@ def ipm(st, Solver, max_iter=60, tol=1e-11, verbose=False, start="lq", trace=Non
         z[1:] += alpha * dz[1:]; v += alpha * dv
         tu += alpha * dtu; tl += alpha * dtl; lu += alpha * dlu; ll += alpha * dll
         if st.has_sigma:
-            sigma += alpha * dsig; ts += alpha * dts; lams += alpha * dlams
+            sigma += alpha * dsig; ts += alpha * dts * SR; lams += alpha * dlams * SR
     return {"z": z, "v": v, "sigma": sigma, "status": status, "iters": it, "mu": mu, "rd": rd}
 
 

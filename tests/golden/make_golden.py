@@ -31,7 +31,7 @@ veh, cfg, tr, laps, inp, q = LS.make(16, 5)
 ss_x, ss_j, nf = LS.oracle_safe_set(cfg, laps, q)
 N, B = cfg.N, 16
 X = np.zeros((6, N, B)); U = np.zeros((2, N - 1, B)); dU = np.zeros((2, N - 1, B)); obj = np.zeros(B); ok = np.zeros(B, bool)
-cert = np.zeros((4, B))
+cert = np.zeros((4, B)); margin = np.zeros(B)
 for b in range(B):
     qp = OQ.build_qp(cfg, veh, OS.problem(inp, b), ss_x=ss_x[:, :, b], ss_j=ss_j[:, b])
     y, info = OQ.solve_dense(qp)
@@ -41,9 +41,10 @@ for b in range(B):
     c = OQ.kkt_certificate(qp, y)
     cert[:, b] = [c["stat"], c["eq"], c["ineq"], c["comp"]]
     ok[b] = info["status"] == 0
-    print("qp_barc_lmpc_n20", b, info["status"], info.get("polished"), c)
+    margin[b] = OQ.strict_complementarity(qp, y, info["lam"])
+    print("qp_barc_lmpc_n20", b, info["status"], info.get("polished"), c, margin[b])
 np.savez_compressed(Path(__file__).parent / "qp_barc_lmpc_n20.npz", X_optm=X, U_optm=U, dU_optm=dU, objective=obj,
-                    kkt_cert=cert, certified=ok, ss_x=ss_x, ss_j=ss_j, query=q,
+                    kkt_cert=cert, certified=ok, margin=margin, ss_x=ss_x, ss_j=ss_j, query=q,
                     **{k: np.asarray(v) for k, v in inp.items()})
 
 for name, (veh, cfg, kind, B, seed) in CASES.items():
@@ -59,6 +60,7 @@ for name, (veh, cfg, kind, B, seed) in CASES.items():
     obj = np.zeros(B)
     cert = np.zeros((4, B))
     ok = np.zeros(B, dtype=bool)
+    margin = np.zeros(B)
     for b in range(B):
         qp = OQ.build_qp(cfg, veh, OS.problem(inp, b))
         y, info = OQ.solve_dense(qp)
@@ -68,7 +70,8 @@ for name, (veh, cfg, kind, B, seed) in CASES.items():
         c = OQ.kkt_certificate(qp, y)
         cert[:, b] = [c["stat"], c["eq"], c["ineq"], c["comp"]]
         ok[b] = info["status"] == 0 and bool(info.get("polished"))
-        print(name, b, info["status"], info.get("polished"), c)
+        margin[b] = OQ.strict_complementarity(qp, y, info["lam"])
+        print(name, b, info["status"], info.get("polished"), c, margin[b])
     arrs = {k: np.asarray(v) for k, v in inp.items()}
     np.savez_compressed(Path(__file__).parent / f"{name}.npz", X_optm=X, U_optm=U, dU_optm=dU, sigma=sig,
-                        objective=obj, kkt_cert=cert, certified=ok, **arrs)
+                        objective=obj, kkt_cert=cert, certified=ok, margin=margin, **arrs)
