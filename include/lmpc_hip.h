@@ -92,7 +92,7 @@ typedef struct lmpc_config {
   int32_t num_ss_pts_per_lap; /* K                                                          */
   int32_t max_lap_stored;
   int32_t max_iter;           /* interior-point iteration cap (<=0: default 40)             */
-  double tol;                 /* complementarity tolerance (<=0: default 1e-13)             */
+  double tol;                 /* complementarity tolerance (<=0: default 3e-14)             */
   double margin;
   double q_contour, q_heading, q_vel, q_vy, q_vyaw, q_boundary;
   double R[4];                /* row-major 2x2                                              */
@@ -213,11 +213,16 @@ int lmpc_ss_query_host(lmpc_handle* h, const double* query, double* ss_x, double
  * SSTrajectory::query(RegQuery) (safe_set.cpp:56-114), SafeSetManager::query(RegQuery) (:182-245) -- BASELINE
  * config 5.  For every linearisation point a kernel-weighted ridge regression of the nominal model's one-step error
  * over the lap samples within dist_max of [X_ref[in_state]; U_ref[in_ctrl]] is added onto (A, B, g):
- *   K_j = 0.75/h (1 - (d_j/h)^2)^2,  M = [z_j' 1],  R_r = (M'KM + 1e-3 I)^-1 (-M'K y_r)   (minus sign as written),
- *   A[r, in_state] += R_r[0:ns],  B[r, in_ctrl] += R_r[ns:ns+nc],  g[r] += R_r[-1].
- * The reference never calls this query and two of its expressions do not type-check as written; the reading taken
- * (same index lists for every regressed row, nominal step evaluated on the full recorded state, residual of the
- * regressed row, dt_j = t_j - t_{j+1} as process_lap_data writes it) is documented in oracle/regression.py.
+ *   K_j = 0.75/h (1 - (d_j/h)^2)^2,  M = [z_j' 1],  R_r = (M'KM + 1e-3 I)^-1 M'K y_r,
+ *   A[r, in_state] += R_r[0:ns],  B[r, in_ctrl] += R_r[ns:ns+nc],  g[r] += R_r[-1],
+ * with y_r,j = x_{j+1}[r] - f_d(x_j, u_j, k_j, t_{j+1} - t_j)[r], so that the corrected model's one-step error on the
+ * recorded samples is the least-squares residual (it shrinks).  The reference never calls this query and two of its
+ * expressions do not type-check as written; the reading taken (same index lists for every regressed row, nominal step
+ * evaluated on the full recorded state, residual of the regressed row) is documented in oracle/regression.py.
+ * AS WRITTEN upstream the step is dt_j = t_j - t_{j+1} < 0 (process_lap_data, safe_set.cpp:130-135: the nominal model is
+ * integrated backwards) and b = -M'K y (:229-231): the correction then points away from the data -- which is consistent
+ * with the query having no caller.  `as_written = 1` reproduces exactly that for comparison; the default (0) is the
+ * physically meaningful regression, and only that one should be switched on in front of a solve.
  * Built for (n_in_state + n_in_ctrl, n_out) = (5, 3) -- rows vx, vy, yaw rate on (vx, vy, yaw rate; u) -- and (8, 6). */
 typedef struct lmpc_regression_spec {
   int32_t n_out;       /* reg_out_state_idxs: one state index per regressed row */
@@ -226,7 +231,7 @@ typedef struct lmpc_regression_spec {
   int32_t in_state[6];
   int32_t n_in_ctrl;   /* reg_in_control_idxs */
   int32_t in_ctrl[2];
-  int32_t reserved;
+  int32_t as_written;  /* 0: dt = t_{j+1} - t_j, b = +M'K y (default); 1: the reference's literal signs (see above) */
   double dist_max;     /* RegQuery::dist_max, the kernel bandwidth h */
 } lmpc_regression_spec;
 

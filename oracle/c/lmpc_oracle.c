@@ -401,9 +401,14 @@ typedef struct {
 /* floor on the simplex rows' barrier weight inside the Newton matrix: keeps 1/theta of the points
  * with lambda > 0 from swamping E^-1 in F = E^-1 + T.  It only regularises the Newton matrix (a
  * proximal term on d lambda); residuals and row updates use the true weights, so the fixed point is
- * unchanged.  Measured on BARC LMPC problems: 1e-3 gives 1e-9 agreement with the dense optimum,
- * 1e-6 gives 1e-5, none stalls at mu ~ 1e-8. */
-#define TH_L_MIN 1e-3
+ * unchanged.  The value is a compromise between two failure modes (measured, scratch/r2_lmpc_fail.py + the CPU replay of
+ * the problems it dumps, the golden vectors, 256 fresh problems): too large and the proximal iteration stalls at
+ * mu ~ 1e-8 on closed-loop problems whose support has two or three points (1e-3: 95 % of those problems hit the iteration
+ * cap); too small and cond(F) ~ E |u|^2 / floor exceeds what the explicit 6x6 inverse carries (1e-6: 5e-4 from the
+ * dense optimum on the golden vectors, 1e-7: the iteration diverges).  1e-4: 1e-10 / 4e-8 agreement, no stall. */
+#define TH_L_MIN 1e-4
+/* complementarity below which a step that does not lower it ends the solve (ipm_solve) */
+#define STALL_MU 1e-9
 /* complementarity below which the factorisation switches to the stabilised form (riccati_factor) */
 #define JOSEPH_MU 1e-8
 
@@ -735,7 +740,7 @@ static void primal_update(prob_t* p, double alpha) {
 }
 
 /* Solve the QP with a Mehrotra predictor-corrector interior-point method.  The iteration
- * stops when the average complementarity mu <= tol (default 1e-13) and every row residual is
+ * stops when the average complementarity mu <= tol (default 3e-14) and every row residual is
  * below 1e-9.  Accuracy (DESIGN.md "numerics"): the cost-to-go is kept exactly symmetric and the last
  * iterations (mu <= JOSEPH_MU) factorise in the stabilised form, so the Newton directions stay accurate
  * down to mu ~ 1e-14; against the dense optimum the returned point is within 1e-6 (scaled) wherever strict
@@ -848,7 +853,7 @@ static int ipm_solve(prob_t* p, work_t* w, int* iters_out, double* kkt_out) {
     cost_gradient(p, w);
     newton_factor(p, w, mu <= JOSEPH_MU);
     double sigc = 0.0, alpha = 1.0;
-    int numerics_failed = 0;
+    int numerics_failed = 0, stalled = 0;
     for (int pass = 0; pass < 2; ++pass) {
       for (int i = 0; i < N; ++i)
         for (int sl = 0; sl < NSLOT; ++sl)
@@ -912,7 +917,23 @@ static int ipm_solve(prob_t* p, work_t* w, int* iters_out, double* kkt_out) {
       } else {
         alpha = tau * amax;
         if (alpha > 1.0) alpha = 1.0;
+        /* no further progress: with the rows feasible and the complementarity already small, a corrector step that
+         * would not lower it (the Newton direction has reached the accuracy of the factorisation; seen on learning
+         * problems whose speed rides its bound over most of the horizon) ends the solve at the current iterate
+         * instead of letting mu wander upwards until the iteration cap */
+        double s = 0.0;
+        for (int i = 0; i < N; ++i)
+          for (int sl = 0; sl < NSLOT; ++sl)
+            for (int sd = 0; sd < 2; ++sd)
+              if (p->act[i][sl][sd])
+                s += (p->t[i][sl][sd] + alpha * p->dtt[i][sl][sd]) * (p->lam[i][sl][sd] + alpha * p->dlam[i][sl][sd]);
+        for (int j = 0; j < S; ++j) s += (p->tl[j] + alpha * p->dtl[j]) * (p->ll[j] + alpha * p->dll[j]);
+        if (rdmax <= 1e-9 && mu <= STALL_MU && s / m >= mu) stalled = 1;
       }
+    }
+    if (stalled) {
+      status = LMPC_SOLVE_OPTIMAL;
+      break;
     }
     if (numerics_failed) {
       status = (mu <= 10.0 * p->tol && rdmax <= 1e-9) ? LMPC_SOLVE_OPTIMAL : LMPC_SOLVE_MAX_ITER;
@@ -963,7 +984,7 @@ static void setup_problem(prob_t* p, const lmpc_config* cfg, const lmpc_vehicle*
   p->has_sigma = cfg->q_boundary > 0.0;
   p->S = cfg->learning ? cfg->num_ss_pts : 0;
   p->max_iter = cfg->max_iter > 0 ? cfg->max_iter : 40;
-  p->tol = cfg->tol > 0 ? cfg->tol : 1e-13;
+  p->tol = cfg->tol > 0 ? cfg->tol : 3e-14;
   for (int i = 0; i < N - 1; ++i) {
     double x[6], u[2], xp[6];
     for (int k = 0; k < 6; ++k) x[k] = X_ref[(size_t)(k * N + i) * B + b];

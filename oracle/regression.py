@@ -13,9 +13,16 @@ would read the first column only.  The reading restated here (and in csrc/lmpc_r
   * for the regressed row r the residual is that row's: y_r = x_{j+1}[r] - x_pred[r];
   * one (in_state, in_ctrl) feature list shared by all regressed rows (the reference allows one list per row);
   * everything else as written: the last sample of a lap is dropped, candidates with d < dist_max, weights
-    K = 0.75/h (1 - (d/h)^2)^2 (:224-225), M = [xs' us' 1], Q = M'KM + 1e-3 I, b = -M'K y (minus sign as written,
-    :229-231), R = Q^-1 b, A[r, in_state] += R[0:ns], B[r, in_ctrl] += R[ns:-1], C[r] += R[-1] (:235-242); a query
-    with no candidate leaves (A, B, C) untouched (:207-210).
+    K = 0.75/h (1 - (d/h)^2)^2 (:224-225), M = [xs' us' 1], Q = M'KM + 1e-3 I, R = Q^-1 b,
+    A[r, in_state] += R[0:ns], B[r, in_ctrl] += R[ns:-1], C[r] += R[-1] (:235-242); a query with no candidate leaves
+    (A, B, C) untouched (:207-210).
+Two signs, one switch.  AS WRITTEN upstream the nominal step is taken with dt_j = t_j - t_{j+1} < 0 (process_lap_data
+stores the differences that way round, :130-135) -- the model is integrated backwards in time, so the "residual" is about
+twice the true step -- and the right-hand side is b = -M'K y (:229-231): the correction points away from the data, which
+is consistent with the query never being called.  `as_written=True` restates exactly that.  The default is the
+regression that does what its name says: dt_j = t_{j+1} - t_j, b = +M'K y, so that A x + B u + C moves TOWARDS the
+recorded successor states (tests/test_regression_oracle.py: a plant with a perturbed parameter is predicted better
+after the correction).  The product applies the default in front of a solve (include/lmpc_hip.h).
 """
 from __future__ import annotations
 
@@ -25,17 +32,18 @@ from .dynamics import rk4
 from .params import Vehicle
 
 
-def lap_residuals(veh: Vehicle, x: np.ndarray, u: np.ndarray, k: np.ndarray, t: np.ndarray) -> np.ndarray:
+def lap_residuals(veh: Vehicle, x: np.ndarray, u: np.ndarray, k: np.ndarray, t: np.ndarray, as_written: bool = False) -> np.ndarray:
     """x [n, 6], u [n, 2], k [n], t [n] of one lap -> one-step residuals [n - 1, 6] of the nominal model."""
     n = x.shape[0]
     y = np.zeros((n - 1, 6))
     for j in range(n - 1):
-        y[j] = x[j + 1] - rk4(x[j], u[j], float(k[j]), float(t[j] - t[j + 1]), veh)
+        dt = float(t[j] - t[j + 1]) if as_written else float(t[j + 1] - t[j])
+        y[j] = x[j + 1] - rk4(x[j], u[j], float(k[j]), dt, veh)
     return y
 
 
 def regress(veh: Vehicle, laps: list, in_state, in_ctrl, out_rows, dist_max: float, q_x: np.ndarray, q_u: np.ndarray,
-            A: np.ndarray, B: np.ndarray, C: np.ndarray):
+            A: np.ndarray, B: np.ndarray, C: np.ndarray, as_written: bool = False):
     """laps: list of (x [n,6], u [n,2], k [n], t [n]); linearisation point (q_x [6], q_u [2]); returns updated copies."""
     A, B, C = A.copy(), B.copy(), C.copy()
     in_state, in_ctrl = list(in_state), list(in_ctrl)
@@ -43,7 +51,7 @@ def regress(veh: Vehicle, laps: list, in_state, in_ctrl, out_rows, dist_max: flo
     Z, Y = [], []
     for (x, u, k, t) in laps:
         Z.append(np.concatenate([x[:-1][:, in_state], u[:-1][:, in_ctrl]], axis=1))
-        Y.append(lap_residuals(veh, x, u, k, t))
+        Y.append(lap_residuals(veh, x, u, k, t, as_written))
     Z, Y = np.concatenate(Z), np.concatenate(Y)
     d = np.sqrt(((Z - q) ** 2).sum(axis=1))
     m = d < dist_max
@@ -55,7 +63,7 @@ def regress(veh: Vehicle, laps: list, in_state, in_ctrl, out_rows, dist_max: flo
     Q = M.T @ (K[:, None] * M) + 1e-3 * np.eye(M.shape[1])
     ns = len(in_state)
     for r in out_rows:
-        R = np.linalg.solve(Q, -M.T @ (K * Y[:, r]))
+        R = np.linalg.solve(Q, (-1.0 if as_written else 1.0) * (M.T @ (K * Y[:, r])))
         A[r, in_state] += R[:ns]
         B[r, in_ctrl] += R[ns:-1]
         C[r] += R[-1]

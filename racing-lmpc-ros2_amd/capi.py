@@ -49,7 +49,7 @@ class CConfig(C.Structure):
 class CRegressionSpec(C.Structure):
     """lmpc_regression_spec: RegQuery's index lists and bandwidth (safe_set.hpp:57-75)."""
     _fields_ = [("n_out", C.c_int32), ("out", C.c_int32 * 6), ("n_in_state", C.c_int32), ("in_state", C.c_int32 * 6),
-                ("n_in_ctrl", C.c_int32), ("in_ctrl", C.c_int32 * 2), ("reserved", C.c_int32), ("dist_max", C.c_double)]
+                ("n_in_ctrl", C.c_int32), ("in_ctrl", C.c_int32 * 2), ("as_written", C.c_int32), ("dist_max", C.c_double)]
 
 
 class CTrack(C.Structure):
@@ -377,8 +377,10 @@ class Solver:
         self._check(rc, "lmpc_set_safe_set")
 
     # ---- error-dynamics regression (safe_set.cpp:56-114, 182-245) ----
-    def set_regression_laps(self, laps, in_state=(3, 4, 5), in_ctrl=(0, 1), out_rows=(3, 4, 5), dist_max: float = 1.0):
-        """laps: list of (x [n,6], u [n,2], k [n], t [n]) host arrays; an empty list switches the regression off."""
+    def set_regression_laps(self, laps, in_state=(3, 4, 5), in_ctrl=(0, 1), out_rows=(3, 4, 5), dist_max: float = 1.0,
+                            as_written: bool = False):
+        """laps: list of (x [n,6], u [n,2], k [n], t [n]) host arrays; an empty list switches the regression off.
+        as_written = True reproduces the reference's literal signs (backward time step, b = -M'K y; lmpc_hip.h)."""
         import numpy as np
 
         if not laps:
@@ -393,6 +395,7 @@ class Solver:
         spec.out[:len(out_rows)] = list(out_rows)
         spec.in_state[:len(in_state)] = list(in_state)
         spec.in_ctrl[:len(in_ctrl)] = list(in_ctrl)
+        spec.as_written = 1 if as_written else 0
         rc = self.lib.lmpc_set_regression_laps(self._h, C.c_int32(len(laps)), n_pts.ctypes.data_as(C.c_void_p),
                                                *[a.ctypes.data_as(C.c_void_p) for a in cat], C.byref(spec))
         self._check(rc, "lmpc_set_regression_laps")

@@ -28,7 +28,7 @@ __global__ void lmpc_solve_kernel(lmpc_params, int, const io*, const io*, const 
                                   const io*, const io*, const io*, io*, io*, io*, io*, int*, int*, io*);
 __global__ void lmpc_ss_query_kernel(int, int, int, int, const int*, const int*, const double*, double, const double*,
                                      double*, double*, int*, double*);
-__global__ void lmpc_reg_residual_kernel(lmpc_vehicle, int, const int*, const double*, const double*, const double*,
+__global__ void lmpc_reg_residual_kernel(lmpc_vehicle, int, int, const int*, const double*, const double*, const double*,
                                          const double*, double*);
 template <int NF, int NOUT, bool WS_LAYOUT>
 __global__ void lmpc_regress_kernel(int, int, lmpc_regression_spec, int, const int*, const double*, const double*,
@@ -59,10 +59,17 @@ struct lmpc_handle {
   double* reg_u = nullptr;  // [total][2]
   double* reg_y = nullptr;  // [total][6]
   lmpc_regression_spec reg_spec{};
-  // staging for lmpc_solve_host (device + pinned-free host mirror)
+  // staging for the single-problem host entry points (lmpc_solve_host, lmpc_ss_query_host): device buffers and PINNED
+  // host mirrors, all sized and allocated by lmpc_create -- the per-step path of one controller allocates nothing
   double* stage_dev = nullptr;
+  double* stage_host = nullptr;
   size_t stage_doubles = 0;
   int* stage_int = nullptr;
+  int* stage_int_host = nullptr;
+  double* ssq_dev = nullptr;   // query [2] | ss_x [6][S] | ss_j [S] | j0
+  double* ssq_host = nullptr;
+  int* ssq_int = nullptr;
+  int* ssq_int_host = nullptr;
   // timing
   bool timing = false;
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
@@ -208,7 +215,7 @@ int lmpc_create(const lmpc_config* cfg, const lmpc_vehicle* veh, int device, lmp
   P.learning = cfg->learning ? 1 : 0;
   P.S = cfg->learning ? cfg->num_ss_pts : 0;
   P.max_iter = cfg->max_iter > 0 ? cfg->max_iter : 40;
-  P.tol = cfg->tol > 0.0 ? cfg->tol : 1e-13;
+  P.tol = cfg->tol > 0.0 ? cfg->tol : 3e-14;
   const double qd[6] = {0.0, cfg->q_contour, cfg->q_heading, cfg->q_vel, cfg->q_vy, cfg->q_vyaw};
   const double qt[6] = {0.0, cfg->q_contour, cfg->q_heading, cfg->q_vel, 0.0, 0.0};
   for (int k = 0; k < 6; ++k) {
@@ -241,6 +248,23 @@ int lmpc_create(const lmpc_config* cfg, const lmpc_vehicle* veh, int device, lmp
     return fail(h, LMPC_ERR_ARGUMENT, "R_d must be positive definite");
   HIP_TRY(h, hipSetDevice(device));
   for (auto& e : h->ev) HIP_TRY(h, hipEventCreate(&e));
+  {  // staging of the single-problem host path, once
+    const size_t N = (size_t)P.N, S = (size_t)P.S;
+    h->stage_doubles = 8 + 6 * N + 2 * (N - 1) + (N - 1) + 4 * N + 7 * S + 6 * N + 4 * (N - 1) + S;
+    HIP_TRY(h, hipMalloc(&h->stage_dev, h->stage_doubles * sizeof(double)));
+    HIP_TRY(h, hipHostMalloc(&h->stage_host, h->stage_doubles * sizeof(double)));
+    HIP_TRY(h, hipMalloc(&h->stage_int, 2 * sizeof(int)));
+    HIP_TRY(h, hipHostMalloc(&h->stage_int_host, 2 * sizeof(int)));
+    if (cfg->num_ss_pts >= 1) {
+      const size_t nd = 2 + 7 * (size_t)cfg->num_ss_pts + 1;
+      HIP_TRY(h, hipMalloc(&h->ssq_dev, nd * sizeof(double)));
+      HIP_TRY(h, hipHostMalloc(&h->ssq_host, nd * sizeof(double)));
+      HIP_TRY(h, hipMalloc(&h->ssq_int, sizeof(int)));
+      HIP_TRY(h, hipHostMalloc(&h->ssq_int_host, sizeof(int)));
+    }
+    const int rc = lmpc_reserve(h, 1);
+    if (rc != LMPC_OK) return rc;
+  }
   return LMPC_OK;
 }
 
@@ -259,6 +283,10 @@ void lmpc_destroy(lmpc_handle* h) {
   if (h->reg_y) (void)hipFree(h->reg_y);
   if (h->stage_dev) (void)hipFree(h->stage_dev);
   if (h->stage_int) (void)hipFree(h->stage_int);
+  if (h->ssq_dev) (void)hipFree(h->ssq_dev);
+  if (h->ssq_int) (void)hipFree(h->ssq_int);
+  for (void* q : {(void*)h->stage_host, (void*)h->stage_int_host, (void*)h->ssq_host, (void*)h->ssq_int_host})
+    if (q) (void)hipHostFree(q);
   for (auto& e : h->ev)
     if (e) (void)hipEventDestroy(e);
   delete h;
@@ -472,14 +500,9 @@ int lmpc_solve_host(lmpc_handle* h, const double* x_ic, const double* u_ic, cons
                o_k = o_br + N, o_v = o_k + N, o_sx = o_v + N, o_sj = o_sx + 6 * (size_t)S, o_Xo = o_sj + S,
                o_Uo = o_Xo + 6 * N, o_dUo = o_Uo + 2 * NS, o_lam = o_dUo + 2 * NS, total = o_lam + S;
   HIP_TRY(h, hipSetDevice(h->device));
-  if (h->stage_doubles < total) {
-    if (h->stage_dev) HIP_TRY(h, hipFree(h->stage_dev));
-    h->stage_dev = nullptr;
-    HIP_TRY(h, hipMalloc(&h->stage_dev, total * sizeof(double)));
-    h->stage_doubles = total;
-  }
-  if (!h->stage_int) HIP_TRY(h, hipMalloc(&h->stage_int, 2 * sizeof(int)));
-  std::vector<double> host(total, 0.0);
+  if (total != h->stage_doubles || !h->stage_dev || !h->stage_host) return fail(h, LMPC_ERR_RUNTIME, "lmpc_solve_host: staging not allocated");
+  double* const host = h->stage_host;  // pinned: the two copies below are asynchronous DMA transfers
+  for (size_t e = o_sx; e < o_Xo; ++e) host[e] = 0.0;
   for (int k = 0; k < 6; ++k) host[o_x + k] = x_ic[k];
   for (int k = 0; k < 2; ++k) host[o_u + k] = u_ic[k];
   for (int i = 0; i < N; ++i)
@@ -500,14 +523,14 @@ int lmpc_solve_host(lmpc_handle* h, const double* x_ic, const double* u_ic, cons
       host[o_sj + j] = ss_j[j];
     }
   double* d = h->stage_dev;
-  HIP_TRY(h, hipMemcpyAsync(d, host.data(), o_Xo * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(d, host, o_Xo * sizeof(double), hipMemcpyHostToDevice, h->stream));
   const int rc = lmpc_solve_batch(h, 1, d + o_x, d + o_u, d + o_X, d + o_U, d + o_T, d + o_bl, d + o_br, d + o_k, d + o_v,
                                   total_length, S ? d + o_sx : nullptr, S ? d + o_sj : nullptr, d + o_Xo, d + o_Uo,
                                   d + o_dUo, S ? d + o_lam : nullptr, h->stage_int, h->stage_int + 1, nullptr);
   if (rc != LMPC_OK) return rc;
-  int si[2] = {0, 0};
-  HIP_TRY(h, hipMemcpyAsync(host.data() + o_Xo, d + o_Xo, (total - o_Xo) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(h, hipMemcpyAsync(si, h->stage_int, sizeof(si), hipMemcpyDeviceToHost, h->stream));
+  int* const si = h->stage_int_host;
+  HIP_TRY(h, hipMemcpyAsync(host + o_Xo, d + o_Xo, (total - o_Xo) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(si, h->stage_int, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   for (int i = 0; i < N; ++i)
     for (int k = 0; k < 6; ++k) X_optm[(size_t)i * 6 + k] = host[o_Xo + (size_t)k * N + i];
@@ -664,28 +687,29 @@ int lmpc_ss_query_host(lmpc_handle* h, const double* query, double* ss_x, double
   const int S = h->cfg.num_ss_pts;
   if (S < 1 || h->cfg.num_ss_pts_per_lap < 1) return fail(h, LMPC_ERR_ARGUMENT, "num_ss_pts / num_ss_pts_per_lap not configured");
   if (h->cfg.num_ss_pts_per_lap > 64) return fail(h, LMPC_ERR_UNSUPPORTED, "num_ss_pts_per_lap > 64");
-  HIP_TRY(h, hipSetDevice(h->device));
-  const size_t nd = 2 + 7 * (size_t)S + 1;  // query | ss_x [6][S] | ss_j [S] | j0
-  double* d = nullptr;
-  int* di = nullptr;
-  HIP_TRY(h, hipMalloc(&d, nd * sizeof(double)));
-  HIP_TRY(h, hipMalloc(&di, sizeof(int)));
-  HIP_TRY(h, hipMemsetAsync(d, 0, nd * sizeof(double), h->stream));
-  HIP_TRY(h, hipMemcpyAsync(d, query, 2 * sizeof(double), hipMemcpyHostToDevice, h->stream));
   const size_t lds = (size_t)3 * (h->ss_nmax > 0 ? h->ss_nmax : 1) * sizeof(double);
   if (lds > 160 * 1024) return fail(h, LMPC_ERR_UNSUPPORTED, "lap longer than 6826 samples");
+  HIP_TRY(h, hipSetDevice(h->device));
+  const size_t nd = 2 + 7 * (size_t)S + 1;  // query | ss_x [6][S] | ss_j [S] | j0
+  double* const d = h->ssq_dev;   // handle-owned staging (lmpc_create): nothing is allocated or freed per call
+  int* const di = h->ssq_int;
+  double* const host = h->ssq_host;
+  if (!d || !di || !host) return fail(h, LMPC_ERR_RUNTIME, "lmpc_ss_query_host: staging not allocated");
+  for (size_t e = 0; e < nd; ++e) host[e] = 0.0;
+  host[0] = query[0];
+  host[1] = query[1];
+  *h->ssq_int_host = 0;
+  HIP_TRY(h, hipMemcpyAsync(d, host, nd * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(di, h->ssq_int_host, sizeof(int), hipMemcpyHostToDevice, h->stream));
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&lmpc_ss_query_kernel),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(lmpc_ss_query_kernel, dim3(8), dim3(64), lds, h->stream, 1, h->ss_laps, S, h->cfg.num_ss_pts_per_lap,
                      h->ss_npts, h->ss_off, h->ss_x, h->ss_L, d, d + 2, d + 2 + 6 * (size_t)S, di, d + 2 + 7 * (size_t)S);
   HIP_TRY(h, hipGetLastError());
-  std::vector<double> host(nd);
-  int nf = 0;
-  HIP_TRY(h, hipMemcpyAsync(host.data(), d, nd * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(h, hipMemcpyAsync(&nf, di, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(host, d, nd * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(h->ssq_int_host, di, sizeof(int), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
-  HIP_TRY(h, hipFree(d));
-  HIP_TRY(h, hipFree(di));
+  const int nf = *h->ssq_int_host;
   for (int j = 0; j < S; ++j) {
     for (int k = 0; k < 6; ++k) ss_x[(size_t)j * 6 + k] = host[2 + (size_t)k * S + j];  // -> column-major 6 x S
     ss_j[j] = host[2 + 6 * (size_t)S + j];
@@ -740,7 +764,7 @@ int lmpc_set_regression_laps(lmpc_handle* h, int32_t n_laps, const int32_t* n_pt
   HIP_TRY(h, hipMemcpy(dk, k, total * sizeof(double), hipMemcpyHostToDevice));
   HIP_TRY(h, hipMemcpy(dt, t, total * sizeof(double), hipMemcpyHostToDevice));
   hipLaunchKernelGGL(lmpc_reg_residual_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, h->P.veh,
-                     (int)total, h->reg_end, h->reg_x, h->reg_u, dk, dt, h->reg_y);
+                     (int)total, spec->as_written ? 1 : 0, h->reg_end, h->reg_x, h->reg_u, dk, dt, h->reg_y);
   HIP_TRY(h, hipGetLastError());
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   HIP_TRY(h, hipFree(dk));

@@ -5,13 +5,17 @@
 // one-step model error over the lap samples within dist_max in feature space, added onto (A, B, g).
 //   features  z_j = [x_j[in_state]; u_j[in_ctrl]]   (the last sample of a lap has no successor and is skipped, :68-76)
 //   weights   K_j = 0.75 / h (1 - (d_j / h)^2)^2  for  d_j = ||z_j - q|| < h                      (:84-87, :224-225)
-//   M = [z_j' 1],  Q = M' K M + 1e-3 I,  b_r = - M' K y_r  (minus sign as written, :229-231),  R_r = Q^-1 b_r
+//   M = [z_j' 1],  Q = M' K M + 1e-3 I,  b_r = M' K y_r,  R_r = Q^-1 b_r      (upstream writes b_r = - M' K y_r, :229-231)
 //   A[r, in_state] += R_r[0:ns],  B[r, in_ctrl] += R_r[ns:ns+nc],  g[r] += R_r[-1]               (:235-242)
 // The reference has no caller and no test for this query, and two of its expressions do not type-check as written
 // (the nominal model is handed the in_state rows instead of the state; the residual is taken on the in_state rows
 // for every output).  The restatement (oracle/regression.py documents the same reading) evaluates the nominal RK4
 // step on the full recorded state and regresses, for output row r, the residual of that row:
-//   y_r,j = x_{j+1}[r] - f_d(x_j, u_j, k_j, dt_j)[r],   dt_j = t_j - t_{j+1}  (negative, as process_lap_data writes it, :130-135).
+//   y_r,j = x_{j+1}[r] - f_d(x_j, u_j, k_j, dt_j)[r],   dt_j = t_{j+1} - t_j.
+// As written upstream dt_j = t_j - t_{j+1} is negative (process_lap_data, :130-135: the model steps backwards in time, the
+// "residual" is about twice the true step) and the right-hand side carries a minus sign, so the correction points away
+// from the data; spec.as_written = 1 reproduces that literally, the default is the regression that reduces the one-step
+// error (include/lmpc_hip.h).
 //
 // Two kernels: lmpc_reg_residual_kernel (once per lap upload: one thread per sample) and lmpc_regress_kernel (one
 // wavefront per (problem, stage): lanes stride over the samples, 21 + 6 NOUT weighted sums per lane in registers,
@@ -21,7 +25,7 @@
 #include "lmpc_device.h"
 #include "lmpc_dynamics.hip.h"
 
-__global__ void lmpc_reg_residual_kernel(lmpc_vehicle veh, int total, const int* __restrict__ lap_end, const double* __restrict__ x,
+__global__ void lmpc_reg_residual_kernel(lmpc_vehicle veh, int total, int as_written, const int* __restrict__ lap_end, const double* __restrict__ x,
                                          const double* __restrict__ u, const double* __restrict__ k,
                                          const double* __restrict__ t, double* __restrict__ y) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -33,7 +37,7 @@ __global__ void lmpc_reg_residual_kernel(lmpc_vehicle veh, int total, const int*
     for (int c = 0; c < 6; ++c) xs[c] = x[(size_t)j * 6 + c];
     us[0] = u[(size_t)j * 2];
     us[1] = u[(size_t)j * 2 + 1];
-    lmpc_rk4(veh, xs, us, k[j], t[j] - t[j + 1], xp);
+    lmpc_rk4(veh, xs, us, k[j], as_written ? t[j] - t[j + 1] : t[j + 1] - t[j], xp);
 #pragma unroll
     for (int c = 0; c < 6; ++c) r[c] = x[(size_t)(j + 1) * 6 + c] - xp[c];
   }
@@ -132,7 +136,7 @@ __global__ __launch_bounds__(64) void lmpc_regress_kernel(int N, int B, lmpc_reg
     double yv[NM], R[NM];
 #pragma unroll
     for (int r = 0; r < NM; ++r) {
-      double tt = -acc[NQ + o * NM + r];  // b = -M'K y
+      double tt = spec.as_written ? -acc[NQ + o * NM + r] : acc[NQ + o * NM + r];  // b = M'K y  (as written: -M'K y)
 #pragma unroll
       for (int k = 0; k < r; ++k) tt -= Lc[r * NM + k] * yv[k];
       yv[r] = tt * Lc[r * NM + r];

@@ -109,7 +109,8 @@ struct Prof {};
 #define TL_A 440    // a = U Th^-1 1
 #define TL_FIA 446  // F^-1 a
 #define TL_S11 452  // s11 = 1'M^-1 1
-#define TH_L_MIN 1e-3  // floor of the simplex rows' weight inside the Newton matrix (see oracle/c/lmpc_oracle.c)
+#define TH_L_MIN 1e-4  // floor of the simplex rows' weight inside the Newton matrix (see oracle/c/lmpc_oracle.c)
+#define STALL_MU 1e-9  // complementarity below which a step that does not lower it ends the solve
 #define F_UP 1
 #define F_LO 2
 #define F_SIG 4
@@ -797,8 +798,9 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
       KN0[lane] = real((lane == 0) ? x_ic[b] - s_shift : x_ic[(size_t)lane * B + b]);
       ct[CT_QD + lane] = P.learning ? 0.0 : P.Qd[lane];
       ct[CT_QT + lane] = P.learning ? 0.0 : P.Qt[lane];
-      ct[CT_HL + 2 * lane] = P.x_max[lane];
-      ct[CT_HL + 2 * lane + 1] = P.x_min[lane];
+      // (the abscissa box moves with the abscissa: single precision carries s relative to x_ic[0])
+      ct[CT_HL + 2 * lane] = lane == 0 ? real(io(P.x_max[0]) - s_shift) : real(P.x_max[lane]);
+      ct[CT_HL + 2 * lane + 1] = lane == 0 ? real(io(P.x_min[0]) - s_shift) : real(P.x_min[lane]);
     } else if (lane < 8) {
       KN0[lane] = real(u_ic[(size_t)(lane - 6) * B + b]);
       ct[CT_HL + 2 * lane] = P.u_hi[lane - 6];
@@ -1126,7 +1128,7 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
     }
 
     real sigc = 0.0, alpha = 1.0, dsigma = 0.0;
-    bool numerics_failed = false;
+    bool numerics_failed = false, stalled = false;
     real eeps[6] = {0, 0, 0, 0, 0, 0};  // E eps of this iterate (safe-set block), in scalar registers
     if constexpr (KS > 0) {
 #pragma unroll
@@ -1351,6 +1353,7 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
           s_lu[q] += alpha * dlu[q];
           s_tl[q] += alpha * dtl[q];
           s_ll[q] += alpha * dll[q];
+          sacc += s_tu[q] * s_lu[q] + s_tl[q] * s_ll[q];
         }
       }
       if constexpr (KS > 0) {
@@ -1365,8 +1368,15 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
             sx.t[q] += alpha * dt_;
             sx.l[q] += alpha * dl_;
             sx.lm[q] += alpha * sx.dl[q];
+            sacc += sx.on[q] ? sx.t[q] * sx.l[q] : 0.0;
           }
         }
+      }
+      if (pass == 1) {
+        // no further progress: rows feasible, complementarity already small, and the corrector step would not lower it
+        // (the Newton direction has reached the accuracy of the factorisation): keep the current primal iterate
+        sacc = wave_sum(sacc);
+        if (rdmax <= lim::rd_ok && mu <= real(STALL_MU) && sacc * inv_m >= mu) stalled = true;
       }
       if (pass == 0) {
         sacc = wave_sum(sacc);
@@ -1378,6 +1388,10 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
 
     if (numerics_failed) {
       status = (mu <= real(10) * tol && rdmax <= lim::rd_ok) ? LMPC_SOLVE_OPTIMAL : LMPC_SOLVE_MAX_ITER;
+      break;
+    }
+    if (stalled) {
+      status = LMPC_SOLVE_OPTIMAL;
       break;
     }
     // ======== primal update by the component owners ========

@@ -135,6 +135,9 @@ __global__ __launch_bounds__(64) void lmpc_ss_query_kernel(int B, int n_laps, in
       ARGMIN_STEP(0x143, 0xc)
       d = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(d), 63), __builtin_amdgcn_readlane(__double2loint(d), 63));
       i = __builtin_amdgcn_readlane(i, 63);
+      if (i == INT_MAX) {  // no finite distance left (a NaN query from a diverged car state): nothing more to take
+        break;
+      }
       const int rep = i / n, j = i - rep * n;
       const double jv = (double)(n - 1 - j) + (1 - rep) * (double)(n - 1);
       if (tot == 0) j0 = jv;
@@ -175,11 +178,14 @@ __global__ __launch_bounds__(64) void lmpc_ss_query_kernel(int B, int n_laps, in
     n_found[b] = tot;
     if (j0_out) j0_out[b] = j0;  // cost-to-go of the first point, subtracted from ss_j (racing_mpc.cpp:280)
   }
-  if (tot > 0)  // pad with the last point (racing_mpc.cpp:263-272)
-    for (int q = tot; q < S; ++q) {
-      if (lane < 6)
-        ss_x[((size_t)lane * S + q) * B + b] = last;
-      else if (lane == 6)
-        ss_j[(size_t)q * B + b] = last;
-    }
+  // pad with the last point (racing_mpc.cpp:263-272).  With nothing found (no lap stored, or a NaN query) the reference
+  // keeps its previous parameter values; a batch has no "previous", so the outputs are zero-filled -- defined data -- and
+  // n_found = 0 tells the caller not to solve on them.
+  if (tot == 0) last = 0.0;
+  for (int q = tot; q < S; ++q) {
+    if (lane < 6)
+      ss_x[((size_t)lane * S + q) * B + b] = last;
+    else if (lane == 6)
+      ss_j[(size_t)q * B + b] = last;
+  }
 }

@@ -33,10 +33,13 @@ RacingMPC::RacingMPC(RacingMPCConfig::SharedPtr mpc_config, VehicleModel::Shared
     h_ = nullptr;
     throw std::runtime_error("RacingMPC: lmpc_create failed: " + msg);
   }
-  if (config_->c.learning) {  // racing_mpc.cpp:57-66: manager sized by max_lap_stored, recorder writing under path_prefix
-    namespace rt = lmpc::vehicle_model::racing_trajectory;
-    ss_manager_.reset(new rt::SafeSetManager(h_, static_cast<std::size_t>(config_->c.max_lap_stored)));
-    ss_recorder_.reset(new rt::SafeSetRecorder(*ss_manager_, config_->record, config_->path_prefix));
+  // racing_mpc.cpp:58-61: manager sized by max_lap_stored and recorder writing under path_prefix exist for EVERY
+  // controller, learning or not -- a tracking controller with record = true is how the laps an LMPC run loads get
+  // written (hawaii_kart_tracking_mpc.param.yaml: learning false, record true, load true)
+  namespace rt = lmpc::vehicle_model::racing_trajectory;
+  ss_manager_.reset(new rt::SafeSetManager(h_, static_cast<std::size_t>(config_->c.max_lap_stored)));
+  ss_recorder_.reset(new rt::SafeSetRecorder(*ss_manager_, config_->record, config_->path_prefix));
+  if (config_->c.learning) {
     ss_x_.assign(6 * static_cast<std::size_t>(config_->c.num_ss_pts), 0.0);
     ss_j_.assign(static_cast<std::size_t>(config_->c.num_ss_pts), 0.0);
   }
@@ -70,7 +73,7 @@ void RacingMPC::solve(const DMDict& in, DMDict& out, Dict& stats) {
       vel_ref.data.size() != N || x_ic.data.size() != 6 || u_ic.data.size() != 2)
     throw std::length_error("RacingMPC::solve: input dimension does not match MPC dimension");
   const std::size_t S = config_->c.learning ? static_cast<std::size_t>(config_->c.num_ss_pts) : 0;
-  if (config_->c.learning) {  // racing_mpc.cpp:240-281
+  {  // racing_mpc.cpp:240-281: load, record and query unconditionally; only the solve's parameters depend on learning
     namespace rt = lmpc::vehicle_model::racing_trajectory;
     if (!ss_loaded_ && config_->load) {
       ss_recorder_->load(config_->load_path, total_length);
@@ -82,12 +85,12 @@ void RacingMPC::solve(const DMDict& in, DMDict& out, Dict& stats) {
     rt::SSQuery q;
     q.x = DM(6, 1);
     for (int r = 0; r < 6; ++r) q.x(r, 0) = X_ref(r, N - 1);
-    q.max_num_total = S;
+    q.max_num_total = static_cast<std::size_t>(config_->c.num_ss_pts);
     q.max_num_per_lap = static_cast<std::size_t>(config_->c.num_ss_pts_per_lap);
     const rt::SSResult ss = ss_manager_->query(q);
     out["ss_x"] = ss.x;
     out["ss_j"] = ss.J;
-    if (ss.x.size2() > 0) {  // pad with the last point or truncate; costs relative to the first (racing_mpc.cpp:263-280)
+    if (S && ss.x.size2() > 0) {  // pad with the last point or truncate; costs relative to the first (racing_mpc.cpp:263-280)
       const std::size_t n = ss.x.size2();
       for (std::size_t j = 0; j < S; ++j) {
         const std::size_t src = j < n ? j : n - 1;

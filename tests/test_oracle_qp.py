@@ -4,7 +4,8 @@ import pytest
 
 from conftest import scaled_err
 from oracle import cbind, params as P, qp as Q, scenario as S
-from tolerances import TOL_DU, TOL_MEDIAN, TOL_XU
+from parity import assert_contract
+from tolerances import TOL_MEDIAN
 
 CASES = [("qp_barc_tracking_n20", P.barc_vehicle, lambda: P.barc_tracking_mpc(20)),
          ("qp_barc_tracking_n10", P.barc_vehicle, lambda: P.barc_tracking_mpc(10)),
@@ -32,18 +33,14 @@ def test_c_twin_matches_golden(golden, name, veh, cfg):
     g = golden(name)
     veh, cfg = veh(), cfg()
     out = cbind.solve_batch(cfg, veh, g)
-    assert (out["status"] == 0).all(), out["status"]
     assert out["iters"].max() <= 30
-    ex = scaled_err(out["X_optm"], g["X_optm"], P.SCALE_X)
-    eu = scaled_err(out["U_optm"], g["U_optm"], P.SCALE_U)
-    ed = scaled_err(out["dU_optm"], g["dU_optm"], P.SCALE_U)
-    assert ex < TOL_XU and eu < TOL_XU and ed < TOL_DU, (ex, eu, ed)
+    assert_contract(out, g, g["margin"], g["certified"], who="twin")
     per = np.abs((out["X_optm"] - g["X_optm"]) / P.SCALE_X[:, None, None]).max(axis=(0, 1))
     assert np.median(per) < TOL_MEDIAN
     # the objective is reproduced far more tightly than the (flat-direction) variables
     for b in range(0, g["x_ic"].shape[1], 5):
         qp = Q.build_qp(cfg, veh, S.problem(g, b))
-        y = Q.pack(qp, out["X_optm"][:, :, b], out["U_optm"][:, :, b], out["dU_optm"][:, :, b], sigma=out["kkt"][3, b])
+        y = Q.pack(qp, out["X_optm"][:, :, b], out["U_optm"][:, :, b], out["dU_optm"][:, :, b], sigma=max(out["kkt"][3, b], 0.0))
         assert qp.objective(y) - g["objective"][b] < 1e-7 * (1 + abs(g["objective"][b]))
         assert np.abs(qp.A @ y - qp.b).max() < 1e-9
         assert (qp.C @ y - qp.d).max() < 1e-8
