@@ -55,12 +55,15 @@ typedef enum lmpc_status {
 #define LMPC_MODEL_SINGLE_TRACK_PLANAR 0
 #define LMPC_MODEL_KINEMATIC_BICYCLE 1
 #define LMPC_MODEL_DOUBLE_TRACK_PLANAR 2
+#define LMPC_INTEGRATOR_RK4 0
+#define LMPC_INTEGRATOR_EULER 1
 
 /* The ~25 scalars compile_dynamics/add_nlp_constraints read
  * (base_vehicle_model_config.hpp:30-154, single_track_planar_model.hpp:31-43). */
 typedef struct lmpc_vehicle {
   int32_t model_id;      /* LMPC_MODEL_SINGLE_TRACK_PLANAR                                */
-  int32_t reserved;
+  int32_t integrator;    /* modeling.integrator_type: LMPC_INTEGRATOR_RK4 (0) | LMPC_INTEGRATOR_EULER (1)
+                            (single_track_planar_model.cpp:357-368; lmpc_utils/src/utils.cpp:88-123)     */
   double m;              /* chassis.total_mass                                            */
   double Jzz;            /* chassis.moi                                                   */
   double l;              /* chassis.wheel_base                                            */
@@ -196,6 +199,35 @@ int lmpc_solve_host(lmpc_handle* h, const double* x_ic, const double* u_ic, cons
                     double total_length, const double* ss_x, const double* ss_j, double* X_optm,
                     double* U_optm, double* dU_optm, double* convex_combi_optm, int32_t* status,
                     int32_t* iters);
+
+/* RacingMPC(full_dynamics = true)::solve for a batch (racing_mpc.cpp:67-84: IPOPT on the problem whose dynamics rows are
+ * x_{i+1} = f_d(x_i, u_i, k_i, t_i), :162-166, instead of their linearisation; the node uses it for its very first
+ * solve, racing_mpc_node.cpp:299-314).  Sequential QPs over the batched kernels, globalised by a backtracking line search
+ * on the l1 merit function cost + nu |dynamics defect|_1 (csrc/lmpc_sqp_kernel.hip): linearise about the iterate, solve
+ * the QP, step, until the scaled step falls below step_tol or max_sqp QPs are spent.  The iterate starts at
+ * (X_ref, U_ref) -- the node hands its zero-input rollout, racing_mpc_node.cpp:210-235 -- with dU = 0, lambda = 0.
+ * DEVICE pointers, layouts of lmpc_solve_batch.  Outputs: the iterate reached; status [B] = status of the last QP taken
+ * into it; iters [B] = interior-point iterations summed over its QPs; sqp_iters [B] = steps taken; sqp_move [B] = scaled
+ * size of the last step (converged iff <= step_tol); defect [B] = |x_{i+1} - f_d(x_i, u_i)|_inf / scale_x of the
+ * iterate.  The first call for a batch size allocates a work area (like lmpc_reserve); synchronises the stream once per
+ * QP (it has to know whether any problem is still moving). */
+int lmpc_solve_full_dynamics_batch(lmpc_handle* h, int32_t batch, const double* x_ic, const double* u_ic, const double* X_ref,
+                                   const double* U_ref, const double* T_ref, const double* bound_left,
+                                   const double* bound_right, const double* curvatures, const double* vel_ref,
+                                   double total_length, const double* ss_x, const double* ss_j, int32_t max_sqp,
+                                   double step_tol, double* X_optm, double* U_optm, double* dU_optm,
+                                   double* convex_combi_optm, int32_t* status, int32_t* iters, int32_t* sqp_iters,
+                                   double* sqp_move, double* defect);
+
+/* The same for ONE problem with HOST pointers (layouts of lmpc_solve_host): what the facade's
+ * RacingMPC(config, model, full_dynamics = true) calls.  sqp_move / defect may be NULL. */
+int lmpc_solve_full_dynamics_host(lmpc_handle* h, const double* x_ic, const double* u_ic, const double* X_ref,
+                                  const double* U_ref, const double* T_ref, const double* bound_left,
+                                  const double* bound_right, const double* curvatures, const double* vel_ref,
+                                  double total_length, const double* ss_x, const double* ss_j, int32_t max_sqp,
+                                  double step_tol, double* X_optm, double* U_optm, double* dU_optm,
+                                  double* convex_combi_optm, int32_t* status, int32_t* iters, int32_t* sqp_iters,
+                                  double* sqp_move, double* defect);
 
 /* Safe set store: SafeSetManager::add_lap / SSTrajectory::process_lap_data
  * (safe_set.cpp:116-151).  HOST pointers: laps oldest first, lap j has n_pts[j] samples,

@@ -147,6 +147,10 @@ void lmpc_oracle_rk4(const lmpc_vehicle* v, const double* x, const double* u, do
                      double* xp) {
   double k1[6], k2[6], k3[6], k4[6], xs[6];
   f_only(v, x, u, k, k1);
+  if (v->integrator == LMPC_INTEGRATOR_EULER) { /* utils.cpp:110-123 */
+    for (int r = 0; r < 6; ++r) xp[r] = x[r] + dt * k1[r];
+    return;
+  }
   for (int r = 0; r < 6; ++r) xs[r] = x[r] + dt / 2.0 * k1[r];
   f_only(v, xs, u, k, k2);
   for (int r = 0; r < 6; ++r) xs[r] = x[r] + dt / 2.0 * k2[r];
@@ -177,11 +181,13 @@ void lmpc_oracle_linearize(const lmpc_vehicle* v, const double* x, const double*
         Ks[s][r * 8 + c] = acc;
       }
   }
+  const int euler = v->integrator == LMPC_INTEGRATOR_EULER; /* x+ = x + dt f(x, u): the first slope alone */
+  const double w0 = euler ? dt : dt / 6, w12 = euler ? 0.0 : dt / 3, w3 = euler ? 0.0 : dt / 6;
   for (int r = 0; r < 6; ++r) {
-    xp[r] = x[r] + dt / 6 * (ks[0][r] + 2 * ks[1][r] + 2 * ks[2][r] + ks[3][r]);
+    xp[r] = x[r] + (w0 * ks[0][r] + w12 * ks[1][r] + w12 * ks[2][r] + w3 * ks[3][r]);
     for (int c = 0; c < 8; ++c) {
       const double d = (r == c ? 1.0 : 0.0) +
-                       dt / 6 * (Ks[0][r * 8 + c] + 2 * Ks[1][r * 8 + c] + 2 * Ks[2][r * 8 + c] + Ks[3][r * 8 + c]);
+                       (w0 * Ks[0][r * 8 + c] + w12 * Ks[1][r * 8 + c] + w12 * Ks[2][r * 8 + c] + w3 * Ks[3][r * 8 + c]);
       if (c < 6)
         A[r * 6 + c] = d;
       else

@@ -18,7 +18,7 @@ _LIB = None
 
 
 class CVehicle(C.Structure):
-    _fields_ = [("model_id", C.c_int32), ("reserved", C.c_int32)] + [
+    _fields_ = [("model_id", C.c_int32), ("integrator", C.c_int32)] + [
         (n, C.c_double) for n in
         ("m Jzz l cg_ratio h b fr kd kb cd Af rho cl_f cl_r mu Bf Cf Br Cr Fd_max Fb_max Td Tb "
          "max_steer max_steer_rate").split()]
@@ -39,6 +39,7 @@ class CConfig(C.Structure):
 def c_vehicle(v: Vehicle) -> CVehicle:
     cv = CVehicle()
     cv.model_id = 0
+    cv.integrator = 1 if getattr(v, "integrator", "rk4") == "euler" else 0
     for name, _ in CVehicle._fields_[2:]:
         setattr(cv, name, float(getattr(v, name)))
     return cv

@@ -71,9 +71,12 @@ def f_continuous(x, u, k, v: Vehicle):
 
 
 def rk4(x, u, k, dt, v: Vehicle):
-    """utils.cpp:88-108 -- classic RK4 with u, k held over the step."""
+    """The model's discrete dynamics: utils.cpp:88-108 -- classic RK4 with u, k held over the step -- or, for a vehicle
+    with integrator = "euler" (modeling.integrator_type, single_track_planar_model.cpp:357-368), x + dt f (utils.cpp:110-123)."""
     dt_ = np.asarray(dt)[..., None] if np.ndim(dt) else dt
     k1 = f_continuous(x, u, k, v)
+    if getattr(v, "integrator", "rk4") == "euler":
+        return x + dt_ * k1
     k2 = f_continuous(x + dt_ / 2.0 * k1, u, k, v)
     k3 = f_continuous(x + dt_ / 2.0 * k2, u, k, v)
     k4 = f_continuous(x + dt_ * k3, u, k, v)

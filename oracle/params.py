@@ -55,6 +55,7 @@ class Vehicle:
     Tb: float
     max_steer: float
     max_steer_rate: float
+    integrator: str = "rk4"   # modeling.integrator_type: "rk4" | "euler"
 
     def as_array(self) -> np.ndarray:
         """Order of lmpc_vehicle in include/lmpc_hip.h."""

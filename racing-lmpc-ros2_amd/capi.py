@@ -19,7 +19,7 @@ _ABI_SYMBOLS = ("lmpc_create", "lmpc_destroy", "lmpc_last_error", "lmpc_set_stre
                 "lmpc_linearize_batch", "lmpc_solve_batch", "lmpc_set_safe_set", "lmpc_ss_query_batch",
                 "lmpc_prepare_batch", "lmpc_reserve", "lmpc_query_launch", "lmpc_enable_timing",
                 "lmpc_last_kernel_ms", "lmpc_query_residency", "lmpc_solve_host", "lmpc_shift_batch",
-                "lmpc_plant_step_batch", "lmpc_set_regression_laps", "lmpc_regress_batch", "lmpc_ss_query_host", "lmpc_solve_batch_f32",
+                "lmpc_plant_step_batch", "lmpc_solve_full_dynamics_batch", "lmpc_solve_full_dynamics_host", "lmpc_set_regression_laps", "lmpc_regress_batch", "lmpc_ss_query_host", "lmpc_solve_batch_f32",
                 "lmpc_solve_batch_mixed", "lmpc_prepare_failed_batch")
 
 
@@ -28,7 +28,7 @@ class LmpcError(RuntimeError):
 
 
 class CVehicle(C.Structure):
-    _fields_ = [("model_id", C.c_int32), ("reserved", C.c_int32)] + [
+    _fields_ = [("model_id", C.c_int32), ("integrator", C.c_int32)] + [
         (n, C.c_double) for n in
         ("m Jzz l cg_ratio h b fr kd kb cd Af rho cl_f cl_r mu Bf Cf Br Cr Fd_max Fb_max Td Tb "
          "max_steer max_steer_rate").split()]
@@ -61,6 +61,10 @@ class CTrack(C.Structure):
 def _fill(struct, values: dict):
     for name, ctype in struct._fields_:
         if name == "reserved":
+            continue
+        if name == "integrator":     # modeling.integrator_type, "rk4" (default) or "euler"
+            iv = values.get("integrator", 0)
+            setattr(struct, name, {"rk4": 0, "euler": 1}[iv] if isinstance(iv, str) else int(iv))
             continue
         v = values[name]
         if hasattr(ctype, "_length_"):
@@ -327,42 +331,35 @@ class Solver:
         return out
 
     # ---- full_dynamics = true (racing_mpc.cpp:162-166; IPOPT upstream, racing_mpc_node.cpp:299-314) ----
-    def solve_full_dynamics(self, inp: dict, max_sqp: int = 10, tol: float = 1e-9):
-        """The nonlinear-dynamics problem x_{i+1} = f_d(x_i, u_i, k_i, t_i) by sequential QPs over the same kernels:
-        re-linearise about the last solution until it stops moving (full steps; the per-knot parameters -- curvature,
-        bounds, vel_ref -- stay fixed, as they are parameters of the reference's NLP too).  Problems whose QP fails
-        keep their last successful iterate and report that QP's status.  Returns the last QP's output dict plus
-        "sqp_iters" [B] and "sqp_move" [B] (largest scaled change of X in the last accepted step)."""
+    def solve_full_dynamics(self, inp: dict, max_sqp: int = 10, tol: float = 1e-9, ss_x=None, ss_j=None):
+        """lmpc_solve_full_dynamics_batch: the nonlinear-dynamics problem x_{i+1} = f_d(x_i, u_i, k_i, t_i) by sequential
+        QPs over the same kernels with a line search on the l1 merit function (csrc/lmpc_sqp_kernel.hip); the per-knot
+        parameters -- curvature, bounds, vel_ref -- stay fixed, as they are parameters of the reference's NLP too.
+        Problems whose QP fails keep their last iterate and report that QP's status.  Returns the iterate reached plus
+        "sqp_iters" [B], "sqp_move" [B] (scaled size of the last step) and "defect" [B] (scaled dynamics defect)."""
         torch = self._torch
-        cur = dict(inp)
-        X = self._t(inp["X_ref"]).clone()
-        U = self._t(inp["U_ref"]).clone()
-        B = X.shape[2]
-        active = torch.ones(B, dtype=torch.bool, device=self.device)
-        sqp_iters = torch.zeros(B, dtype=torch.int32, device=self.device)
-        move = torch.full((B,), float("inf"), dtype=torch.float64, device=self.device)
-        scale = torch.tensor([2000.0, 10.0, 0.1, 80.0, 2.0, 2.0], dtype=torch.float64, device=self.device)[:, None, None]
-        out = None
-        for _ in range(max_sqp):
-            cur["X_ref"], cur["U_ref"] = X, U
-            o = self.solve(cur)
-            ok = (o["status"] == 0) & active
-            step = ((o["X_optm"] - X).abs() / scale).amax(dim=(0, 1))
-            X = torch.where(ok[None, None, :], o["X_optm"], X)
-            U = torch.where(ok[None, None, :], o["U_optm"], U)
-            move = torch.where(ok, step, move)
-            sqp_iters += ok.to(torch.int32)
-            if out is None:
-                out = {k: (v.clone() if hasattr(v, "clone") else v) for k, v in o.items()}
-            else:
-                for k in ("X_optm", "U_optm", "dU_optm"):
-                    out[k] = torch.where(ok[None, None, :], o[k], out[k])
-                for k in ("status", "iters"):
-                    out[k] = torch.where(active, o[k], out[k])
-            active = ok & (step > tol)
-            if not bool(active.any()):
-                break
-        out["sqp_iters"], out["sqp_move"] = sqp_iters, move
+        self.use_current_stream()
+        a = {k: self._t(inp[k]) for k in ("x_ic", "u_ic", "X_ref", "U_ref", "T_ref", "bound_left", "bound_right",
+                                          "curvatures", "vel_ref")}
+        B = a["x_ic"].shape[1]
+        out = self.alloc_outputs(B)
+        kw = dict(device=self.device)
+        out["sqp_iters"] = torch.zeros((B,), dtype=torch.int32, **kw)
+        out["sqp_move"] = torch.zeros((B,), dtype=torch.float64, **kw)
+        out["defect"] = torch.zeros((B,), dtype=torch.float64, **kw)
+        learning = bool(self.config["learning"])
+        if learning:
+            out["convex_combi_optm"] = torch.zeros((int(self.config["num_ss_pts"]), B), dtype=torch.float64, **kw)
+            ss_x, ss_j = self._t(ss_x), self._t(ss_j)
+        rc = self.lib.lmpc_solve_full_dynamics_batch(
+            self._h, C.c_int32(B), *[_ptr(a[k]) for k in ("x_ic", "u_ic", "X_ref", "U_ref", "T_ref", "bound_left",
+                                                           "bound_right", "curvatures", "vel_ref")],
+            C.c_double(float(inp.get("L", 0.0))), _ptr(ss_x) if learning else None, _ptr(ss_j) if learning else None,
+            C.c_int32(int(max_sqp)), C.c_double(float(tol)), _ptr(out["X_optm"]), _ptr(out["U_optm"]), _ptr(out["dU_optm"]),
+            _ptr(out["convex_combi_optm"]) if learning else None, _ptr(out["status"]), _ptr(out["iters"]),
+            _ptr(out["sqp_iters"]), _ptr(out["sqp_move"]), _ptr(out["defect"]))
+        self._check(rc, "lmpc_solve_full_dynamics_batch")
+        out["_inputs_keepalive"] = a
         return out
 
     # ---- safe set (safe_set.cpp:116-180) ----

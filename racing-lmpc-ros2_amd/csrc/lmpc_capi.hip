@@ -33,6 +33,9 @@ __global__ void lmpc_reg_residual_kernel(lmpc_vehicle, int, int, const int*, con
 template <int NF, int NOUT, bool WS_LAYOUT>
 __global__ void lmpc_regress_kernel(int, int, lmpc_regression_spec, int, const int*, const double*, const double*,
                                     const double*, const double*, const double*, double*, double*, double*);
+struct lmpc_sqp_arrays;
+__global__ void lmpc_sqp_linesearch_kernel(lmpc_params, int, lmpc_sqp_arrays, int, double);
+__global__ void lmpc_sqp_accumulate_kernel(int, const int*, int*);
 
 struct lmpc_handle {
   lmpc_params P;
@@ -70,6 +73,11 @@ struct lmpc_handle {
   double* ssq_host = nullptr;
   int* ssq_int = nullptr;
   int* ssq_int_host = nullptr;
+  // work area of lmpc_solve_full_dynamics_batch (grown by its first call for a batch size, like the workspace)
+  double* sqp_ws = nullptr;
+  int* sqp_int = nullptr;
+  size_t sqp_cap = 0;
+  int* sqp_count_host = nullptr;  // pinned
   // timing
   bool timing = false;
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
@@ -185,6 +193,10 @@ int launch_regress(lmpc_handle* h, int batch, const double* X_ref, const double*
 
 extern "C" {
 
+namespace {
+int reserve_sqp(lmpc_handle* h, size_t B);
+}
+
 int lmpc_create(const lmpc_config* cfg, const lmpc_vehicle* veh, int device, lmpc_handle** out) {
   if (!cfg || !veh || !out) return LMPC_ERR_ARGUMENT;
   *out = nullptr;
@@ -250,11 +262,11 @@ int lmpc_create(const lmpc_config* cfg, const lmpc_vehicle* veh, int device, lmp
   for (auto& e : h->ev) HIP_TRY(h, hipEventCreate(&e));
   {  // staging of the single-problem host path, once
     const size_t N = (size_t)P.N, S = (size_t)P.S;
-    h->stage_doubles = 8 + 6 * N + 2 * (N - 1) + (N - 1) + 4 * N + 7 * S + 6 * N + 4 * (N - 1) + S;
+    h->stage_doubles = 8 + 6 * N + 2 * (N - 1) + (N - 1) + 4 * N + 7 * S + 6 * N + 4 * (N - 1) + S + 2;
     HIP_TRY(h, hipMalloc(&h->stage_dev, h->stage_doubles * sizeof(double)));
     HIP_TRY(h, hipHostMalloc(&h->stage_host, h->stage_doubles * sizeof(double)));
-    HIP_TRY(h, hipMalloc(&h->stage_int, 2 * sizeof(int)));
-    HIP_TRY(h, hipHostMalloc(&h->stage_int_host, 2 * sizeof(int)));
+    HIP_TRY(h, hipMalloc(&h->stage_int, 3 * sizeof(int)));
+    HIP_TRY(h, hipHostMalloc(&h->stage_int_host, 3 * sizeof(int)));
     if (cfg->num_ss_pts >= 1) {
       const size_t nd = 2 + 7 * (size_t)cfg->num_ss_pts + 1;
       HIP_TRY(h, hipMalloc(&h->ssq_dev, nd * sizeof(double)));
@@ -262,7 +274,8 @@ int lmpc_create(const lmpc_config* cfg, const lmpc_vehicle* veh, int device, lmp
       HIP_TRY(h, hipMalloc(&h->ssq_int, sizeof(int)));
       HIP_TRY(h, hipHostMalloc(&h->ssq_int_host, sizeof(int)));
     }
-    const int rc = lmpc_reserve(h, 1);
+    int rc = lmpc_reserve(h, 1);
+    if (rc == LMPC_OK) rc = reserve_sqp(h, 1);
     if (rc != LMPC_OK) return rc;
   }
   return LMPC_OK;
@@ -283,6 +296,9 @@ void lmpc_destroy(lmpc_handle* h) {
   if (h->reg_y) (void)hipFree(h->reg_y);
   if (h->stage_dev) (void)hipFree(h->stage_dev);
   if (h->stage_int) (void)hipFree(h->stage_int);
+  if (h->sqp_ws) (void)hipFree(h->sqp_ws);
+  if (h->sqp_int) (void)hipFree(h->sqp_int);
+  if (h->sqp_count_host) (void)hipHostFree(h->sqp_count_host);
   if (h->ssq_dev) (void)hipFree(h->ssq_dev);
   if (h->ssq_int) (void)hipFree(h->ssq_int);
   for (void* q : {(void*)h->stage_host, (void*)h->stage_int_host, (void*)h->ssq_host, (void*)h->ssq_int_host})
@@ -486,10 +502,102 @@ int lmpc_solve_batch_f32(lmpc_handle* h, int32_t batch, const float* x_ic, const
   return LMPC_OK;
 }
 
-int lmpc_solve_host(lmpc_handle* h, const double* x_ic, const double* u_ic, const double* X_ref, const double* U_ref,
+namespace {
+// work area of the sequential-QP solve for up to B problems: QP solution + penalty weights, per-problem ints, a counter
+int reserve_sqp(lmpc_handle* h, size_t B) {
+  if (B <= h->sqp_cap) return LMPC_OK;
+  const size_t N = (size_t)h->P.N, S = (size_t)h->P.S;
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  if (h->sqp_ws) HIP_TRY(h, hipFree(h->sqp_ws));
+  if (h->sqp_int) HIP_TRY(h, hipFree(h->sqp_int));
+  h->sqp_ws = nullptr;
+  h->sqp_int = nullptr;
+  h->sqp_cap = 0;
+  HIP_TRY(h, hipMalloc(&h->sqp_ws, (6 * N + 4 * (N - 1) + S + 1) * B * sizeof(double)));
+  HIP_TRY(h, hipMalloc(&h->sqp_int, (3 * B + 1) * sizeof(int)));
+  if (!h->sqp_count_host) HIP_TRY(h, hipHostMalloc(&h->sqp_count_host, sizeof(int)));
+  h->sqp_cap = B;
+  return LMPC_OK;
+}
+}  // namespace
+
+int lmpc_solve_full_dynamics_batch(lmpc_handle* h, int32_t batch, const double* x_ic, const double* u_ic, const double* X_ref,
+                                   const double* U_ref, const double* T_ref, const double* bound_left,
+                                   const double* bound_right, const double* curvatures, const double* vel_ref,
+                                   double total_length, const double* ss_x, const double* ss_j, int32_t max_sqp,
+                                   double step_tol, double* X_optm, double* U_optm, double* dU_optm,
+                                   double* convex_combi_optm, int32_t* status, int32_t* iters, int32_t* sqp_iters,
+                                   double* sqp_move, double* defect) {
+  if (!h) return LMPC_ERR_ARGUMENT;
+  if (batch < 0 || !X_ref || !U_ref || !X_optm || !U_optm || !dU_optm || !status || !iters || !sqp_iters || !sqp_move || !defect)
+    return fail(h, LMPC_ERR_ARGUMENT, "lmpc_solve_full_dynamics_batch: null pointer or negative batch");
+  if (max_sqp < 1) return fail(h, LMPC_ERR_ARGUMENT, "lmpc_solve_full_dynamics_batch: max_sqp < 1");
+  if (h->P.learning && !convex_combi_optm) return fail(h, LMPC_ERR_ARGUMENT, "learning=1 needs convex_combi_optm");
+  if (batch == 0) return LMPC_OK;
+  HIP_TRY(h, hipSetDevice(h->device));
+  const size_t B = (size_t)batch, N = (size_t)h->P.N, NS = N - 1, S = (size_t)h->P.S;
+  const size_t nX = 6 * N * B, nU = 2 * NS * B, nL = S * B;
+  // work area: QP solution (Xq, Uq, dUq, lamq), penalty weights; ints: status_q, iters_q, active, counter
+  {
+    const int rc = reserve_sqp(h, B);
+    if (rc != LMPC_OK) return rc;
+  }
+  double* Xq = h->sqp_ws;
+  double* Uq = Xq + nX;
+  double* dUq = Uq + nU;
+  double* lamq = dUq + nU;
+  double* nu = lamq + nL;
+  int* status_q = h->sqp_int;
+  int* iters_q = status_q + B;
+  int* active = iters_q + B;
+  int* counter = active + B;
+  // the iterate lives in the caller's output arrays: start = the reference trajectory (the node's zero-input rollout,
+  // racing_mpc_node.cpp:210-235), dU = 0, lambda = 0 (its convex_combi_optm_ref)
+  HIP_TRY(h, hipMemcpyAsync(X_optm, X_ref, nX * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(U_optm, U_ref, nU * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+  HIP_TRY(h, hipMemsetAsync(dU_optm, 0, nU * sizeof(double), h->stream));
+  if (S) HIP_TRY(h, hipMemsetAsync(convex_combi_optm, 0, nL * sizeof(double), h->stream));
+  HIP_TRY(h, hipMemsetAsync(nu, 0, B * sizeof(double), h->stream));
+  HIP_TRY(h, hipMemsetAsync(iters, 0, B * sizeof(int), h->stream));
+  HIP_TRY(h, hipMemsetAsync(sqp_iters, 0, B * sizeof(int), h->stream));
+  HIP_TRY(h, hipMemsetAsync(defect, 0, B * sizeof(double), h->stream));
+  {  // active = 1, move = inf
+    std::vector<int> ones(B, 1);
+    std::vector<double> inf(B, INFINITY);
+    HIP_TRY(h, hipMemcpyAsync(active, ones.data(), B * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(sqp_move, inf.data(), B * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+  }
+  lmpc_sqp_arrays A{};
+  A.X = X_optm; A.U = U_optm; A.dU = dU_optm; A.lam = S ? convex_combi_optm : nullptr;
+  A.Xq = Xq; A.Uq = Uq; A.dUq = dUq; A.lamq = S ? lamq : nullptr;
+  A.status_q = status_q;
+  A.T_ref = T_ref; A.curv = curvatures; A.bl = bound_left; A.br = bound_right; A.vref = vel_ref; A.ss_x = ss_x; A.ss_j = ss_j;
+  A.nu = nu; A.active = active; A.status = status; A.sqp_iters = sqp_iters; A.move = sqp_move; A.defect = defect;
+  A.n_active = counter;
+  for (int it = 0; it < max_sqp; ++it) {
+    // QP about the iterate (racing_mpc.cpp:169-186 with X_ref, U_ref := the iterate)
+    const int rc = lmpc_solve_batch(h, batch, x_ic, u_ic, X_optm, U_optm, T_ref, bound_left, bound_right, curvatures, vel_ref,
+                                    total_length, ss_x, ss_j, Xq, Uq, dUq, S ? lamq : nullptr, status_q, iters_q, nullptr);
+    if (rc != LMPC_OK) return rc;
+    HIP_TRY(h, hipMemsetAsync(counter, 0, sizeof(int), h->stream));
+    hipLaunchKernelGGL(lmpc_sqp_linesearch_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, h->stream, h->P, batch, A,
+                       it == 0 ? 1 : 0, step_tol);
+    HIP_TRY(h, hipGetLastError());
+    hipLaunchKernelGGL(lmpc_sqp_accumulate_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, h->stream, batch, iters_q, iters);
+    HIP_TRY(h, hipMemcpyAsync(h->sqp_count_host, counter, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (*h->sqp_count_host == 0) break;
+  }
+  return LMPC_OK;
+}
+
+namespace {
+int solve_host_impl(lmpc_handle* h, const double* x_ic, const double* u_ic, const double* X_ref, const double* U_ref,
                     const double* T_ref, const double* bound_left, const double* bound_right, const double* curvatures,
                     const double* vel_ref, double total_length, const double* ss_x, const double* ss_j, double* X_optm,
-                    double* U_optm, double* dU_optm, double* convex_combi_optm, int32_t* status, int32_t* iters) {
+                    double* U_optm, double* dU_optm, double* convex_combi_optm, int32_t* status, int32_t* iters,
+                    int max_sqp, double step_tol, int32_t* sqp_iters, double* sqp_move, double* defect) {
   if (!h) return LMPC_ERR_ARGUMENT;
   if (!x_ic || !u_ic || !X_ref || !U_ref || !T_ref || !bound_left || !bound_right || !curvatures || !vel_ref ||
       !X_optm || !U_optm || !dU_optm || !status || !iters)
@@ -498,7 +606,7 @@ int lmpc_solve_host(lmpc_handle* h, const double* x_ic, const double* u_ic, cons
   // staging layout (doubles): inputs then outputs, each in the batch = 1 device layout
   const size_t o_x = 0, o_u = 6, o_X = 8, o_U = o_X + 6 * N, o_T = o_U + 2 * NS, o_bl = o_T + NS, o_br = o_bl + N,
                o_k = o_br + N, o_v = o_k + N, o_sx = o_v + N, o_sj = o_sx + 6 * (size_t)S, o_Xo = o_sj + S,
-               o_Uo = o_Xo + 6 * N, o_dUo = o_Uo + 2 * NS, o_lam = o_dUo + 2 * NS, total = o_lam + S;
+               o_Uo = o_Xo + 6 * N, o_dUo = o_Uo + 2 * NS, o_lam = o_dUo + 2 * NS, o_mv = o_lam + S, total = o_mv + 2;
   HIP_TRY(h, hipSetDevice(h->device));
   if (total != h->stage_doubles || !h->stage_dev || !h->stage_host) return fail(h, LMPC_ERR_RUNTIME, "lmpc_solve_host: staging not allocated");
   double* const host = h->stage_host;  // pinned: the two copies below are asynchronous DMA transfers
@@ -524,13 +632,18 @@ int lmpc_solve_host(lmpc_handle* h, const double* x_ic, const double* u_ic, cons
     }
   double* d = h->stage_dev;
   HIP_TRY(h, hipMemcpyAsync(d, host, o_Xo * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  const int rc = lmpc_solve_batch(h, 1, d + o_x, d + o_u, d + o_X, d + o_U, d + o_T, d + o_bl, d + o_br, d + o_k, d + o_v,
-                                  total_length, S ? d + o_sx : nullptr, S ? d + o_sj : nullptr, d + o_Xo, d + o_Uo,
-                                  d + o_dUo, S ? d + o_lam : nullptr, h->stage_int, h->stage_int + 1, nullptr);
+  const int rc = max_sqp > 0
+      ? lmpc_solve_full_dynamics_batch(h, 1, d + o_x, d + o_u, d + o_X, d + o_U, d + o_T, d + o_bl, d + o_br, d + o_k, d + o_v,
+                                       total_length, S ? d + o_sx : nullptr, S ? d + o_sj : nullptr, max_sqp, step_tol,
+                                       d + o_Xo, d + o_Uo, d + o_dUo, S ? d + o_lam : nullptr, h->stage_int,
+                                       h->stage_int + 1, h->stage_int + 2, d + o_mv, d + o_mv + 1)
+      : lmpc_solve_batch(h, 1, d + o_x, d + o_u, d + o_X, d + o_U, d + o_T, d + o_bl, d + o_br, d + o_k, d + o_v,
+                         total_length, S ? d + o_sx : nullptr, S ? d + o_sj : nullptr, d + o_Xo, d + o_Uo,
+                         d + o_dUo, S ? d + o_lam : nullptr, h->stage_int, h->stage_int + 1, nullptr);
   if (rc != LMPC_OK) return rc;
   int* const si = h->stage_int_host;
   HIP_TRY(h, hipMemcpyAsync(host + o_Xo, d + o_Xo, (total - o_Xo) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(h, hipMemcpyAsync(si, h->stage_int, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(si, h->stage_int, 3 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   for (int i = 0; i < N; ++i)
     for (int k = 0; k < 6; ++k) X_optm[(size_t)i * 6 + k] = host[o_Xo + (size_t)k * N + i];
@@ -543,7 +656,32 @@ int lmpc_solve_host(lmpc_handle* h, const double* x_ic, const double* u_ic, cons
     for (int j = 0; j < S; ++j) convex_combi_optm[j] = host[o_lam + j];
   *status = si[0];
   *iters = si[1];
+  if (sqp_iters) *sqp_iters = max_sqp > 0 ? si[2] : 1;
+  if (sqp_move) *sqp_move = max_sqp > 0 ? host[o_mv] : 0.0;
+  if (defect) *defect = max_sqp > 0 ? host[o_mv + 1] : 0.0;
   return LMPC_OK;
+}
+}  // namespace
+
+int lmpc_solve_host(lmpc_handle* h, const double* x_ic, const double* u_ic, const double* X_ref, const double* U_ref,
+                    const double* T_ref, const double* bound_left, const double* bound_right, const double* curvatures,
+                    const double* vel_ref, double total_length, const double* ss_x, const double* ss_j, double* X_optm,
+                    double* U_optm, double* dU_optm, double* convex_combi_optm, int32_t* status, int32_t* iters) {
+  return solve_host_impl(h, x_ic, u_ic, X_ref, U_ref, T_ref, bound_left, bound_right, curvatures, vel_ref, total_length, ss_x,
+                         ss_j, X_optm, U_optm, dU_optm, convex_combi_optm, status, iters, 0, 0.0, nullptr, nullptr, nullptr);
+}
+
+int lmpc_solve_full_dynamics_host(lmpc_handle* h, const double* x_ic, const double* u_ic, const double* X_ref,
+                                  const double* U_ref, const double* T_ref, const double* bound_left,
+                                  const double* bound_right, const double* curvatures, const double* vel_ref,
+                                  double total_length, const double* ss_x, const double* ss_j, int32_t max_sqp,
+                                  double step_tol, double* X_optm, double* U_optm, double* dU_optm,
+                                  double* convex_combi_optm, int32_t* status, int32_t* iters, int32_t* sqp_iters,
+                                  double* sqp_move, double* defect) {
+  if (max_sqp < 1) return h ? fail(h, LMPC_ERR_ARGUMENT, "lmpc_solve_full_dynamics_host: max_sqp < 1") : LMPC_ERR_ARGUMENT;
+  return solve_host_impl(h, x_ic, u_ic, X_ref, U_ref, T_ref, bound_left, bound_right, curvatures, vel_ref, total_length, ss_x,
+                         ss_j, X_optm, U_optm, dU_optm, convex_combi_optm, status, iters, max_sqp, step_tol, sqp_iters,
+                         sqp_move, defect);
 }
 
 namespace {

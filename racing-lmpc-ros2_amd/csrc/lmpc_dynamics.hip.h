@@ -135,13 +135,19 @@ __device__ __forceinline__ void lmpc_jvp(const lmpc_fjac& J, const double* tx, c
   o[5] = J.a5[0] * tx[3] + J.a5[1] * tx[4] + J.a5[2] * tx[5] + J.b5[0] * tu[0] + J.b5[1] * tu[1];
 }
 
-// x+ = rk4(x, u, k, dt)
-__device__ __forceinline__ void lmpc_rk4(const lmpc_vehicle& v, const double* x, const double* u, double k,
-                                         double dt, double* xp) {
+// x+ = f_d(x, u, k, dt): the model's discrete dynamics -- classic RK4 with u, k held over the step (utils.cpp:88-108) or,
+// with modeling.integrator_type = "euler", x + dt f(x, u, k) (utils.cpp:110-123)
+__device__ __forceinline__ void lmpc_fd(const lmpc_vehicle& v, const double* x, const double* u, double k,
+                                        double dt, double* xp) {
   lmpc_uterms ut;
   lmpc_u_terms(v, u[0], u[1], ut);
   double k1[6], k2[6], k3[6], k4[6], xs[6];
   lmpc_f<false>(v, ut, x, k, k1, nullptr);
+  if (v.integrator == LMPC_INTEGRATOR_EULER) {
+#pragma unroll
+    for (int r = 0; r < 6; ++r) xp[r] = x[r] + dt * k1[r];
+    return;
+  }
 #pragma unroll
   for (int r = 0; r < 6; ++r) xs[r] = x[r] + dt / 2.0 * k1[r];
   lmpc_f<false>(v, ut, xs, k, k2, nullptr);

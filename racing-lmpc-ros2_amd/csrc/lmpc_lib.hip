@@ -4,4 +4,5 @@
 #include "lmpc_solve_kernel.hip"
 #include "lmpc_ss_kernel.hip"
 #include "lmpc_reg_kernel.hip"
+#include "lmpc_sqp_kernel.hip"
 #include "lmpc_capi.hip"

@@ -47,10 +47,14 @@ __global__ __launch_bounds__(256) void lmpc_linearize_kernel(lmpc_params P, int 
     for (int r = 0; r < 6; ++r) xs[r] = (s == 0) ? x[r] : x[r] + cs[s] * dt * ks[s - 1][r];
     lmpc_f<true>(P.veh, ut, xs, kap, ks[s], &J[s]);
   }
+  // weights of the four slopes: dt/6 (1, 2, 2, 1), or -- Euler, utils.cpp:110-123 -- the first slope alone (the other
+  // three evaluations are then wasted; no shipped file selects Euler)
+  const bool euler = P.veh.integrator == LMPC_INTEGRATOR_EULER;
+  const double wgt[4] = {euler ? dt : dt / 6, euler ? 0.0 : dt / 3, euler ? 0.0 : dt / 3, euler ? 0.0 : dt / 6};
   double xp[6], gacc[6];
 #pragma unroll
   for (int r = 0; r < 6; ++r) {
-    xp[r] = x[r] + dt / 6 * (ks[0][r] + 2 * ks[1][r] + 2 * ks[2][r] + ks[3][r]);
+    xp[r] = x[r] + (wgt[0] * ks[0][r] + wgt[1] * ks[1][r] + wgt[2] * ks[2][r] + wgt[3] * ks[3][r]);
     gacc[r] = xp[r];
   }
 #pragma unroll
@@ -63,7 +67,6 @@ __global__ __launch_bounds__(256) void lmpc_linearize_kernel(lmpc_params P, int 
       tx[r] = e[r];
       acc[r] = 0.0;
     }
-    const double wgt[4] = {1.0, 2.0, 2.0, 1.0};
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       lmpc_jvp(J[s], tx, tu, kc);
@@ -76,7 +79,7 @@ __global__ __launch_bounds__(256) void lmpc_linearize_kernel(lmpc_params P, int 
     const double xu = (c < 6) ? x[c] : u[c - 6];
 #pragma unroll
     for (int r = 0; r < 6; ++r) {
-      const double d = e[r] + dt / 6 * acc[r];  // [A B][r][c]
+      const double d = e[r] + acc[r];  // [A B][r][c]
       gacc[r] -= d * xu;
       if (WS_LAYOUT)
         outA[((size_t)b * NS + i) * LMPC_LIN_RECORD + c * 6 + r] = (io)d;
@@ -173,7 +176,7 @@ __global__ __launch_bounds__(256) void lmpc_shift_kernel(lmpc_params P, int B, l
         U_ref[(size_t)(k * NS + i) * B + b] = u[k];
       }
       T_ref[(size_t)i * B + b] = dt;
-      if (i == NS - 1) lmpc_rk4(P.veh, x, u, kap, dt, xn);  // :248-249
+      if (i == NS - 1) lmpc_fd(P.veh, x, u, kap, dt, xn);  // :248-249
     }
   }
 }
@@ -192,7 +195,7 @@ __global__ __launch_bounds__(256) void lmpc_plant_kernel(lmpc_params P, int B, l
   for (int j = 0; j < nsub; ++j) {
     if (fabs(x[3]) < 1e-6) x[3] = copysign(1e-6, x[3]);  // :99-102
     const double kap = track_lookup(trk.curvature, trk.M, trk.L, x[0]);
-    lmpc_rk4(P.veh, x, u, kap, dt_sim, xn);
+    lmpc_fd(P.veh, x, u, kap, dt_sim, xn);
     // align_abscissa(s, L/2, L): lmpc_utils/utils.hpp:35-41
     const double s1 = xn[0], s2 = trk.L / 2.0;
     const double kk = fabs(s2 - s1) + trk.L / 2.0;
@@ -237,7 +240,7 @@ __global__ __launch_bounds__(256) void lmpc_prepare_kernel(lmpc_params P, int B,
       U_ref[(size_t)(0 * NS + i) * B + b] = u[0];
       U_ref[(size_t)(1 * NS + i) * B + b] = u[1];
       T_ref[(size_t)i * B + b] = dt;
-      lmpc_rk4(P.veh, x, u, kap, dt, xn);  // :216-224, curvature at the knot's own abscissa (:72-76)
+      lmpc_fd(P.veh, x, u, kap, dt, xn);  // :216-224, curvature at the knot's own abscissa (:72-76)
 #pragma unroll
       for (int k = 0; k < 6; ++k) x[k] = xn[k];
     }

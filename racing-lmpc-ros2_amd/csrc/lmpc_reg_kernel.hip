@@ -37,7 +37,7 @@ __global__ void lmpc_reg_residual_kernel(lmpc_vehicle veh, int total, int as_wri
     for (int c = 0; c < 6; ++c) xs[c] = x[(size_t)j * 6 + c];
     us[0] = u[(size_t)j * 2];
     us[1] = u[(size_t)j * 2 + 1];
-    lmpc_rk4(veh, xs, us, k[j], as_written ? t[j] - t[j + 1] : t[j + 1] - t[j], xp);
+    lmpc_fd(veh, xs, us, k[j], as_written ? t[j] - t[j + 1] : t[j + 1] - t[j], xp);
 #pragma unroll
     for (int c = 0; c < 6; ++c) r[c] = x[(size_t)(j + 1) * 6 + c] - xp[c];
   }

@@ -101,8 +101,28 @@ void RacingMPC::solve(const DMDict& in, DMDict& out, Dict& stats) {
   }
   DM X(6, N), U(2, N - 1), dU(2, N - 1), lam(S, 1);
   int32_t status = 0, iters = 0, total_iters = 0;
-  const int n_sqp = full_dynamics_ ? 8 : 1;
-  for (int k = 0; k < n_sqp; ++k) {
+  if (full_dynamics_) {
+    // The nonlinear-dynamics problem (racing_mpc.cpp:162-166; IPOPT upstream, :67-84): sequential QPs over the same
+    // kernels with a line search on the l1 merit function, from the reference trajectory handed in (the node's
+    // zero-input rollout, racing_mpc_node.cpp:210-235).  Like IPOPT with error_on_fail, a run that has not converged
+    // within its budget is a failure.
+    int32_t sqp_iters = 0;
+    double move = 0.0, defect = 0.0;
+    const int rc = lmpc_solve_full_dynamics_host(h_, x_ic.data.data(), u_ic.data.data(), X_ref.data.data(), U_ref.data.data(),
+                                                 T.data.data(), bound_left.data.data(), bound_right.data.data(),
+                                                 curvatures.data.data(), vel_ref.data.data(), total_length,
+                                                 S ? ss_x_.data() : nullptr, S ? ss_j_.data() : nullptr, 40, 1e-8,
+                                                 X.data.data(), U.data.data(), dU.data.data(), S ? lam.data.data() : nullptr,
+                                                 &status, &iters, &sqp_iters, &move, &defect);
+    if (rc != LMPC_OK) {
+      std::cerr << "RacingMPC::solve: " << lmpc_last_error(h_) << '\n';
+      return;
+    }
+    total_iters = iters;
+    stats["sqp_iter_count"] = static_cast<double>(sqp_iters);
+    stats["dynamics_defect"] = defect;
+    if (status == LMPC_SOLVE_OPTIMAL && !(move <= 1e-8)) status = LMPC_SOLVE_MAX_ITER;
+  } else {
     const int rc = lmpc_solve_host(h_, x_ic.data.data(), u_ic.data.data(), X_ref.data.data(), U_ref.data.data(),
                                    T.data.data(), bound_left.data.data(), bound_right.data.data(),
                                    curvatures.data.data(), vel_ref.data.data(), total_length, S ? ss_x_.data() : nullptr,
@@ -112,15 +132,7 @@ void RacingMPC::solve(const DMDict& in, DMDict& out, Dict& stats) {
       std::cerr << "RacingMPC::solve: " << lmpc_last_error(h_) << '\n';
       return;
     }
-    total_iters += iters;
-    if (status != LMPC_SOLVE_OPTIMAL) break;
-    if (!full_dynamics_) break;
-    // sequential QP on the nonlinear dynamics: re-linearise about the new trajectory until it stops moving
-    double move = 0.0;
-    for (std::size_t j = 0; j < X.data.size(); ++j) move = std::fmax(move, std::fabs(X.data[j] - X_ref.data[j]));
-    X_ref = X;
-    U_ref = U;
-    if (move < 1e-8) break;
+    total_iters = iters;
   }
   stats["iter_count"] = static_cast<double>(total_iters);
   if (status != LMPC_SOLVE_OPTIMAL) {

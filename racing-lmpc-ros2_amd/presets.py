@@ -11,14 +11,14 @@ INF = float("inf")
 
 
 def barc_vehicle() -> dict:
-    return dict(model_id=0, m=2.2187, Jzz=0.02723, l=0.324, cg_ratio=0.5, h=0.07, b=0.281, fr=0.012,
+    return dict(model_id=0, integrator="rk4", m=2.2187, Jzz=0.02723, l=0.324, cg_ratio=0.5, h=0.07, b=0.281, fr=0.012,
                 kd=0.0, kb=0.5, cd=0.0, Af=1.0, rho=1.2, cl_f=0.0, cl_r=0.0, mu=0.9,
                 Bf=5.0, Cf=2.28, Br=5.0, Cr=2.28, Fd_max=15.0, Fb_max=-15.0, Td=0.1, Tb=0.1,
                 max_steer=0.314159, max_steer_rate=10.0)
 
 
 def iac_vehicle() -> dict:
-    return dict(model_id=0, m=811.9303, Jzz=700.0, l=2.9718, cg_ratio=0.45, h=0.35, b=2.0, fr=0.012,
+    return dict(model_id=0, integrator="rk4", m=811.9303, Jzz=700.0, l=2.9718, cg_ratio=0.45, h=0.35, b=2.0, fr=0.012,
                 kd=0.0, kb=0.54, cd=1.0, Af=1.0, rho=1.2, cl_f=1.0, cl_r=1.0, mu=1.3,
                 Bf=11.0, Cf=1.7, Br=11.0, Cr=1.7, Fd_max=10000.0, Fb_max=-20000.0, Td=0.1, Tb=0.1,
                 max_steer=0.314159, max_steer_rate=0.66)

@@ -98,11 +98,9 @@ def vehicle_from_params(params: dict, model: str = "single_track_planar_model") 
     if not _need(params, "modeling.use_frenet", bool):
         raise NotImplementedError("modeling.use_frenet = false is not built (RacingMPC uses the Frenet model)")
     integ = _need(params, "modeling.integrator_type", str)
-    if integ != "rk4":
-        if integ == "euler":
-            raise NotImplementedError("modeling.integrator_type = euler is not built (every shipped file uses rk4)")
+    if integ not in ("rk4", "euler"):   # base_vehicle_model_config.cpp: any other string throws
         raise ValueError(f"Unknown integrator type: {integ}")
-    return dict(model_id=0,
+    return dict(model_id=0, integrator=integ,
                 m=f("chassis.total_mass"), Jzz=f("chassis.moi"), l=f("chassis.wheel_base"),
                 cg_ratio=f("chassis.cg_ratio"), h=f("chassis.cg_height"), b=f("chassis.b"), fr=f("chassis.fr"),
                 kd=f("powertrain.kd"), kb=f("front_brake.bias"),

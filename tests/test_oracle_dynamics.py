@@ -2,6 +2,7 @@
 from pathlib import Path
 
 import numpy as np
+import pytest
 
 from oracle import cbind, dynamics as D, params as P
 
@@ -28,9 +29,12 @@ def test_analytic_jacobian_matches_complex_step():
         assert np.abs(g - g2).max() <= 1e-10 * max(1.0, np.abs(g).max())
 
 
-def test_c_oracle_linearisation_matches_complex_step():
+@pytest.mark.parametrize("integrator", ["rk4", "euler"])
+def test_c_oracle_linearisation_matches_complex_step(integrator):
+    """Both integrators of the model (single_track_planar_model.cpp:357-368): RK4, and Euler x + dt f (utils.cpp:110-123)."""
+    import dataclasses
     rng = np.random.default_rng(1)
-    veh, cfg = P.barc_vehicle(), P.barc_tracking_mpc(8)
+    veh, cfg = dataclasses.replace(P.barc_vehicle(), integrator=integrator), P.barc_tracking_mpc(8)
     B = 40
     x, u, k = _random_points(veh, rng, B * 8, False)
     inp = {"X_ref": x.reshape(8, B, 6).transpose(2, 0, 1).copy(), "U_ref": u.reshape(8, B, 2)[:7].transpose(2, 0, 1).copy(),
@@ -76,3 +80,13 @@ def test_align_abscissa():
     assert abs(D.align_abscissa(0.5, 14.8, L) - 15.5) < 1e-12
     assert abs(D.align_abscissa(14.9, 0.2, L) - (-0.1)) < 1e-12
     assert abs(D.align_abscissa(3.0, 4.0, L) - 3.0) < 1e-12
+
+
+def test_euler_is_one_slope():
+    import dataclasses
+    veh = dataclasses.replace(P.barc_vehicle(), integrator="euler")
+    x, u, k = np.array([1.0, 0.05, 0.02, 2.0, 0.03, 0.4]), np.array([0.004, 0.1]), 0.2
+    assert np.allclose(D.rk4(x, u, k, 0.025, veh), x + 0.025 * D.f_continuous(x, u, k, veh), rtol=0, atol=1e-15)
+    A, B, g = D.rk4_jacobian_cs(x, u, k, 0.025, veh)
+    Fx = (A - np.eye(6)) / 0.025
+    assert np.abs(Fx[:, 0]).max() == 0.0 and abs(Fx[1, 2] - (x[3] * np.cos(x[2]) - x[4] * np.sin(x[2]))) < 1e-12

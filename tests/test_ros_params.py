@@ -144,8 +144,9 @@ def test_what_the_device_path_does_not_build_is_refused(pkg, tmp_path):
     rp, veh = pkg.ros_params, pkg.presets.barc_vehicle()
     with pytest.raises(NotImplementedError, match="simplify_lon_control"):
         rp.vehicle_from_params(rp.load_ros_params(*vehicle_files(tmp_path, veh, **{"single_track_planar.simplify_lon_control": False})))
-    with pytest.raises(NotImplementedError, match="euler"):
-        rp.vehicle_from_params(rp.load_ros_params(*vehicle_files(tmp_path, veh, **{"modeling.integrator_type": "euler"})))
+    # modeling.integrator_type = euler is built (utils.cpp:110-123): it selects the integrator field of lmpc_vehicle
+    assert rp.vehicle_from_params(rp.load_ros_params(*vehicle_files(tmp_path, veh, **{"modeling.integrator_type": "euler"})))["integrator"] == "euler"
+    assert rp.vehicle_from_params(rp.load_ros_params(*vehicle_files(tmp_path, veh)))["integrator"] == "rk4"
     with pytest.raises(ValueError, match="Unknown integrator type"):
         rp.vehicle_from_params(rp.load_ros_params(*vehicle_files(tmp_path, veh, **{"modeling.integrator_type": "rk9"})))
     with pytest.raises(NotImplementedError, match="only single_track_planar_model"):
