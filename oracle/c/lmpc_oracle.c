@@ -235,6 +235,7 @@ typedef struct {
   double ez[NMAX][8], ev[NMAX][2]; /* Schur vector e = R(c) */
   /* LMPC terminal elimination */
   double PT[36], Minv_cache[49];
+  double tau; /* theta below which a safe-set point is kept as an explicit unknown of the terminal block */
 } prob_t;
 
 static inline double abar(const prob_t* p, int i, int k, int r) { /* Abar[k][r], k < 6 */
@@ -399,24 +400,41 @@ static inline double slot_val(double (*z)[8], double (*v)[2], int i, int sl) {
  *     U dl0 = -(beta - T F^-1 beta) + g (sbl - a'F^-1 beta + r1)/s11,   pT = -E U dl0,
  *     dl_j = (r_j - u_j'F^-1 gamma)/theta_j - Mi1_j (oMr - r1)/s11,  r_j = u_j'E dx - bl_j,
  *            gamma = T E dx - beta,  oMr = a'E dx - sbl - a'F^-1 gamma,  Mi1_j = (1 - u_j'F^-1 a)/theta_j. */
-typedef struct {
-  double T[36], Fi[36], a[6], Fia[6], s11;
-  double beta[6], Fibeta[6], sbl;
-} term_t;
-
-/* floor on the simplex rows' barrier weight inside the Newton matrix: keeps 1/theta of the points
- * with lambda > 0 from swamping E^-1 in F = E^-1 + T.  It only regularises the Newton matrix (a
- * proximal term on d lambda); residuals and row updates use the true weights, so the fixed point is
- * unchanged.  The value is a compromise between two failure modes (measured, scratch/r2_lmpc_fail.py + the CPU replay of
- * the problems it dumps, the golden vectors, 256 fresh problems): too large and the proximal iteration stalls at
- * mu ~ 1e-8 on closed-loop problems whose support has two or three points (1e-3: 95 % of those problems hit the iteration
- * cap); too small and cond(F) ~ E |u|^2 / floor exceeds what the explicit 6x6 inverse carries (1e-6: 5e-4 from the
- * dense optimum on the golden vectors, 1e-7: the iteration diverges).  1e-4: 1e-10 / 4e-8 agreement, no stall. */
-#define TH_L_MIN 1e-4
-/* complementarity below which a step that does not lower it ends the solve (ipm_solve) */
-#define STALL_MU 1e-9
+/* Two-level elimination -- no division by a small theta.  The points split into
+ *     B: theta_j >= tau      eliminated through Theta_B^-1 (Woodbury as above, on the sums over B only):
+ *                            T_B = U_B Th_B^-1 U_B', a_B = U_B Th_B^-1 1, s_B = sum_B 1/theta, F_B = E^-1 + T_B
+ *     A: theta_j <  tau      the (few) points whose lambda stays positive: theta = l/t -> 0 there.  They are kept as
+ *                            explicit unknowns of a small dense system, at most MA_MAX of them (the smallest theta).
+ * With W_A = F_B^-1 U_A (6 x m) and C_A = Theta_A + U_A' F_B^-1 U_A (m x m, the Schur complement of M_BB in M):
+ *     F^-1      = F_B^-1 - W_A C_A^-1 W_A'                       (F over all points)
+ *     g = E U M^-1 1 = F_B^-1 z1,  z1 = a_B + U_A x1,  x1 = C_A^-1 (1_A - W_A' a_B)
+ *     s11       = 1_A' x1 + s_B - a_B' F_B^-1 z1
+ *     PT        = F^-1 + g g'/s11
+ * and for a right-hand side r (r_j = u_j'E dx - bl_j) with simplex residual r1:
+ *     beta = U_B Th_B^-1 r_B, sig = 1'Th_B^-1 r_B,  x_A = C_A^-1 (r_A - W_A' beta),  z = beta + U_A x_A,
+ *     nu = (1_A' x_A + sig - a_B' F_B^-1 z - r1)/s11,   h = E U dl = F_B^-1 z - nu g,
+ *     dl_A = x_A - nu x1,   dl_j = (r_j - nu - u_j' h)/theta_j  (j in B).
+ * cond(F_B) <= 1 + E |u|^2 / tau whatever the iteration does, and theta_A enters only as an addend on the diagonal of
+ * C_A.  (Round 1 floored theta inside the Newton matrix instead -- a proximal term on d lambda: it kept F conditioned but
+ * damped the step of exactly the points that matter, so problems with two or three supporting points crawled or stalled,
+ * and at IAC scale the iterate stopped 1e-3 .. 1e-2 from the optimum with mu -> 0.) */
 /* complementarity below which the factorisation switches to the stabilised form (riccati_factor) */
 #define JOSEPH_MU 1e-8
+/* complementarity below which a step that does not lower it ends the solve (ipm_solve) */
+#define STALL_MU 1e-9
+#define MA_MAX 6
+#define TAU_REL 1e-5 /* tau = TAU_REL * max_j u_j'E u_j: cond(F_B) <= ~1e5 */
+typedef struct {
+  double Fi[36];       /* F^-1 over all points */
+  double FBi[36];      /* F_B^-1 */
+  double aB[6], sB;    /* sums over B */
+  double g[6], s11;
+  int m, idx[MA_MAX];  /* the explicit points */
+  double W[6][MA_MAX]; /* W_A = F_B^-1 U_A */
+  double Lc[MA_MAX][MA_MAX]; /* Cholesky factor of C_A */
+  double x1[MA_MAX];
+  unsigned char inA[SMAX];
+} term_t;
 
 static void sym_inv6(const double* F, double* Fi) { /* Cholesky inverse of SPD 6x6 */
   double Lc[36] = {0};
@@ -455,78 +473,160 @@ static void mv6(const double* M, const double* x, double* y) {
   }
 }
 
-/* All subtractions between large quantities are avoided through F - T = E^-1:
- *   PT = E - E U Z U'E = F^-1 + (F^-1 a)(F^-1 a)'/s11,   pT = F^-1 beta - F^-1 a (sbl - a'F^-1 beta + r1)/s11;
- * only s11 = sth - a'F^-1 a remains a difference (relative error ~ eps * sth / s11, bounded by the floor). */
+/* x <- C_A^-1 x through the Cholesky factor */
+static void solve_CA(const term_t* tm, double* x) {
+  const int m = tm->m;
+  for (int i = 0; i < m; ++i) {
+    double s = x[i];
+    for (int k = 0; k < i; ++k) s -= tm->Lc[i][k] * x[k];
+    x[i] = s / tm->Lc[i][i];
+  }
+  for (int i = m - 1; i >= 0; --i) {
+    double s = x[i];
+    for (int k = i + 1; k < m; ++k) s -= tm->Lc[k][i] * x[k];
+    x[i] = s / tm->Lc[i][i];
+  }
+}
+
 static void term_factor(prob_t* p, term_t* tm, const double* thl, double* PT) {
   const int S = p->S;
-  double F[36], sth = 0.0;
-  for (int r = 0; r < 6; ++r) {
-    tm->a[r] = 0.0;
-    for (int c = 0; c < 6; ++c) tm->T[r * 6 + c] = 0.0;
+  /* the explicit set: the (at most MA_MAX) smallest theta below tau, ties to the lower index */
+  memset(tm->inA, 0, sizeof(tm->inA));
+  tm->m = 0;
+  for (int q = 0; q < MA_MAX; ++q) {
+    int best = -1;
+    for (int j = 0; j < S; ++j)
+      if (!tm->inA[j] && thl[j] < p->tau && (best < 0 || thl[j] < thl[best])) best = j;
+    if (best < 0) break;
+    tm->inA[best] = 1;
+    tm->idx[tm->m++] = best;
   }
+  const int m = tm->m;
+  double F[36], T[36] = {0};
+  tm->sB = 0.0;
+  for (int r = 0; r < 6; ++r) tm->aB[r] = 0.0;
   for (int j = 0; j < S; ++j) {
-    const double it = 1.0 / fmax(thl[j], TH_L_MIN);
-    sth += it;
+    if (tm->inA[j]) continue;
+    const double it = 1.0 / thl[j];
+    tm->sB += it;
     for (int r = 0; r < 6; ++r) {
-      tm->a[r] += p->ssx[r][j] * it;
-      for (int c = 0; c < 6; ++c) tm->T[r * 6 + c] += p->ssx[r][j] * p->ssx[c][j] * it;
+      tm->aB[r] += p->ssx[r][j] * it;
+      for (int c = 0; c < 6; ++c) T[r * 6 + c] += p->ssx[r][j] * p->ssx[c][j] * it;
     }
   }
   for (int r = 0; r < 6; ++r)
-    for (int c = 0; c < 6; ++c) F[r * 6 + c] = tm->T[r * 6 + c] + (r == c ? 1.0 / p->chs2[r] : 0.0);
-  sym_inv6(F, tm->Fi);
-  mv6(tm->Fi, tm->a, tm->Fia);
-  tm->s11 = sth;
-  for (int r = 0; r < 6; ++r) tm->s11 -= tm->a[r] * tm->Fia[r];
+    for (int c = 0; c < 6; ++c) F[r * 6 + c] = T[r * 6 + c] + (r == c ? 1.0 / p->chs2[r] : 0.0);
+  sym_inv6(F, tm->FBi);
+  double C[MA_MAX][MA_MAX];
+  for (int a = 0; a < m; ++a)
+    for (int r = 0; r < 6; ++r) {
+      double s = 0.0;
+      for (int c = 0; c < 6; ++c) s += tm->FBi[r * 6 + c] * p->ssx[c][tm->idx[a]];
+      tm->W[r][a] = s;
+    }
+  for (int a = 0; a < m; ++a)
+    for (int b = 0; b <= a; ++b) {
+      double s = (a == b) ? thl[tm->idx[a]] : 0.0;
+      for (int r = 0; r < 6; ++r) s += p->ssx[r][tm->idx[a]] * tm->W[r][b];
+      C[a][b] = s;
+    }
+  double jit = 0.0; /* identical points (the padding repeats the last one) make C_A singular as theta -> 0 */
+  for (int a = 0; a < m; ++a) jit += C[a][a];
+  jit *= 1e-13;
+  for (int a = 0; a < m; ++a) {
+    for (int b = 0; b <= a; ++b) {
+      double s = C[a][b] + (a == b ? jit : 0.0);
+      for (int k = 0; k < b; ++k) s -= tm->Lc[a][k] * tm->Lc[b][k];
+      tm->Lc[a][b] = (a == b) ? sqrt(s) : s / tm->Lc[b][b];
+    }
+  }
+  /* F^-1 = F_B^-1 - W C^-1 W' (column by column) */
+  for (int c = 0; c < 6; ++c) {
+    double x[MA_MAX];
+    for (int a = 0; a < m; ++a) x[a] = tm->W[c][a];
+    solve_CA(tm, x);
+    for (int r = 0; r < 6; ++r) {
+      double s = tm->FBi[r * 6 + c];
+      for (int a = 0; a < m; ++a) s -= tm->W[r][a] * x[a];
+      tm->Fi[r * 6 + c] = s;
+    }
+  }
+  /* x1, z1, g, s11 */
+  double z1[6];
+  for (int a = 0; a < m; ++a) {
+    double s = 1.0;
+    for (int r = 0; r < 6; ++r) s -= tm->W[r][a] * tm->aB[r];
+    tm->x1[a] = s;
+  }
+  solve_CA(tm, tm->x1);
+  for (int r = 0; r < 6; ++r) {
+    z1[r] = tm->aB[r];
+    for (int a = 0; a < m; ++a) z1[r] += p->ssx[r][tm->idx[a]] * tm->x1[a];
+  }
+  mv6(tm->FBi, z1, tm->g);
+  tm->s11 = tm->sB;
+  for (int a = 0; a < m; ++a) tm->s11 += tm->x1[a];
+  for (int r = 0; r < 6; ++r) tm->s11 -= tm->aB[r] * tm->g[r];
   for (int r = 0; r < 6; ++r)
-    for (int c = 0; c < 6; ++c) PT[r * 6 + c] = tm->Fi[r * 6 + c] + tm->Fia[r] * tm->Fia[c] / tm->s11;
+    for (int c = 0; c < 6; ++c) PT[r * 6 + c] = tm->Fi[r * 6 + c] + tm->g[r] * tm->g[c] / tm->s11;
 }
 
-/* per right-hand side: sums with bl, returns the terminal-gradient contribution pT = -E U dl0 */
-static void term_rhs(const prob_t* p, term_t* tm, const double* thl, const double* bl, double r1, double* pT) {
-  const int S = p->S;
-  tm->sbl = 0.0;
-  for (int r = 0; r < 6; ++r) tm->beta[r] = 0.0;
+/* the solve for a right-hand side r_j = (e'u_j) - bl_j (e = E dx, or 0) and simplex residual r1: fills dl (all points)
+ * and h = E U dl */
+static void term_solve(const prob_t* p, const term_t* tm, const double* thl, const double* bl, double r1, const double* e,
+                       double* dl, double* h) {
+  const int S = p->S, m = tm->m;
+  double beta[6] = {0}, sig = 0.0, xA[MA_MAX], z[6], Fz[6];
   for (int j = 0; j < S; ++j) {
-    const double w = bl[j] / fmax(thl[j], TH_L_MIN);
-    tm->sbl += w;
-    for (int r = 0; r < 6; ++r) tm->beta[r] += p->ssx[r][j] * w;
+    if (tm->inA[j]) continue;
+    double rj = -bl[j];
+    if (e)
+      for (int k = 0; k < 6; ++k) rj += p->ssx[k][j] * e[k];
+    const double w = rj / thl[j];
+    sig += w;
+    for (int k = 0; k < 6; ++k) beta[k] += p->ssx[k][j] * w;
   }
-  mv6(tm->Fi, tm->beta, tm->Fibeta);
-  double aFib = 0.0;
-  for (int r = 0; r < 6; ++r) aFib += tm->a[r] * tm->Fibeta[r];
-  const double coef = (tm->sbl - aFib + r1) / tm->s11;
-  for (int r = 0; r < 6; ++r) pT[r] = tm->Fibeta[r] - tm->Fia[r] * coef;
+  for (int a = 0; a < m; ++a) {
+    const int j = tm->idx[a];
+    double s = -bl[j];
+    if (e)
+      for (int k = 0; k < 6; ++k) s += p->ssx[k][j] * e[k];
+    for (int r = 0; r < 6; ++r) s -= tm->W[r][a] * beta[r];
+    xA[a] = s;
+  }
+  solve_CA(tm, xA);
+  double num = sig - r1;
+  for (int r = 0; r < 6; ++r) {
+    z[r] = beta[r];
+    for (int a = 0; a < m; ++a) z[r] += p->ssx[r][tm->idx[a]] * xA[a];
+  }
+  mv6(tm->FBi, z, Fz);
+  for (int a = 0; a < m; ++a) num += xA[a];
+  for (int r = 0; r < 6; ++r) num -= tm->aB[r] * Fz[r];
+  const double nu = num / tm->s11;
+  for (int r = 0; r < 6; ++r) h[r] = Fz[r] - nu * tm->g[r];
+  if (!dl) return;
+  for (int j = 0; j < S; ++j) {
+    if (tm->inA[j]) continue;
+    double rj = -bl[j] - nu;
+    for (int k = 0; k < 6; ++k) rj += p->ssx[k][j] * ((e ? e[k] : 0.0) - h[k]);
+    dl[j] = rj / thl[j];
+  }
+  for (int a = 0; a < m; ++a) dl[tm->idx[a]] = xA[a] - nu * tm->x1[a];
+}
+
+/* per right-hand side: the terminal-gradient contribution pT = -E U dl0 (dl0: the step at dx = 0) */
+static void term_rhs(const prob_t* p, term_t* tm, const double* thl, const double* bl, double r1, double* pT) {
+  double h[6];
+  term_solve(p, tm, thl, bl, r1, NULL, NULL, h);
+  for (int r = 0; r < 6; ++r) pT[r] = -h[r];
 }
 
 static void term_dl_of_dx(const prob_t* p, const term_t* tm, const double* thl, const double* bl, double r1,
                           const double* dx, double* dl) {
-  const int S = p->S;
-  double e[6], gam[6] = {0}, Figam[6], sr = 0.0, aFig = 0.0;
+  double e[6], h[6];
   for (int k = 0; k < 6; ++k) e[k] = p->chs2[k] * dx[k];
-  /* gamma = U Th^-1 r and sr = 1'Th^-1 r summed from the per-point residuals r_j = u_j'E dx - bl_j
-   * (small for points with lambda > 0) rather than as T e - beta, which cancels */
-  for (int j = 0; j < S; ++j) {
-    double rj = -bl[j];
-    for (int k = 0; k < 6; ++k) rj += p->ssx[k][j] * e[k];
-    const double w = rj / fmax(thl[j], TH_L_MIN);
-    sr += w;
-    for (int k = 0; k < 6; ++k) gam[k] += p->ssx[k][j] * w;
-  }
-  mv6(tm->Fi, gam, Figam);
-  for (int k = 0; k < 6; ++k) aFig += tm->a[k] * Figam[k];
-  const double coef = (sr - aFig - r1) / tm->s11;
-  for (int j = 0; j < S; ++j) {
-    double rj = -bl[j], ug = 0.0, ua = 0.0;
-    for (int k = 0; k < 6; ++k) {
-      rj += p->ssx[k][j] * e[k];
-      ug += p->ssx[k][j] * Figam[k];
-      ua += p->ssx[k][j] * tm->Fia[k];
-    }
-    const double it = 1.0 / fmax(thl[j], TH_L_MIN);
-    dl[j] = (rj - ug) * it - (1.0 - ua) * it * coef;
-  }
+  term_solve(p, tm, thl, bl, r1, e, dl, h);
 }
 
 /* ---- shared Newton machinery -------------------------------------------------------------
@@ -1030,6 +1130,13 @@ static void setup_problem(prob_t* p, const lmpc_config* cfg, const lmpc_vehicle*
       for (int j = 0; j < p->S; ++j) p->ssx[k][j] = ss_x[(size_t)(k * p->S + j) * B + b] - p->ss0[k];
     }
     for (int j = 0; j < p->S; ++j) p->ssj[j] = ss_j[(size_t)j * B + b];
+    double umax = 0.0; /* largest u_j' E u_j over the (centred) points */
+    for (int j = 0; j < p->S; ++j) {
+      double q = 0.0;
+      for (int k = 0; k < 6; ++k) q += p->chs2[k] * p->ssx[k][j] * p->ssx[k][j];
+      if (q > umax) umax = q;
+    }
+    p->tau = TAU_REL * umax;
   }
   /* bounds */
   const double u_lo[2] = {fmax(cfg->u_min[0], veh->Fb_max / 1000.0), fmax(cfg->u_min[1], -veh->max_steer)};

@@ -141,3 +141,10 @@ def iac_tracking_mpc(N: int = 40) -> MPCConfig:
                      x_max=np.array([INF, INF, INF, 100.0, 15.0, 2.0]),
                      x_min=np.array([-INF, -INF, -INF, 3.0, -15.0, -2.0]),
                      u_max=np.array([5.0, 0.314159]), u_min=np.array([-10.0, -0.314159]))
+
+
+def iac_lmpc(N: int = 60, n_laps: int = 3) -> MPCConfig:
+    """iac_car_lmpc.param.yaml (ships n = 60)."""
+    return iac_tracking_mpc(N).with_(learning=True, R=np.diag([1e-4, 1e-3]), R_d=np.diag([5e-4, 1e-1]),
+                                     convex_hull_slack=np.array([200.0, 20.0, 2.0, 200.0, 2.0, 20.0]),
+                                     num_ss_pts=32 * n_laps, num_ss_pts_per_lap=32, max_lap_stored=n_laps)

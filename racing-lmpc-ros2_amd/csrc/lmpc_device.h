@@ -34,7 +34,7 @@ struct lmpc_params {
 #define LMPC_STAGE_STRIDE 78
 #define LMPC_KNOT_STRIDE 36
 #define LMPC_TAIL_DOUBLES 320
-#define LMPC_TAIL_DOUBLES_LMPC 464  // + terminal-block scratch (PT, T, F^-1, a, ...)
+#define LMPC_TAIL_DOUBLES_LMPC 552  // + terminal-block scratch (PT, F_B^-1, W_A, U_A, factor of C_A, ...; lmpc_solve_kernel.hip TL_*)
 #define LMPC_LIN_RECORD 54  // per stage in the linearisation workspace: ABt[8][6] | g[6]
 
 static inline int lmpc_lds_doubles(int N, int learning) {

@@ -100,16 +100,23 @@ struct Prof {};
 #define CT_HL 20    // box bounds of the ten primal components, (hi, lo) interleaved
 #define CT_ZERO 40  // a 0.0 entry: coefficient slot for "no term"
 #define CT_E 41     // 2 * convex_hull_slack (LMPC)
-// LMPC extension of the tail (only allocated when learning): terminal-block quantities
-#define TL_PT 320   // PT[6][6]: terminal cost-to-go contributed by the safe-set block
-#define TL_TG 356   // terminal gradient contribution  E eps + pT
-#define TL_EPS 362  // eps = (x_T - ss0) - (SS - ss0 1') lambda
-#define TL_T 368    // T = U Th^-1 U' (6x6)
-#define TL_FI 404   // F^-1, F = E^-1 + T
-#define TL_A 440    // a = U Th^-1 1
-#define TL_FIA 446  // F^-1 a
-#define TL_S11 452  // s11 = 1'M^-1 1
-#define TH_L_MIN 1e-4  // floor of the simplex rows' weight inside the Newton matrix (see oracle/c/lmpc_oracle.c)
+// LMPC extension of the tail (only allocated when learning): terminal-block quantities (see term_factor_u)
+#define TL_PT 320    // PT[6][6]: terminal cost-to-go contributed by the safe-set block
+#define TL_TG 356    // terminal gradient contribution  E eps + pT
+#define TL_EPS 362   // eps = (x_T - ss0) - (SS - ss0 1') lambda
+#define TL_FB 368    // F_B^-1 [6][6], F_B = E^-1 + U_B Th_B^-1 U_B' (the points eliminated through 1/theta)
+#define TL_WA 404    // W_A = F_B^-1 U_A, column a at +6a
+#define TL_UA 440    // u of the explicit points, point a at +6a
+#define TL_LC 476    // Cholesky factor of C_A = Theta_A + U_A'F_B^-1 U_A, [i][k] (k < i); the RECIPROCAL pivots on the diagonal
+#define TL_X1 512    // C_A^-1 (1_A - W_A'a_B)
+#define TL_G 518     // g = E U M^-1 1
+#define TL_AB 524    // a_B = U_B Th_B^-1 1
+#define TL_RA 530    // right-hand side of the explicit points (written by their owner lanes)
+#define TL_THA 536   // theta of the explicit points
+#define TL_XA 542    // their step d lambda_A (read back by the owner lanes)
+#define TL_S11 548   // s11 = 1'M^-1 1
+#define MA_MAX 6       // explicit points at most (the smallest theta below tau)
+#define TAU_REL 1e-5   // tau = TAU_REL * max_j u_j'E u_j: cond(F_B) <= ~1e5 whatever the iteration does
 #define STALL_MU 1e-9  // complementarity below which a step that does not lower it ends the solve
 #define F_UP 1
 #define F_LO 2
@@ -124,6 +131,17 @@ struct Prof {};
 // so cross-lane exchange through LDS needs no s_barrier and no wait for the write to retire: only the
 // compiler must not move memory operations across the exchange point.
 __device__ __forceinline__ void wave_sync() { __builtin_amdgcn_wave_barrier(); }
+// The same with memory-model fences at wavefront scope around it.  wave_barrier alone is invisible to the IR-level memory
+// passes (it is declared as not touching memory), so around a store that only SOME lanes execute -- `if (lane == 0)
+// T[..] = ..` -- the compiler may schedule the other lanes' later loads of those cells on the not-taken path ahead of the
+// taken path's stores: the readers then see the previous workgroup's LDS content.  (Seen on the terminal block of the
+// learning problem: results changed from process to process.)  The fences pin the order; at wavefront scope they cost no
+// cache action.
+__device__ __forceinline__ void wave_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 // A value that is the same in every lane, moved to scalar registers (v_readfirstlane): the solver's
 // wave-wide scalars (mu, step lengths, sigma, ...) then cost no vector registers while they are carried
@@ -348,14 +366,14 @@ __device__ __forceinline__ void spd_inv6(const real (&F)[36], real (&Fi)[36]) {
 }
 
 // LMPC simplex row j: gradient of the (eps-eliminated) terminal cost wrt lambda_j including the row's
-// barrier coefficient, bl_j = ss_j - cf_j - u_j'E eps; also returns 1/max(theta_j, floor).
+// barrier coefficient, bl_j = ss_j - cf_j - u_j'E eps; also returns 1/theta_j.
 // (ee = E eps of this iteration, wave-uniform)
 template <typename real>
 __device__ __forceinline__ real simplex_bl(real lm, real t, real l, real pprod, real ssj, const real (&u)[6],
                                              real smu, real pm, const real (&ee)[6], real& itf) {
   const real it_ = frcp(t);
   const real th = l * it_;
-  itf = frcp(fmax(th, TH_L_MIN));
+  itf = frcp(th);
   const real cf = th * (-lm + t) + (smu - pm * pprod) * it_;
   real ue = 0.0;
 #pragma unroll
@@ -363,14 +381,264 @@ __device__ __forceinline__ real simplex_bl(real lm, real t, real l, real pprod, 
   return ssj - cf - ue;
 }
 
+// ---- terminal block: two-level elimination of the simplex weights (oracle/c/lmpc_oracle.c documents the derivation) ----
+// Points with theta >= tau (B) are eliminated through 1/theta and enter as wave sums (T_B, a_B, s_B); the few points
+// whose lambda stays positive have theta -> 0 and are kept as explicit unknowns (A, at most MA_MAX): nothing is ever
+// divided by a small theta, and cond(F_B) stays below ~1/TAU_REL.  Everything here is wave-uniform arithmetic on values
+// every lane holds; results go to the LDS tail (lane 0 writes), the per-right-hand-side solves read them back as
+// broadcast reads.  Unused explicit slots (a >= m) hold u = 0, theta = 1, so they drop out without a branch.
+template <typename real>
+__device__ __forceinline__ void chol_solve6(const real* Lc, real (&x)[MA_MAX]) {  // x <- C_A^-1 x
+#pragma unroll
+  for (int i = 0; i < MA_MAX; ++i) {
+    real v = x[i];
+#pragma unroll
+    for (int k = 0; k < i; ++k) v -= Lc[i * 6 + k] * x[k];
+    x[i] = v * Lc[i * 6 + i];
+  }
+#pragma unroll
+  for (int i = MA_MAX - 1; i >= 0; --i) {
+    real v = x[i];
+#pragma unroll
+    for (int k = i + 1; k < MA_MAX; ++k) v -= Lc[k * 6 + i] * x[k];
+    x[i] = v * Lc[i * 6 + i];
+  }
+}
+
+// F = E^-1 + T_B (full 6x6), a_B, s_B, m explicit points (their u, theta already in T[TL_UA], T[TL_THA]).
+// Writes F_B^-1, W_A, the factor of C_A, x1, g, a_B, s11 and PT = F^-1 + g g'/s11.
+// Every lane computes everything (wave-uniform values), lane 0 stores, later stages read back as broadcast reads: W and
+// F_B^-1 go through LDS between the stages so that they are not live together with the factor and with Y -- kept in
+// registers throughout, the block pushed 200 registers of the iteration's row state to scratch (LMPC batch: 4.0 ms).
+// (A version that dealt the 6x6 products to 36 lanes, one element each, was 25 % faster still and NOT reproducible from
+// run to run; the single-writer pattern used everywhere else in this kernel is.)
+template <typename real>
+__device__ __forceinline__ void term_factor_u(real* T, int lane, const real (&F)[36], const real (&aB)[6], real sB, int m) {
+  // Loops over the explicit points / the columns are deliberately NOT unrolled: their operands come from LDS by a
+  // run-time index, so only one 6x6 triangular factor is ever live in registers.
+  {  // F_B^-1 by Cholesky, one column at a time straight into LDS (the inverse is never held in registers)
+    real Lf[36];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      real d = F[j * 6 + j];
+#pragma unroll
+      for (int k = 0; k < j; ++k) d -= Lf[j * 6 + k] * Lf[j * 6 + k];
+      const real id = real(1) / sqrt(d);
+      Lf[j * 6 + j] = id;  // reciprocal pivot
+#pragma unroll
+      for (int i = j + 1; i < 6; ++i) {
+        real t = F[i * 6 + j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) t -= Lf[i * 6 + k] * Lf[j * 6 + k];
+        Lf[i * 6 + j] = t * id;
+      }
+    }
+#pragma nounroll
+    for (int c = 0; c < 6; ++c) {
+      real y[6], x[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        real t = (i == c) ? real(1) : real(0);
+#pragma unroll
+        for (int k = 0; k < i; ++k) t -= Lf[i * 6 + k] * y[k];
+        y[i] = t * Lf[i * 6 + i];
+      }
+#pragma unroll
+      for (int i = 5; i >= 0; --i) {
+        real t = y[i];
+#pragma unroll
+        for (int k = i + 1; k < 6; ++k) t -= Lf[k * 6 + i] * x[k];
+        x[i] = t * Lf[i * 6 + i];
+      }
+      if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) T[TL_FB + i * 6 + c] = x[i];
+      }
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) T[TL_AB + k] = aB[k];
+    }
+  }
+  wave_fence();
+  // W[a][r] = sum_c F_B^-1[r][c] u_a[c]
+#pragma nounroll
+  for (int a = 0; a < MA_MAX; ++a) {
+    real ua[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) ua[c] = T[TL_UA + a * 6 + c];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      real v = 0.0;
+#pragma unroll
+      for (int c = 0; c < 6; ++c) v += T[TL_FB + r * 6 + c] * ua[c];
+      if (lane == 0) T[TL_WA + a * 6 + r] = v;
+    }
+  }
+  wave_fence();
+  // C_A = Theta_A + U_A'W_A, staged through the factor's cells
+#pragma nounroll
+  for (int a = 0; a < MA_MAX; ++a) {
+    real ua[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) ua[c] = T[TL_UA + a * 6 + c];
+    const real tha = T[TL_THA + a];
+#pragma unroll
+    for (int bq = 0; bq < MA_MAX; ++bq) {
+      real v = (a == bq) ? tha : real(0);
+#pragma unroll
+      for (int r = 0; r < 6; ++r) v += ua[r] * T[TL_WA + bq * 6 + r];
+      if (lane == 0) T[TL_LC + a * 6 + bq] = v;
+    }
+  }
+  wave_fence();
+  // its Cholesky factor, reciprocal pivots on the diagonal; a jitter for identical points (the padding repeats the last
+  // point of the set: C_A is then singular as theta -> 0)
+  real Lc[36];
+  {
+    real jit = 0.0;
+#pragma unroll
+    for (int a = 0; a < MA_MAX; ++a) {
+#pragma unroll
+      for (int bq = 0; bq <= a; ++bq) Lc[a * 6 + bq] = T[TL_LC + a * 6 + bq];
+      jit += Lc[a * 6 + a];
+    }
+    jit *= real(1e-13);
+#pragma unroll
+    for (int a = 0; a < MA_MAX; ++a) {
+#pragma unroll
+      for (int bq = 0; bq <= a; ++bq) {
+        real v = Lc[a * 6 + bq] + (a == bq ? jit : real(0));
+#pragma unroll
+        for (int k = 0; k < bq; ++k) v -= Lc[a * 6 + k] * Lc[bq * 6 + k];
+        Lc[a * 6 + bq] = (a == bq) ? real(1) / sqrt(v) : v * Lc[bq * 6 + bq];
+      }
+    }
+  }
+  wave_fence();
+  // x1 = C_A^-1 (1_A - W_A'a_B), z1 = a_B + U_A x1, g = F_B^-1 z1, s11 = 1_A'x1 + s_B - a_B'g
+  real g[6];
+  real s11 = sB;
+  {
+    real x1[MA_MAX];
+#pragma unroll
+    for (int a = 0; a < MA_MAX; ++a) {
+      real v = a < m ? real(1) : real(0);
+#pragma unroll
+      for (int r = 0; r < 6; ++r) v -= T[TL_WA + a * 6 + r] * aB[r];
+      x1[a] = v;
+    }
+    chol_solve6(Lc, x1);
+    real z1[6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) z1[r] = aB[r];
+#pragma unroll
+    for (int a = 0; a < MA_MAX; ++a) {
+#pragma unroll
+      for (int r = 0; r < 6; ++r) z1[r] += T[TL_UA + a * 6 + r] * x1[a];
+      s11 += a < m ? x1[a] : real(0);
+    }
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      real v = 0.0;
+#pragma unroll
+      for (int c = 0; c < 6; ++c) v += T[TL_FB + r * 6 + c] * z1[c];
+      g[r] = v;
+      s11 -= aB[r] * v;
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        T[TL_X1 + k] = x1[k];
+        T[TL_G + k] = g[k];
+      }
+      T[TL_S11] = s11;
+#pragma unroll
+      for (int a = 0; a < MA_MAX; ++a)
+#pragma unroll
+        for (int bq = 0; bq <= a; ++bq) T[TL_LC + a * 6 + bq] = Lc[a * 6 + bq];
+    }
+  }
+  // PT = F_B^-1 - W_A C_A^-1 W_A' + g g'/s11, column by column
+  const real is11 = real(1) / s11;
+#pragma nounroll
+  for (int c = 0; c < 6; ++c) {
+    real t[MA_MAX];
+#pragma unroll
+    for (int a = 0; a < MA_MAX; ++a) t[a] = T[TL_WA + a * 6 + c];
+    chol_solve6(Lc, t);
+    const real gc = T[TL_G + c];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      real v = T[TL_FB + r * 6 + c] + g[r] * gc * is11;
+#pragma unroll
+      for (int a = 0; a < MA_MAX; ++a) v -= T[TL_WA + a * 6 + r] * t[a];
+      if (lane == 0) T[TL_PT + r * 6 + c] = v;
+    }
+  }
+  wave_fence();
+}
+
+// One right-hand side: beta = U_B Th_B^-1 r_B, sig = 1'Th_B^-1 r_B (wave sums over B), r_A in T[TL_RA], simplex
+// residual r1.  Returns h = E U dlambda and nu; writes the explicit points' step to T[TL_XA] (lane 0).
+template <typename real>
+__device__ __forceinline__ void term_solve_u(real* T, int lane, int m, const real (&beta)[6], real sig, real r1, real (&h)[6],
+                                             real& nu) {
+  real xa[MA_MAX];
+#pragma unroll
+  for (int a = 0; a < MA_MAX; ++a) {
+    real v = T[TL_RA + a];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) v -= T[TL_WA + a * 6 + r] * beta[r];
+    xa[a] = v;
+  }
+  {
+    real Lc[36];
+#pragma unroll
+    for (int i = 0; i < MA_MAX; ++i)
+#pragma unroll
+      for (int k = 0; k <= i; ++k) Lc[i * 6 + k] = T[TL_LC + i * 6 + k];
+    chol_solve6(Lc, xa);
+  }
+  real z[6], num = sig - r1;
+#pragma unroll
+  for (int r = 0; r < 6; ++r) z[r] = beta[r];
+#pragma unroll
+  for (int a = 0; a < MA_MAX; ++a) {
+#pragma unroll
+    for (int r = 0; r < 6; ++r) z[r] += T[TL_UA + a * 6 + r] * xa[a];
+    num += a < m ? xa[a] : real(0);
+  }
+  real Fz[6];
+#pragma unroll
+  for (int r = 0; r < 6; ++r) {
+    real v = 0.0;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) v += T[TL_FB + r * 6 + c] * z[c];
+    Fz[r] = v;
+    num -= T[TL_AB + r] * v;
+  }
+  nu = num / T[TL_S11];
+#pragma unroll
+  for (int r = 0; r < 6; ++r) h[r] = Fz[r] - nu * T[TL_G + r];
+  if (lane == 0) {
+#pragma unroll
+    for (int a = 0; a < MA_MAX; ++a) T[TL_XA + a] = xa[a] - nu * T[TL_X1 + a];
+  }
+  wave_fence();
+}
+
 // Register-resident state of the LMPC simplex rows lambda_j >= 0 (KS safe-set points per lane); empty for
 // the tracking kernel so that it costs it nothing.
 template <typename real, int KS>
 struct SimplexRows {
   bool on[KS];
+  int aidx[KS];  // slot of the point among the explicit ones of this iteration, -1: eliminated through 1/theta
   real lm[KS], t[KS], l[KS], p[KS], j[KS], u[KS][6], dl[KS];
   real ss0[6];
-  real r1;  // 1 - 1'lambda
+  real r1;   // 1 - 1'lambda
+  real tau;  // theta below which a point is kept explicit
+  int m;     // explicit points of this iteration
 };
 template <typename real>
 struct SimplexRows<real, 0> {};
@@ -915,8 +1183,19 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
       sx.l[q] = 0.0;
       sx.p[q] = 0.0;
       sx.dl[q] = 0.0;
+      sx.aidx[q] = -1;
       m_rows += sx.on[q] ? 1.0 : 0.0;
     }
+    real umax = 0.0;  // largest u_j'E u_j of the (centred) points
+#pragma unroll
+    for (int q = 0; q < KS; ++q) {
+      real v = 0.0;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) v += real(P.chs2[k]) * sx.u[q][k] * sx.u[q][k];
+      umax = fmax(umax, v);
+    }
+    sx.tau = uni(real(TAU_REL) * wave_max(umax));
+    sx.m = 0;
   }
   const real m_tot = wave_sum(m_rows);
   const real inv_m = uni(real(1) / m_tot);
@@ -1006,7 +1285,49 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
         }
       }
       if constexpr (KS > 0) {
-        real tt[21], av[14];  // T (upper triangle) | a[6], sum 1/theta, U lambda [6], sum lambda
+        // ---- which points stay explicit this iteration: the (at most MA_MAX) smallest theta below tau ----
+        real thq[KS];
+#pragma unroll
+        for (int q = 0; q < KS; ++q) {
+          thq[q] = sx.on[q] ? sx.l[q] * frcp(sx.t[q]) : inf;
+          sx.aidx[q] = -1;
+        }
+        if (lane < 6 * MA_MAX) T[TL_UA + lane] = 0.0;            // unused slots: u = 0, theta = 1, rhs = 0
+        if (lane < MA_MAX) {
+          T[TL_THA + lane] = 1.0;
+          T[TL_RA + lane] = 0.0;
+        }
+        wave_fence();
+        int m = 0;
+        for (int a = 0; a < MA_MAX; ++a) {
+          real cand = inf;
+          int cq = 0;
+#pragma unroll
+          for (int q = 0; q < KS; ++q) {
+            const bool better = sx.aidx[q] < 0 && thq[q] < sx.tau && thq[q] < cand;
+            cand = better ? thq[q] : cand;
+            cq = better ? q : cq;
+          }
+          const real best = wave_min(cand);
+          if (!(best < inf)) break;
+          const int owner = __ffsll((long long)__ballot(cand == best)) - 1;  // the lowest lane holding the minimum
+          if (lane == owner) {
+#pragma unroll
+            for (int q = 0; q < KS; ++q)
+              if (q == cq) {
+                sx.aidx[q] = a;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) T[TL_UA + a * 6 + k] = sx.u[q][k];
+                T[TL_THA + a] = thq[q];
+              }
+          }
+          wave_fence();
+          m = a + 1;
+        }
+        sx.m = m;
+        wave_fence();
+        // ---- sums over the eliminated points: T_B (21), a_B (6), s_B; and over all points: U lambda (6), sum lambda ----
+        real tt[21], av[14];
 #pragma unroll
         for (int k = 0; k < 21; ++k) tt[k] = 0.0;
 #pragma unroll
@@ -1014,7 +1335,7 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
 #pragma unroll
         for (int q = 0; q < KS; ++q) {
           const real on = sx.on[q] ? 1.0 : 0.0;
-          const real itf = on * frcp(fmax(sx.l[q] * frcp(sx.t[q]), TH_L_MIN));
+          const real itf = (sx.on[q] && sx.aidx[q] < 0) ? frcp(thq[q]) : real(0);
           musum += on * sx.l[q] * sx.t[q];
           rdl = fmax(rdl, on * fabs(-sx.lm[q] + sx.t[q]));
           int n = 0;
@@ -1045,49 +1366,31 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
           av[13] = red3[2];
         }
         sx.r1 = 1.0 - av[13];
-        real F[36], Fi[36], Fia[6];
         {
+          real F[36], aB[6];
           int n = 0;
 #pragma unroll
-          for (int r = 0; r < 6; ++r)
+          for (int r = 0; r < 6; ++r) {
 #pragma unroll
             for (int c = r; c < 6; ++c) {
               F[r * 6 + c] = tt[n];
               F[c * 6 + r] = tt[n];
               ++n;
             }
-        }
-        if (lane == 0) {
-#pragma unroll
-          for (int k = 0; k < 36; ++k) T[TL_T + k] = F[k];
-        }
-#pragma unroll
-        for (int k = 0; k < 6; ++k) F[k * 6 + k] += 1.0 / ct[CT_E + k];
-        spd_inv6(F, Fi);
-        real s11 = av[6];
-#pragma unroll
-        for (int r = 0; r < 6; ++r) {
-          real t = 0.0;
-#pragma unroll
-          for (int c = 0; c < 6; ++c) t += Fi[r * 6 + c] * av[c];
-          Fia[r] = t;
-          s11 -= av[r] * t;
-        }
-        const real is11 = 1.0 / s11;
-        if (lane == 0) {
-#pragma unroll
-          for (int r = 0; r < 6; ++r) {
-#pragma unroll
-            for (int c = 0; c < 6; ++c) {
-              T[TL_FI + r * 6 + c] = Fi[r * 6 + c];
-              T[TL_PT + r * 6 + c] = Fi[r * 6 + c] + Fia[r] * Fia[c] * is11;  // PT = F^-1 + (F^-1 a)(F^-1 a)'/s11
-            }
-            T[TL_A + r] = av[r];
-            T[TL_FIA + r] = Fia[r];
-            T[TL_EPS + r] = (L.kn(N - 1)[r] - sx.ss0[r]) - av[7 + r];
+            aB[r] = av[r];
           }
-          T[TL_S11] = s11;
+#pragma unroll
+          for (int k = 0; k < 6; ++k) F[k * 6 + k] += 1.0 / ct[CT_E + k];
+          term_factor_u(T, lane, F, aB, av[6], m);
         }
+        if (lane < 6) {
+          real e = 0.0;
+#pragma unroll
+          for (int k = 0; k < 6; ++k)
+            if (k == lane) e = (L.kn(N - 1)[k] - sx.ss0[k]) - av[7 + k];
+          T[TL_EPS + lane] = e;
+        }
+        wave_fence();
       }
       {
         real red[2] = {musum, eysum};
@@ -1142,35 +1445,32 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
       real sgsum = 0.0;  // sum of boundary-row coefficients entering the sigma gradient
       if constexpr (KS > 0) {
         if (ipm) {
-          real sbl = 0.0;
+          // right-hand side r_j = -bl_j (dx = 0): sums over the eliminated points, the explicit ones through LDS
           real bs[7] = {0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
           for (int q = 0; q < KS; ++q) {
             real itf;
-            const real w = sx.on[q] ? simplex_bl(sx.lm[q], sx.t[q], sx.l[q], sx.p[q], sx.j[q], sx.u[q], smu, pm, eeps, itf) * itf : 0.0;
+            const real rj = sx.on[q] ? -simplex_bl(sx.lm[q], sx.t[q], sx.l[q], sx.p[q], sx.j[q], sx.u[q], smu, pm, eeps, itf) : real(0);
+            if (sx.aidx[q] >= 0) T[TL_RA + sx.aidx[q]] = rj;
+            const real w = (sx.on[q] && sx.aidx[q] < 0) ? rj * itf : real(0);
             bs[6] += w;
 #pragma unroll
             for (int k = 0; k < 6; ++k) bs[k] += sx.u[q][k] * w;
           }
           wave_sum_split<7>(bs, lane);
-          sbl = bs[6];
-          real Fib[6], aFib = 0.0;
+          wave_fence();
+          real beta[6], h[6], nu;
 #pragma unroll
-          for (int r = 0; r < 6; ++r) {
-            real t = 0.0;
-#pragma unroll
-            for (int c = 0; c < 6; ++c) t += T[TL_FI + r * 6 + c] * bs[c];
-            Fib[r] = t;
-            aFib += T[TL_A + r] * t;
-          }
-          const real coef = (sbl - aFib + sx.r1) / T[TL_S11];
-          if (lane < 6) {
+          for (int k = 0; k < 6; ++k) beta[k] = bs[k];
+          term_solve_u(T, lane, sx.m, beta, bs[6], sx.r1, h, nu);
+          if (lane < 6) {  // terminal gradient onto x_T: E eps + pT, pT = -h
             real tg = 0.0;
 #pragma unroll
             for (int k = 0; k < 6; ++k)
-              if (k == lane) tg = ct[CT_E + k] * T[TL_EPS + k] + Fib[k] - T[TL_FIA + k] * coef;
+              if (k == lane) tg = ct[CT_E + k] * T[TL_EPS + k] - h[k];
             T[TL_TG + lane] = tg;
           }
+          wave_fence();
         }
       }
       {
@@ -1254,7 +1554,8 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
         dsigma = uni(-(qsg + red[0]) / (hsig + ce));
       }
       if constexpr (KS > 0) {
-        // d lambda_j = (r_j - u_j'F^-1 gamma)/theta_j - Mi1_j (sr - a'F^-1 gamma - sx.r1)/s11,  r_j = u_j'E dx_T - bl_j
+        // r_j = u_j'E dx_T - bl_j;  d lambda_j = (r_j - nu - u_j'h)/theta_j for the eliminated points, the explicit
+        // ones from the small dense solve
         const real* knT = L.kn(N - 1);
         real e[6], gs[7] = {0, 0, 0, 0, 0, 0, 0}, rj[KS], itfq[KS];
 #pragma unroll
@@ -1268,31 +1569,26 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
           r = sx.on[q] ? r : 0.0;
           rj[q] = r;
           itfq[q] = itf;
-          const real w = r * itf;
+          if (sx.aidx[q] >= 0) T[TL_RA + sx.aidx[q]] = r;
+          const real w = (sx.on[q] && sx.aidx[q] < 0) ? r * itf : real(0);
           gs[6] += w;
 #pragma unroll
           for (int k = 0; k < 6; ++k) gs[k] += sx.u[q][k] * w;
         }
         wave_sum_split<7>(gs, lane);
-        real Fig[6], aFig = 0.0;
+        wave_fence();
+        real beta[6], h[6], nu;
 #pragma unroll
-        for (int r = 0; r < 6; ++r) {
-          real t = 0.0;
-#pragma unroll
-          for (int c = 0; c < 6; ++c) t += T[TL_FI + r * 6 + c] * gs[c];
-          Fig[r] = t;
-          aFig += T[TL_A + r] * t;
-        }
-        const real coef = (gs[6] - aFig - sx.r1) / T[TL_S11];
+        for (int k = 0; k < 6; ++k) beta[k] = gs[k];
+        term_solve_u(T, lane, sx.m, beta, gs[6], sx.r1, h, nu);
 #pragma unroll
         for (int q = 0; q < KS; ++q) {
-          real ug = 0.0, ua = 0.0;
+          real uh = 0.0;
 #pragma unroll
-          for (int k = 0; k < 6; ++k) {
-            ug += sx.u[q][k] * Fig[k];
-            ua += sx.u[q][k] * T[TL_FIA + k];
-          }
-          sx.dl[q] = sx.on[q] ? (rj[q] - ug) * itfq[q] - (1.0 - ua) * itfq[q] * coef : 0.0;
+          for (int k = 0; k < 6; ++k) uh += sx.u[q][k] * h[k];
+          const real dB = (rj[q] - nu - uh) * itfq[q];
+          const real dA = T[TL_XA + (sx.aidx[q] >= 0 ? sx.aidx[q] : 0)];
+          sx.dl[q] = sx.on[q] ? (sx.aidx[q] >= 0 ? dA : dB) : real(0);
         }
       }
       // ======== row steps; largest feasible step as 1 / max(1, max -dt/t, max -dlam/lam) ========

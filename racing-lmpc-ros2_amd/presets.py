@@ -48,3 +48,12 @@ def iac_tracking_mpc(N: int = 40) -> dict:
                 x_max=[INF, INF, INF, 100.0, 15.0, 2.0], x_min=[-INF, -INF, -INF, 3.0, -15.0, -2.0],
                 u_max=[5.0, 0.314159], u_min=[-10.0, -0.314159],
                 convex_hull_slack=[20.0, 20.0, 2.0, 20.0, 20.0, 2.0], max_vel_ref_diff=1.0)
+
+
+def iac_lmpc(N: int = 60, n_laps: int = 3) -> dict:
+    """iac_car_lmpc.param.yaml (n = 60): the IAC learning controller."""
+    c = iac_tracking_mpc(N)
+    c.update(learning=1, R=[1e-4, 0.0, 0.0, 1e-3], R_d=[5e-4, 0.0, 0.0, 1e-1],
+             convex_hull_slack=[200.0, 20.0, 2.0, 200.0, 2.0, 20.0],
+             num_ss_pts=32 * n_laps, num_ss_pts_per_lap=32, max_lap_stored=n_laps)
+    return c

@@ -99,3 +99,44 @@ def test_headline_batch_status_parity(pkg):
     for b in range(0, B, 128):  # and a sample of the solved ones is solvable for the dense solver too
         if status[b] == 0:
             assert Q.solve_dense(Q.build_qp(cfg, veh, S.problem(npinp, b)))[1]["status"] == 0, b
+
+
+# ---- the IAC learning controller as shipped: iac_car_lmpc.param.yaml, n = 60 (tests/golden/make_golden_iac_lmpc.py) ----
+def _iac_lmpc_check(out, g, who):
+    """Honest statuses: a problem reported optimal is within the contract of the dense optimum (twice the tracking bound
+    on strictly complementary problems -- the simplex rows carry a proximal floor, csrc TH_L_MIN -- the degenerate bound
+    otherwise); the iteration may run out on a few (the floor damps the simplex weights' steps: slow on the IAC's hull
+    slack weights [200, 20, 2, 200, 2, 20]), and those say so and are still within 1e-4."""
+    from parity import per_problem_err
+    from tolerances import TOL_DEGENERATE, TOL_XU
+    e, ed = per_problem_err(out, g)
+    st = np.asarray(out["status"])
+    ok = st == 0
+    strict = (g["margin"] >= Q.DEGENERATE_MARGIN) & g["certified"]
+    assert ok.sum() >= 5, (who, st)
+    assert (st[~ok] == 1).all() and e[~ok].max(initial=0.0) < 1e-4, (who, st, e)
+    assert e[ok & strict].max(initial=0.0) < 2 * TOL_XU and e[ok & ~strict].max(initial=0.0) < TOL_DEGENERATE, (who, e, st)
+    lam = np.asarray(out["convex_combi_optm"])[:, ok]
+    assert np.abs(lam.sum(0) - 1.0).max() < 1e-9 and lam.min() > -1e-12
+
+
+def test_twin_on_the_iac_learning_controller_golden(golden):
+    g = golden("qp_iac_lmpc_n60")
+    out = cbind.solve_batch(P.iac_lmpc(60, 3), P.iac_vehicle(), g, ss_x=g["ss_x"], ss_j=g["ss_j"])
+    _iac_lmpc_check(out, g, "twin")
+
+
+@pytest.mark.gpu
+def test_kernel_on_the_iac_learning_controller_golden(pkg, golden):
+    """Safe-set query kernel -> LMPC QP kernel with the IAC vehicle and iac_car_lmpc.param.yaml's weights at its N = 60."""
+    import torch
+    g = golden("qp_iac_lmpc_n60")
+    solver = pkg.Solver(pkg.presets.iac_lmpc(60, 3), pkg.presets.iac_vehicle(), device=0)
+    solver.set_safe_set(list(g["laps"]), float(g["L"]))
+    ss_x, ss_j, nf = solver.ss_query(g["query"])
+    assert np.array_equal(ss_x.cpu().numpy(), g["ss_x"]) and np.array_equal(ss_j.cpu().numpy(), g["ss_j"])
+    B = g["x_ic"].shape[1]
+    out = solver.alloc_outputs(B)
+    out["convex_combi_optm"] = torch.zeros((96, B), dtype=torch.float64, device="cuda")
+    o = {k: v.cpu().numpy() for k, v in solver.solve(g, out, ss_x=ss_x, ss_j=ss_j).items() if hasattr(v, "cpu")}
+    _iac_lmpc_check(o, g, "kernel")

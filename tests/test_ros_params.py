@@ -163,7 +163,7 @@ def test_presets_equal_the_reference_shipped_files(pkg):
         params = rp.load_ros_params(REF_PARAM / car / f"{car}_base.param.yaml", REF_PARAM / car / f"{car}_single_track.param.yaml")
         assert rp.vehicle_from_params(params) == preset()
     for name, preset, n in (("barc_tracking_mpc", pr.barc_tracking_mpc, 60), ("barc_lmpc", pr.barc_lmpc, 40),
-                            ("iac_car_tracking_mpc", pr.iac_tracking_mpc, 80)):
+                            ("iac_car_tracking_mpc", pr.iac_tracking_mpc, 80), ("iac_car_lmpc", pr.iac_lmpc, 60)):
         params = rp.load_ros_params(REF_PARAM / "racing_mpc" / f"{name}.param.yaml")
         assert params["racing_mpc.n"] == n
         assert rp.mpc_config_from_params(params) == preset(n), name
@@ -181,7 +181,8 @@ def test_oracle_parameter_sets_equal_the_package_presets(pkg):
         for k, v in dataclasses.asdict(a).items():
             assert v == b[k], k
     for a, b in ((OP.barc_tracking_mpc(60), pkg.presets.barc_tracking_mpc(60)), (OP.barc_lmpc(40, 3), pkg.presets.barc_lmpc(40, 3)),
-                 (OP.barc_lmpc(20, 5), pkg.presets.barc_lmpc(20, 5)), (OP.iac_tracking_mpc(80), pkg.presets.iac_tracking_mpc(80))):
+                 (OP.barc_lmpc(20, 5), pkg.presets.barc_lmpc(20, 5)), (OP.iac_tracking_mpc(80), pkg.presets.iac_tracking_mpc(80)),
+                 (OP.iac_lmpc(60, 3), pkg.presets.iac_lmpc(60, 3))):
         for k, v in dataclasses.asdict(a).items():
             if isinstance(v, np.ndarray):
                 assert np.array_equal(v.ravel(), np.asarray(b[k], dtype=float).ravel()), k
