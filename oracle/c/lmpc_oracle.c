@@ -422,7 +422,7 @@ static inline double slot_val(double (*z)[8], double (*v)[2], int i, int sl) {
 #define JOSEPH_MU 1e-8
 /* complementarity below which a step that does not lower it ends the solve (ipm_solve) */
 #define STALL_MU 1e-9
-#define MA_MAX 6
+#define MA_MAX 4
 #define TAU_REL 1e-5 /* tau = TAU_REL * max_j u_j'E u_j: cond(F_B) <= ~1e5 */
 typedef struct {
   double Fi[36];       /* F^-1 over all points */

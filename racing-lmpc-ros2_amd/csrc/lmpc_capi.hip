@@ -148,7 +148,8 @@ const void* pick_solve_fn(int kq, int ks) {
 
 // fp32 interior-point iteration between fp64 arrays (lmpc_solve_batch_mixed): tracking problem
 const void* pick_mixed_fn(int kq, int ks) {
-  if (ks != 0) return nullptr;
+  if (ks == 2) return kq <= 4 ? solve_fn<4, 2, float>() : nullptr;   // the learning problem: N <= 23 (BASELINE configs[4])
+  if (ks == 3) return kq <= 4 ? solve_fn<4, 3, float>() : nullptr;
   switch (kq) {
     case 2:
     case 4: return solve_fn<4, 0, float>();
@@ -338,7 +339,7 @@ int lmpc_reserve(lmpc_handle* h, int32_t max_batch) {
 
 int lmpc_query_launch(const lmpc_handle* h, int32_t* lds_bytes_per_problem, int32_t* threads_per_problem) {
   if (!h) return LMPC_ERR_ARGUMENT;
-  if (lds_bytes_per_problem) *lds_bytes_per_problem = lmpc_lds_doubles(h->P.N, h->P.learning) * (int)sizeof(double);
+  if (lds_bytes_per_problem) *lds_bytes_per_problem = (int32_t)lmpc_lds_bytes(h->P.N, h->P.learning, h->P.S, 8);
   if (threads_per_problem) *threads_per_problem = 64;
   return LMPC_OK;
 }
@@ -346,7 +347,7 @@ int lmpc_query_launch(const lmpc_handle* h, int32_t* lds_bytes_per_problem, int3
 int lmpc_query_residency(lmpc_handle* h, int32_t* problems_per_cu) {
   if (!h || !problems_per_cu) return LMPC_ERR_ARGUMENT;
   HIP_TRY(h, hipSetDevice(h->device));
-  const size_t lds = (size_t)lmpc_lds_doubles(h->P.N, h->P.learning) * sizeof(double);
+  const size_t lds = lmpc_lds_bytes(h->P.N, h->P.learning, h->P.S, 8);
   int n = 0;
   const void* fn = pick_solve_fn(kq_for(h->P.N), ks_for(h->P.S));
   if (!fn) return fail(h, LMPC_ERR_UNSUPPORTED, "no kernel for this (N, num_ss_pts)");
@@ -400,8 +401,6 @@ int solve_batch_fp64_arrays(lmpc_handle* h, bool mixed, int32_t batch, const dou
       !vel_ref || !X_optm || !U_optm || !dU_optm || !status || !iters)
     return fail(h, LMPC_ERR_ARGUMENT, "lmpc_solve_batch: null pointer or negative batch");
   if (h->P.learning && (!ss_x || !ss_j)) return fail(h, LMPC_ERR_ARGUMENT, "learning=1 needs ss_x and ss_j");
-  if (mixed && h->P.learning)
-    return fail(h, LMPC_ERR_UNSUPPORTED, "mixed precision is built for the tracking problem: the safe-set terminal block needs fp64");
   if (batch == 0) return LMPC_OK;
   HIP_TRY(h, hipSetDevice(h->device));
   if ((size_t)batch > h->ws_cap) {
@@ -423,7 +422,7 @@ int solve_batch_fp64_arrays(lmpc_handle* h, bool mixed, int32_t batch, const dou
   if (!fn) return fail(h, LMPC_ERR_UNSUPPORTED, "no kernel for this (N, num_ss_pts)");
   solve_args a{};
   a.B = batch;
-  a.lds_bytes = (size_t)lmpc_lds_doubles(N, h->P.learning) * (mixed ? sizeof(float) : sizeof(double));
+  a.lds_bytes = lmpc_lds_bytes(N, h->P.learning, h->P.S, mixed ? 4 : 8);
   a.x_ic = x_ic; a.u_ic = u_ic; a.T_ref = T_ref; a.bl = bound_left; a.br = bound_right; a.vref = vel_ref;
   a.ss_x = h->P.learning ? ss_x : nullptr; a.ss_j = h->P.learning ? ss_j : nullptr;
   a.lam = h->P.learning ? convex_combi_optm : nullptr;
@@ -489,7 +488,7 @@ int lmpc_solve_batch_f32(lmpc_handle* h, int32_t batch, const float* x_ic, const
                      curvatures, h->ws_f32, (float*)nullptr, (float*)nullptr);
   HIP_TRY(h, hipGetLastError());
   if (h->timing) HIP_TRY(h, hipEventRecord(h->ev[1], h->stream));
-  const size_t lds = (size_t)lmpc_lds_doubles(N, 0) * sizeof(float);
+  const size_t lds = lmpc_lds_bytes(N, 0, 0, 4);
   HIP_TRY(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   lmpc_params P = h->P;
   int B = batch;

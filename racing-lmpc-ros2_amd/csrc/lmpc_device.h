@@ -34,11 +34,16 @@ struct lmpc_params {
 #define LMPC_STAGE_STRIDE 78
 #define LMPC_KNOT_STRIDE 36
 #define LMPC_TAIL_DOUBLES 320
-#define LMPC_TAIL_DOUBLES_LMPC 552  // + terminal-block scratch (PT, F_B^-1, W_A, U_A, factor of C_A, ...; lmpc_solve_kernel.hip TL_*)
+// learning: the terminal region behind the records -- always fp64 cells, whatever the records' type: the terminal-block
+// scratch (lmpc_solve_kernel.hip TL_*) and the (centred) safe-set points [6][64 KS], KS = 2 up to 128 points, 3 up to 192
+#define LMPC_TERM_CELLS 236
 #define LMPC_LIN_RECORD 54  // per stage in the linearisation workspace: ABt[8][6] | g[6]
 
-static inline int lmpc_lds_doubles(int N, int learning) {
-  return (N - 1) * LMPC_STAGE_STRIDE + N * LMPC_KNOT_STRIDE + (learning ? LMPC_TAIL_DOUBLES_LMPC : LMPC_TAIL_DOUBLES);
+// LDS bytes per problem; real_bytes = 8 (fp64 records) or 4 (fp32 records: single-precision and mixed solves)
+static inline size_t lmpc_lds_bytes(int N, int learning, int S, int real_bytes) {
+  const int ks = !learning ? 0 : (S <= 128 ? 2 : 3);
+  const size_t records = (size_t)((N - 1) * LMPC_STAGE_STRIDE + N * LMPC_KNOT_STRIDE + LMPC_TAIL_DOUBLES) * (size_t)real_bytes;
+  return records + (learning ? (size_t)(LMPC_TERM_CELLS + 6 * 64 * ks) * 8 : 0);
 }
 
 #endif

@@ -101,21 +101,24 @@ struct Prof {};
 #define CT_ZERO 40  // a 0.0 entry: coefficient slot for "no term"
 #define CT_E 41     // 2 * convex_hull_slack (LMPC)
 // LMPC extension of the tail (only allocated when learning): terminal-block quantities (see term_factor_u)
-#define TL_PT 320    // PT[6][6]: terminal cost-to-go contributed by the safe-set block
-#define TL_TG 356    // terminal gradient contribution  E eps + pT
-#define TL_EPS 362   // eps = (x_T - ss0) - (SS - ss0 1') lambda
-#define TL_FB 368    // F_B^-1 [6][6], F_B = E^-1 + U_B Th_B^-1 U_B' (the points eliminated through 1/theta)
-#define TL_WA 404    // W_A = F_B^-1 U_A, column a at +6a
-#define TL_UA 440    // u of the explicit points, point a at +6a
-#define TL_LC 476    // Cholesky factor of C_A = Theta_A + U_A'F_B^-1 U_A, [i][k] (k < i); the RECIPROCAL pivots on the diagonal
-#define TL_X1 512    // C_A^-1 (1_A - W_A'a_B)
-#define TL_G 518     // g = E U M^-1 1
-#define TL_AB 524    // a_B = U_B Th_B^-1 1
-#define TL_RA 530    // right-hand side of the explicit points (written by their owner lanes)
-#define TL_THA 536   // theta of the explicit points
-#define TL_XA 542    // their step d lambda_A (read back by the owner lanes)
-#define TL_S11 548   // s11 = 1'M^-1 1
-#define MA_MAX 6       // explicit points at most (the smallest theta below tau)
+// (offsets in `treal` cells from the start of the terminal region, which follows the real-typed records and tail)
+#define TL_PT 0      // PT[6][6]: terminal cost-to-go contributed by the safe-set block
+#define TL_TG 36     // terminal gradient contribution  E eps + pT
+#define TL_EPS 42    // eps = (x_T - ss0) - (SS - ss0 1') lambda
+#define TL_FB 48     // F_B^-1 [6][6], F_B = E^-1 + U_B Th_B^-1 U_B' (the points eliminated through 1/theta)
+#define TL_WA 84     // W_A = F_B^-1 U_A, column a at +6a
+#define TL_UA 120    // u of the explicit points, point a at +6a
+#define TL_LC 156    // Cholesky factor of C_A = Theta_A + U_A'F_B^-1 U_A, [i][k] (k < i); the RECIPROCAL pivots on the diagonal
+#define TL_X1 192    // C_A^-1 (1_A - W_A'a_B)
+#define TL_G 198     // g = E U M^-1 1
+#define TL_AB 204    // a_B = U_B Th_B^-1 1
+#define TL_RA 210    // right-hand side of the explicit points (written by their owner lanes)
+#define TL_THA 216   // theta of the explicit points
+#define TL_XA 222    // their step d lambda_A (read back by the owner lanes)
+#define TL_S11 228   // s11 = 1'M^-1 1
+#define TL_E 230     // E = 2 convex_hull_slack (exact, whatever `real` is)
+#define TL_UL 236    // the (centred) safe-set points, [6][64 KS]
+#define MA_MAX 4       // explicit points at most (the smallest theta below tau); supports of 1-3 points are what occurs
 #define TAU_REL 1e-5   // tau = TAU_REL * max_j u_j'E u_j: cond(F_B) <= ~1e5 whatever the iteration does
 #define STALL_MU 1e-9  // complementarity below which a step that does not lower it ends the solve
 #define F_UP 1
@@ -503,7 +506,7 @@ __device__ __forceinline__ void term_factor_u(real* T, int lane, const real (&F)
       for (int bq = 0; bq <= a; ++bq) Lc[a * 6 + bq] = T[TL_LC + a * 6 + bq];
       jit += Lc[a * 6 + a];
     }
-    jit *= real(1e-13);
+    jit *= real(sizeof(real) == 4 ? 1e-6 : 1e-13);
 #pragma unroll
     for (int a = 0; a < MA_MAX; ++a) {
 #pragma unroll
@@ -634,7 +637,13 @@ template <typename real, int KS>
 struct SimplexRows {
   bool on[KS];
   int aidx[KS];  // slot of the point among the explicit ones of this iteration, -1: eliminated through 1/theta
-  real lm[KS], t[KS], l[KS], p[KS], j[KS], u[KS][6], dl[KS];
+  real lm[KS], t[KS], l[KS], p[KS], j[KS], dl[KS];
+  const real* ul;  // the (centred) points in LDS, component k of point j at ul[k * 64 KS + j]: read-only after the load, 36
+                   // registers (KS = 3) the iteration's row state needs more -- consecutive lanes read consecutive cells
+  __device__ __forceinline__ void load_u(int q, int lane, real (&u)[6]) const {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) u[k] = ul[k * 64 * KS + lane + 64 * q];
+  }
   real ss0[6];
   real r1;   // 1 - 1'lambda
   real tau;  // theta below which a point is kept explicit
@@ -685,8 +694,8 @@ __device__ __forceinline__ real qz_entry(const real* ct, bool terminal, int r, i
 // cancellation happens inside Phi, before the multiplication by P.  It costs a second pair of 8x8 products (8-term,
 // Phi has no identity block), so the iteration uses it only once mu <= JOSEPH_MU: about two factorisations per solve.
 #define JOSEPH_MU 1e-8
-template <bool HAS_PT, bool JOSEPH, typename real>
-__device__ void riccati_factor(const Lds<real>& L, int lane, const real* PT) {
+template <bool HAS_PT, bool JOSEPH, typename real, typename ptreal>
+__device__ void riccati_factor(const Lds<real>& L, int lane, const ptreal* PT) {
   const int N = L.N, r = lane >> 3, c = lane & 7;
   real* T = L.tail();
   real* MP = T + TL_P;
@@ -702,7 +711,7 @@ __device__ void riccati_factor(const Lds<real>& L, int lane, const real* PT) {
     const real th = kn[KN_R0 + r] + (r == 1 ? kn[KN_EY] : real(0));
     if (diag) e += th;
     // LMPC: safe-set block condensed onto x_T; its upper triangle is the block (see the symmetry note in the loop)
-    if (HAS_PT && r < 6 && c < 6) e += PT[r <= c ? r * 6 + c : c * 6 + r];
+    if (HAS_PT && r < 6 && c < 6) e += real(PT[r <= c ? r * 6 + c : c * 6 + r]);
     pown = e;
     MP[r * MROW + c] = e;
   }
@@ -1035,6 +1044,7 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
   const int lane = threadIdx.x;
   const int N = P.N, NS = N - 1;
   typedef typename vec2<real>::type real2;
+  typedef double treal;  // the safe-set block (simplex rows, terminal elimination) is always carried in fp64
   typedef ipm_limits<real> lim;
   const real inf = real(INFINITY), marg = real(P.marg), qsig = real(P.qsig), tol = lim::tol(P.tol);
   // single precision carries the abscissa relative to x_ic[0] (the QP is invariant to the shift: A(:, s) = e_s)
@@ -1043,6 +1053,9 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
   real* T = L.tail();
   real* ct = T + TL_CT;
   real* KN0 = L.kn(0);
+  // terminal region (learning only): treal cells behind the records; 16-byte aligned because every record size is even
+  treal* const TT = reinterpret_cast<treal*>(T + LMPC_TAIL_DOUBLES);
+  const treal tinf = treal(INFINITY);
   PT_DECL
 
   // ---------------- load: linearisation records, per-knot data, constant tables ----------------
@@ -1163,21 +1176,24 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
   // (racing_mpc.cpp:484-504).  The points are centred on the first one (valid because 1'lambda = 1):
   // all sums below then run over O(1) offsets instead of absolute abscissae.
   const int S = P.S;
-  SimplexRows<real, KS> sx;
+  SimplexRows<treal, KS> sx;
   if constexpr (KS > 0) {
+    treal* const UL = TT + TL_UL;
+    sx.ul = UL;
+    if (lane < 6) TT[TL_E + lane] = treal(P.chs2[lane]);
     io c0[6];  // the differences are formed in the storage precision, the abscissa relative to the shift
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
       c0[k] = ss_x[((size_t)k * S) * B + b];
-      sx.ss0[k] = real(k == 0 ? c0[k] - s_shift : c0[k]);
+      sx.ss0[k] = treal(k == 0 ? c0[k] - s_shift : c0[k]);
     }
 #pragma unroll
     for (int q = 0; q < KS; ++q) {
       const int j = lane + 64 * q;
       sx.on[q] = j < S;
 #pragma unroll
-      for (int k = 0; k < 6; ++k) sx.u[q][k] = sx.on[q] ? real(ss_x[((size_t)k * S + j) * B + b] - c0[k]) : real(0);
-      sx.j[q] = sx.on[q] ? real(ss_j[(size_t)j * B + b]) : real(0);
+      for (int k = 0; k < 6; ++k) UL[k * 64 * KS + j] = sx.on[q] ? treal(ss_x[((size_t)k * S + j) * B + b] - c0[k]) : treal(0);
+      sx.j[q] = sx.on[q] ? treal(ss_j[(size_t)j * B + b]) : treal(0);
       sx.lm[q] = sx.on[q] ? 1.0 / S : 0.0;
       sx.t[q] = sx.on[q] ? 1.0 / S : 1.0;
       sx.l[q] = 0.0;
@@ -1186,15 +1202,17 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
       sx.aidx[q] = -1;
       m_rows += sx.on[q] ? 1.0 : 0.0;
     }
-    real umax = 0.0;  // largest u_j'E u_j of the (centred) points
+    wave_fence();
+    treal umax = 0.0;  // largest u_j'E u_j of the (centred) points
 #pragma unroll
     for (int q = 0; q < KS; ++q) {
-      real v = 0.0;
+      treal uq[6], v = 0.0;
+      sx.load_u(q, lane, uq);
 #pragma unroll
-      for (int k = 0; k < 6; ++k) v += real(P.chs2[k]) * sx.u[q][k] * sx.u[q][k];
+      for (int k = 0; k < 6; ++k) v += treal(P.chs2[k]) * uq[k] * uq[k];
       umax = fmax(umax, v);
     }
-    sx.tau = uni(real(TAU_REL) * wave_max(umax));
+    sx.tau = uni(treal(TAU_REL) * wave_max(umax));
     sx.m = 0;
   }
   const real m_tot = wave_sum(m_rows);
@@ -1227,25 +1245,28 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
     lds[o_csig(q)] = 0.0;
   }
   if constexpr (KS > 0) {  // lambda frozen at 1/S: terminal cost eps'D eps only
-    if (lane < 36) T[TL_PT + lane] = (lane % 7 == 0) ? ct[CT_E + lane / 7] : 0.0;
+    if (lane < 36) TT[TL_PT + lane] = (lane % 7 == 0) ? TT[TL_E + lane / 7] : treal(0);
   }
   wave_sync();
-  riccati_factor<(KS > 0), false>(L, lane, T + TL_PT);
+  riccati_factor<(KS > 0), false>(L, lane, TT + TL_PT);
   feedback_rollout(L, lane);
   if constexpr (KS > 0) {
-    real ul[6] = {0, 0, 0, 0, 0, 0};
+    treal ul[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
-    for (int q = 0; q < KS; ++q)
+    for (int q = 0; q < KS; ++q) {
+      treal uq[6];
+      sx.load_u(q, lane, uq);
 #pragma unroll
-      for (int k = 0; k < 6; ++k) ul[k] += sx.u[q][k] * sx.lm[q];
+      for (int k = 0; k < 6; ++k) ul[k] += uq[k] * sx.lm[q];
+    }
     wave_sum_split<6>(ul, lane);
     if (lane < 6) {
-      real e = 0.0;
+      treal e = 0.0;
 #pragma unroll
       for (int k = 0; k < 6; ++k)
-        if (k == lane) e = (L.kn(N - 1)[k] - sx.ss0[k]) - ul[k];
-      T[TL_EPS + lane] = e;
-      T[TL_TG + lane] = ct[CT_E + lane] * e;
+        if (k == lane) e = (treal(L.kn(N - 1)[k]) - sx.ss0[k]) - ul[k];
+      TT[TL_EPS + lane] = e;
+      TT[TL_TG + lane] = TT[TL_E + lane] * e;
     }
     wave_sync();
   }
@@ -1286,21 +1307,21 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
       }
       if constexpr (KS > 0) {
         // ---- which points stay explicit this iteration: the (at most MA_MAX) smallest theta below tau ----
-        real thq[KS];
+        treal thq[KS];
 #pragma unroll
         for (int q = 0; q < KS; ++q) {
-          thq[q] = sx.on[q] ? sx.l[q] * frcp(sx.t[q]) : inf;
+          thq[q] = sx.on[q] ? sx.l[q] * frcp(sx.t[q]) : tinf;
           sx.aidx[q] = -1;
         }
-        if (lane < 6 * MA_MAX) T[TL_UA + lane] = 0.0;            // unused slots: u = 0, theta = 1, rhs = 0
+        if (lane < 6 * MA_MAX) TT[TL_UA + lane] = 0.0;            // unused slots: u = 0, theta = 1, rhs = 0
         if (lane < MA_MAX) {
-          T[TL_THA + lane] = 1.0;
-          T[TL_RA + lane] = 0.0;
+          TT[TL_THA + lane] = 1.0;
+          TT[TL_RA + lane] = 0.0;
         }
         wave_fence();
         int m = 0;
         for (int a = 0; a < MA_MAX; ++a) {
-          real cand = inf;
+          treal cand = tinf;
           int cq = 0;
 #pragma unroll
           for (int q = 0; q < KS; ++q) {
@@ -1308,17 +1329,19 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
             cand = better ? thq[q] : cand;
             cq = better ? q : cq;
           }
-          const real best = wave_min(cand);
-          if (!(best < inf)) break;
+          const treal best = wave_min(cand);
+          if (!(best < tinf)) break;
           const int owner = __ffsll((long long)__ballot(cand == best)) - 1;  // the lowest lane holding the minimum
           if (lane == owner) {
 #pragma unroll
             for (int q = 0; q < KS; ++q)
               if (q == cq) {
                 sx.aidx[q] = a;
+                treal uq[6];
+                sx.load_u(q, lane, uq);
 #pragma unroll
-                for (int k = 0; k < 6; ++k) T[TL_UA + a * 6 + k] = sx.u[q][k];
-                T[TL_THA + a] = thq[q];
+                for (int k = 0; k < 6; ++k) TT[TL_UA + a * 6 + k] = uq[k];
+                TT[TL_THA + a] = thq[q];
               }
           }
           wave_fence();
@@ -1327,30 +1350,32 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
         sx.m = m;
         wave_fence();
         // ---- sums over the eliminated points: T_B (21), a_B (6), s_B; and over all points: U lambda (6), sum lambda ----
-        real tt[21], av[14];
+        treal tt[21], av[14];
 #pragma unroll
         for (int k = 0; k < 21; ++k) tt[k] = 0.0;
 #pragma unroll
         for (int k = 0; k < 14; ++k) av[k] = 0.0;
 #pragma unroll
         for (int q = 0; q < KS; ++q) {
-          const real on = sx.on[q] ? 1.0 : 0.0;
-          const real itf = (sx.on[q] && sx.aidx[q] < 0) ? frcp(thq[q]) : real(0);
-          musum += on * sx.l[q] * sx.t[q];
-          rdl = fmax(rdl, on * fabs(-sx.lm[q] + sx.t[q]));
+          const treal on = sx.on[q] ? 1.0 : 0.0;
+          const treal itf = (sx.on[q] && sx.aidx[q] < 0) ? frcp(thq[q]) : treal(0);
+          musum += real(on * sx.l[q] * sx.t[q]);
+          rdl = fmax(rdl, real(on * fabs(-sx.lm[q] + sx.t[q])));
           int n = 0;
+          treal uq[6];
+          sx.load_u(q, lane, uq);
 #pragma unroll
           for (int r = 0; r < 6; ++r) {
 #pragma unroll
-            for (int c = r; c < 6; ++c) tt[n++] += sx.u[q][r] * sx.u[q][c] * itf;
-            av[r] += sx.u[q][r] * itf;
-            av[7 + r] += sx.u[q][r] * sx.lm[q];
+            for (int c = r; c < 6; ++c) tt[n++] += uq[r] * uq[c] * itf;
+            av[r] += uq[r] * itf;
+            av[7 + r] += uq[r] * sx.lm[q];
           }
           av[6] += itf;
           av[13] += sx.lm[q];
         }
         {  // 35 sums: 32 through the splitting butterfly, the last three on their own
-          real red[32], red3[3] = {av[11], av[12], av[13]};
+          treal red[32], red3[3] = {av[11], av[12], av[13]};
 #pragma unroll
           for (int k = 0; k < 21; ++k) red[k] = tt[k];
 #pragma unroll
@@ -1367,7 +1392,7 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
         }
         sx.r1 = 1.0 - av[13];
         {
-          real F[36], aB[6];
+          treal F[36], aB[6];
           int n = 0;
 #pragma unroll
           for (int r = 0; r < 6; ++r) {
@@ -1380,15 +1405,15 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
             aB[r] = av[r];
           }
 #pragma unroll
-          for (int k = 0; k < 6; ++k) F[k * 6 + k] += 1.0 / ct[CT_E + k];
-          term_factor_u(T, lane, F, aB, av[6], m);
+          for (int k = 0; k < 6; ++k) F[k * 6 + k] += 1.0 / TT[TL_E + k];
+          term_factor_u(TT, lane, F, aB, av[6], m);
         }
         if (lane < 6) {
-          real e = 0.0;
+          treal e = 0.0;
 #pragma unroll
           for (int k = 0; k < 6; ++k)
-            if (k == lane) e = (L.kn(N - 1)[k] - sx.ss0[k]) - av[7 + k];
-          T[TL_EPS + lane] = e;
+            if (k == lane) e = (treal(L.kn(N - 1)[k]) - sx.ss0[k]) - av[7 + k];
+          TT[TL_EPS + lane] = e;
         }
         wave_fence();
       }
@@ -1424,18 +1449,18 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
       wave_sync();
       PT_MARK(2)
       if (sizeof(real) == 8 && mu <= real(JOSEPH_MU))  // (single precision stops at mu ~ 2e-6)
-        riccati_factor<(KS > 0), (sizeof(real) == 8)>(L, lane, T + TL_PT);
+        riccati_factor<(KS > 0), (sizeof(real) == 8)>(L, lane, TT + TL_PT);
       else
-        riccati_factor<(KS > 0), false>(L, lane, T + TL_PT);
+        riccati_factor<(KS > 0), false>(L, lane, TT + TL_PT);
       PT_MARK(3)
     }
 
     real sigc = 0.0, alpha = 1.0, dsigma = 0.0;
     bool numerics_failed = false, stalled = false;
-    real eeps[6] = {0, 0, 0, 0, 0, 0};  // E eps of this iterate (safe-set block), in scalar registers
+    treal eeps[6] = {0, 0, 0, 0, 0, 0};  // E eps of this iterate (safe-set block), in scalar registers
     if constexpr (KS > 0) {
 #pragma unroll
-      for (int k = 0; k < 6; ++k) eeps[k] = uni(ct[CT_E + k] * T[TL_EPS + k]);
+      for (int k = 0; k < 6; ++k) eeps[k] = uni(TT[TL_E + k] * TT[TL_EPS + k]);
     }
     real d_val[KQ];
     const int npass = ipm ? 2 : 1;
@@ -1446,29 +1471,30 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
       if constexpr (KS > 0) {
         if (ipm) {
           // right-hand side r_j = -bl_j (dx = 0): sums over the eliminated points, the explicit ones through LDS
-          real bs[7] = {0, 0, 0, 0, 0, 0, 0};
+          treal bs[7] = {0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
           for (int q = 0; q < KS; ++q) {
-            real itf;
-            const real rj = sx.on[q] ? -simplex_bl(sx.lm[q], sx.t[q], sx.l[q], sx.p[q], sx.j[q], sx.u[q], smu, pm, eeps, itf) : real(0);
-            if (sx.aidx[q] >= 0) T[TL_RA + sx.aidx[q]] = rj;
-            const real w = (sx.on[q] && sx.aidx[q] < 0) ? rj * itf : real(0);
+            treal itf, uq[6];
+            sx.load_u(q, lane, uq);
+            const treal rj = sx.on[q] ? -simplex_bl(sx.lm[q], sx.t[q], sx.l[q], sx.p[q], sx.j[q], uq, treal(smu), treal(pm), eeps, itf) : treal(0);
+            if (sx.aidx[q] >= 0) TT[TL_RA + sx.aidx[q]] = rj;
+            const treal w = (sx.on[q] && sx.aidx[q] < 0) ? rj * itf : treal(0);
             bs[6] += w;
 #pragma unroll
-            for (int k = 0; k < 6; ++k) bs[k] += sx.u[q][k] * w;
+            for (int k = 0; k < 6; ++k) bs[k] += uq[k] * w;
           }
           wave_sum_split<7>(bs, lane);
           wave_fence();
-          real beta[6], h[6], nu;
+          treal beta[6], h[6], nu;
 #pragma unroll
           for (int k = 0; k < 6; ++k) beta[k] = bs[k];
-          term_solve_u(T, lane, sx.m, beta, bs[6], sx.r1, h, nu);
+          term_solve_u(TT, lane, sx.m, beta, bs[6], sx.r1, h, nu);
           if (lane < 6) {  // terminal gradient onto x_T: E eps + pT, pT = -h
-            real tg = 0.0;
+            treal tg = 0.0;
 #pragma unroll
             for (int k = 0; k < 6; ++k)
-              if (k == lane) tg = ct[CT_E + k] * T[TL_EPS + k] - h[k];
-            T[TL_TG + lane] = tg;
+              if (k == lane) tg = TT[TL_E + k] * TT[TL_EPS + k] - h[k];
+            TT[TL_TG + lane] = tg;
           }
           wave_fence();
         }
@@ -1510,7 +1536,7 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
       }
       if constexpr (KS > 0) {  // terminal gradient of the safe-set block onto x_T (lanes 0..5 != EY lanes' cells)
         wave_sync();
-        if (lane < 6) L.kn(N - 1)[KN_R0 + lane] += T[TL_TG + lane];
+        if (lane < 6) L.kn(N - 1)[KN_R0 + lane] += real(TT[TL_TG + lane]);
       }
       wave_sync();
       // ======== Newton step: predictor together with the Schur vector, then the corrector ========
@@ -1557,46 +1583,48 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
         // r_j = u_j'E dx_T - bl_j;  d lambda_j = (r_j - nu - u_j'h)/theta_j for the eliminated points, the explicit
         // ones from the small dense solve
         const real* knT = L.kn(N - 1);
-        real e[6], gs[7] = {0, 0, 0, 0, 0, 0, 0}, rj[KS], itfq[KS];
+        treal e[6], gs[7] = {0, 0, 0, 0, 0, 0, 0}, rj[KS], itfq[KS];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) e[k] = ct[CT_E + k] * (knT[KN_R0 + k] + dsigma * knT[KN_R1 + k]);
+        for (int k = 0; k < 6; ++k) e[k] = TT[TL_E + k] * treal(knT[KN_R0 + k] + dsigma * knT[KN_R1 + k]);
 #pragma unroll
         for (int q = 0; q < KS; ++q) {
-          real itf;
-          real r = -simplex_bl(sx.lm[q], sx.t[q], sx.l[q], sx.p[q], sx.j[q], sx.u[q], smu, pm, eeps, itf);
+          treal itf, uq[6];
+          sx.load_u(q, lane, uq);
+          treal r = -simplex_bl(sx.lm[q], sx.t[q], sx.l[q], sx.p[q], sx.j[q], uq, treal(smu), treal(pm), eeps, itf);
 #pragma unroll
-          for (int k = 0; k < 6; ++k) r += sx.u[q][k] * e[k];
+          for (int k = 0; k < 6; ++k) r += uq[k] * e[k];
           r = sx.on[q] ? r : 0.0;
           rj[q] = r;
           itfq[q] = itf;
-          if (sx.aidx[q] >= 0) T[TL_RA + sx.aidx[q]] = r;
-          const real w = (sx.on[q] && sx.aidx[q] < 0) ? r * itf : real(0);
+          if (sx.aidx[q] >= 0) TT[TL_RA + sx.aidx[q]] = r;
+          const treal w = (sx.on[q] && sx.aidx[q] < 0) ? r * itf : treal(0);
           gs[6] += w;
 #pragma unroll
-          for (int k = 0; k < 6; ++k) gs[k] += sx.u[q][k] * w;
+          for (int k = 0; k < 6; ++k) gs[k] += uq[k] * w;
         }
         wave_sum_split<7>(gs, lane);
         wave_fence();
-        real beta[6], h[6], nu;
+        treal beta[6], h[6], nu;
 #pragma unroll
         for (int k = 0; k < 6; ++k) beta[k] = gs[k];
-        term_solve_u(T, lane, sx.m, beta, gs[6], sx.r1, h, nu);
+        term_solve_u(TT, lane, sx.m, beta, gs[6], sx.r1, h, nu);
 #pragma unroll
         for (int q = 0; q < KS; ++q) {
-          real uh = 0.0;
+          treal uh = 0.0, uq[6];
+          sx.load_u(q, lane, uq);
 #pragma unroll
-          for (int k = 0; k < 6; ++k) uh += sx.u[q][k] * h[k];
-          const real dB = (rj[q] - nu - uh) * itfq[q];
-          const real dA = T[TL_XA + (sx.aidx[q] >= 0 ? sx.aidx[q] : 0)];
-          sx.dl[q] = sx.on[q] ? (sx.aidx[q] >= 0 ? dA : dB) : real(0);
+          for (int k = 0; k < 6; ++k) uh += uq[k] * h[k];
+          const treal dB = (rj[q] - nu - uh) * itfq[q];
+          const treal dA = TT[TL_XA + (sx.aidx[q] >= 0 ? sx.aidx[q] : 0)];
+          sx.dl[q] = sx.on[q] ? (sx.aidx[q] >= 0 ? dA : dB) : treal(0);
         }
       }
       // ======== row steps; largest feasible step as 1 / max(1, max -dt/t, max -dlam/lam) ========
-      auto row_step = [&](bool on, real t, real lam, real pprod, real rd, real cdy, real& dt_, real& dl_,
-                          real& it_) {
+      auto row_step = [&](bool on, treal t, treal lam, treal pprod, treal rd, treal cdy, treal& dt_, treal& dl_,
+                          treal& it_) {  // (the simplex rows: always fp64)
         it_ = frcp(t);
         dt_ = on ? (-rd - cdy) : 0.0;
-        dl_ = on ? (-lam + (smu - pm * pprod) * it_ - lam * it_ * dt_) : 0.0;
+        dl_ = on ? (-lam + (treal(smu) - treal(pm) * pprod) * it_ - lam * it_ * dt_) : 0.0;
       };
       real dtu[KQ], dlu[KQ], dtl[KQ], dll[KQ];
       real rmax = 1.0;
@@ -1623,9 +1651,9 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
       if constexpr (KS > 0) {
 #pragma unroll
         for (int q = 0; q < KS; ++q) {
-          real dt_, dl_, it_;
+          treal dt_, dl_, it_;
           row_step(sx.on[q], sx.t[q], sx.l[q], sx.p[q], -sx.lm[q] + sx.t[q], -sx.dl[q], dt_, dl_, it_);
-          rmax = fmax(rmax, fmax(-dt_ * it_, -dl_ * frcp(fmax(sx.l[q], lim::tiny))));
+          rmax = fmax(rmax, real(fmax(-dt_ * it_, -dl_ * frcp(fmax(sx.l[q], treal(1e-300))))));
         }
       }
       rmax = wave_max(finite_step ? rmax : inf);
@@ -1655,16 +1683,16 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
       if constexpr (KS > 0) {
 #pragma unroll
         for (int q = 0; q < KS; ++q) {
-          real dt_, dl_, it_;
+          treal dt_, dl_, it_;
           row_step(sx.on[q], sx.t[q], sx.l[q], sx.p[q], -sx.lm[q] + sx.t[q], -sx.dl[q], dt_, dl_, it_);
           if (pass == 0) {
-            sacc += sx.on[q] ? (sx.t[q] + amax * dt_) * (sx.l[q] + amax * dl_) : 0.0;
+            sacc += sx.on[q] ? real((sx.t[q] + treal(amax) * dt_) * (sx.l[q] + treal(amax) * dl_)) : real(0);
             sx.p[q] = dt_ * dl_;
           } else {
-            sx.t[q] += alpha * dt_;
-            sx.l[q] += alpha * dl_;
-            sx.lm[q] += alpha * sx.dl[q];
-            sacc += sx.on[q] ? sx.t[q] * sx.l[q] : 0.0;
+            sx.t[q] += treal(alpha) * dt_;
+            sx.l[q] += treal(alpha) * dl_;
+            sx.lm[q] += treal(alpha) * sx.dl[q];
+            sacc += sx.on[q] ? real(sx.t[q] * sx.l[q]) : real(0);
           }
         }
       }
@@ -1730,7 +1758,7 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
       sigma = 0.0;
       if constexpr (KS > 0) {
 #pragma unroll
-        for (int q = 0; q < KS; ++q) sx.l[q] = sx.on[q] ? mu0 / sx.t[q] : 0.0;
+        for (int q = 0; q < KS; ++q) sx.l[q] = sx.on[q] ? treal(mu0) / sx.t[q] : treal(0);
       }
     }
   }
@@ -1809,3 +1837,5 @@ LMPC_INSTANTIATE(float, 4, 0, double)
 LMPC_INSTANTIATE(float, 7, 0, double)
 LMPC_INSTANTIATE(float, 11, 0, double)  // iac_car_tracking_mpc.param.yaml ships N = 80
 LMPC_INSTANTIATE(float, 14, 0, double)
+LMPC_INSTANTIATE(float, 4, 2, double)  // the learning problem, N <= 23 (BASELINE configs[4])
+LMPC_INSTANTIATE(float, 4, 3, double)

@@ -103,21 +103,18 @@ def test_headline_batch_status_parity(pkg):
 
 # ---- the IAC learning controller as shipped: iac_car_lmpc.param.yaml, n = 60 (tests/golden/make_golden_iac_lmpc.py) ----
 def _iac_lmpc_check(out, g, who):
-    """Honest statuses: a problem reported optimal is within the contract of the dense optimum (twice the tracking bound
-    on strictly complementary problems -- the simplex rows carry a proximal floor, csrc TH_L_MIN -- the degenerate bound
-    otherwise); the iteration may run out on a few (the floor damps the simplex weights' steps: slow on the IAC's hull
-    slack weights [200, 20, 2, 200, 2, 20]), and those say so and are still within 1e-4."""
+    """Every problem solved and within the contract of the dense optimum.  (With the simplex rows' weight floored inside
+    the Newton matrix -- round 1 -- these problems stopped 1e-3 .. 1e-2 away with status 0; the two-level elimination of the
+    terminal block reaches 1e-12 on them.)"""
     from parity import per_problem_err
-    from tolerances import TOL_DEGENERATE, TOL_XU
+    from tolerances import TOL_XU
     e, ed = per_problem_err(out, g)
     st = np.asarray(out["status"])
-    ok = st == 0
-    strict = (g["margin"] >= Q.DEGENERATE_MARGIN) & g["certified"]
-    assert ok.sum() >= 5, (who, st)
-    assert (st[~ok] == 1).all() and e[~ok].max(initial=0.0) < 1e-4, (who, st, e)
-    assert e[ok & strict].max(initial=0.0) < 2 * TOL_XU and e[ok & ~strict].max(initial=0.0) < TOL_DEGENERATE, (who, e, st)
-    lam = np.asarray(out["convex_combi_optm"])[:, ok]
+    assert (st == 0).all(), (who, st)
+    assert e.max() < TOL_XU and ed.max() < 40 * TOL_XU, (who, e, ed)      # degenerate or not: all of them
+    lam = np.asarray(out["convex_combi_optm"])
     assert np.abs(lam.sum(0) - 1.0).max() < 1e-9 and lam.min() > -1e-12
+    assert np.asarray(out["iters"]).max() <= 20
 
 
 def test_twin_on_the_iac_learning_controller_golden(golden):
