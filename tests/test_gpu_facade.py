@@ -74,3 +74,47 @@ def test_c_abi_from_plain_cpp_without_python_buffers():
     f = r.stdout.split()
     rate, solved = float(f[f.index("solves/s") - 1]), float(f[f.index("solved") + 1])
     assert solved > 0.99 and rate > 1e6, r.stdout
+
+
+@pytest.mark.parametrize("N,mode", [(20, "continuous"), (20, "step"), (60, "continuous")])
+def test_node_core_drives_two_laps_of_the_reference_barc_track(N, mode):
+    """RacingMPCNodeCore::step = RacingMPCNode::on_step_timer without ROS 2 (racing_mpc_node.cpp:150-477): global pose in,
+    actuation out, first solve by the full-dynamics controller, first QP solve discarded (jit), plan shifted every period.
+    Closed loop with a host plant on 15_barc_optm.txt at velocity_profile_scale 0.9, both step modes, and at the shipped
+    horizon N = 60 (barc_tracking_mpc.param.yaml)."""
+    import re
+    exe = LIB / "test_node_core"
+    assert exe.exists(), "run __graft_entry__.build() first"
+    track = ROOT / "tests" / "golden" / "barc_track" / "15_barc_optm.txt"
+    r = subprocess.run([str(exe), str(track), str(N), "2.1", mode], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "PASS" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+    m = re.search(r"laps ([\d.]+) time ([\d.]+) published (\d+) failed (\d+) .* worst_excess (-?[\d.]+) mean_step_ms ([\d.]+)", r.stdout)
+    laps, t, published, failed, excess, step_ms = float(m[1]), float(m[2]), int(m[3]), int(m[4]), float(m[5]), float(m[6])
+    assert laps >= 2.1 and failed <= published // 100 and excess < 0.02
+    assert step_ms < 25.0                      # one controller inside its 25 ms period, host staging included
+    print(f"N={N} {mode}: {laps:.2f} laps in {t:.2f} s, {published} steps, {failed} failed, {step_ms:.2f} ms per step")
+
+
+def test_host_model_matches_the_device_model(pkg):
+    """single_track_model.cpp (what the node core steps on the host) against the device kernels: the cold-start rollout of
+    lmpc_prepare_batch is the same sequence of discrete_dynamics calls."""
+    import ctypes as C
+    import torch
+    so = C.CDLL(str(LIB / "liblmpc_racing_mpc.so"))
+    fn = so.lmpc_host_discrete_dynamics
+    capi = __import__("importlib").import_module(pkg.__name__ + ".capi")
+    veh = capi._fill(capi.CVehicle(), dict(pkg.presets.barc_vehicle()))
+    solver = pkg.Solver(pkg.presets.barc_tracking_mpc(12), pkg.presets.barc_vehicle(), device=0)
+    tr = pkg.workloads.synthetic_track("barc")
+    rng = np.random.default_rng(4)
+    x0 = np.array([rng.uniform(0, tr["L"], 8), rng.uniform(-0.2, 0.2, 8), rng.normal(0, 0.05, 8), rng.uniform(0.6, 3.0, 8),
+                   rng.normal(0, 0.05, 8), rng.normal(0, 0.3, 8)])
+    inp = solver.prepare(tr, x0, 0.025)
+    X, K = inp["X_ref"].cpu().numpy(), inp["curvatures"].cpu().numpy()
+    u = np.array([1e-9, 1e-9])
+    for b in range(8):
+        for i in range(11):
+            xn = np.zeros(6)
+            fn(C.byref(veh), X[:, i, b].copy().ctypes.data_as(C.c_void_p), u.ctypes.data_as(C.c_void_p), C.c_double(K[i, b]),
+               C.c_double(0.025), xn.ctypes.data_as(C.c_void_p))
+            assert np.abs(xn - X[:, i + 1, b]).max() <= 1e-12 * max(1.0, np.abs(xn).max()), (b, i)

@@ -718,12 +718,13 @@ def test_mixed_precision_solve_on_the_iac_problem(pkg, golden):
     e = np.abs((om["X_optm"] - o64["X_optm"]) / P.SCALE_X[:, None, None]).max(axis=(0, 1))[ok]
     assert np.median(e) < 1e-4 and np.percentile(e, 99) < 5e-3 and e.max() < 5e-2
 
-    lm = pkg.Solver(pkg.presets.barc_lmpc(20, 3), pkg.presets.barc_vehicle(), device=0)
+    # the learning problem is served up to N = 23 (tests/test_gpu_mixed_lmpc.py); its long horizons have no mixed kernel
+    lm = pkg.Solver(pkg.presets.barc_lmpc(40, 3), pkg.presets.barc_vehicle(), device=0)
     lm.set_safe_set(LS.load_laps(), LS.L_BARC_SS)
-    g = golden("qp_barc_lmpc_n20")
-    ss_x, ss_j, _ = lm.ss_query(g["query"])
-    with pytest.raises(pkg.LmpcError, match="tracking problem"):
-        lm.solve(g, ss_x=ss_x, ss_j=ss_j, mixed=True)
+    veh_, cfg_, tr_, laps_, inp_, q_ = LS.make(4, 2, N=40)
+    ss_x, ss_j, _ = lm.ss_query(q_)
+    with pytest.raises(pkg.LmpcError, match="no kernel"):
+        lm.solve(inp_, ss_x=ss_x, ss_j=ss_j, mixed=True)
 
 
 def test_c_abi_rejects_misuse_without_crashing(pkg):
