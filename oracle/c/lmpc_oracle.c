@@ -515,7 +515,8 @@ static void term_factor(prob_t* p, term_t* tm, const double* thl, double* PT) {
     }
   }
   for (int r = 0; r < 6; ++r)
-    for (int c = 0; c < 6; ++c) F[r * 6 + c] = T[r * 6 + c] + (r == c ? 1.0 / p->chs2[r] : 0.0);
+    for (int c = 0; c < 6; ++c) /* a zero hull-slack weight (racing_mpc.cpp:497: that component of eps is free): E_k^-1 -> "infinite" */
+      F[r * 6 + c] = T[r * 6 + c] + (r == c ? 1.0 / fmax(p->chs2[r], 1e-30) : 0.0);
   sym_inv6(F, tm->FBi);
   double C[MA_MAX][MA_MAX];
   for (int a = 0; a < m; ++a)

@@ -215,8 +215,9 @@ int lmpc_create(const lmpc_config* cfg, const lmpc_vehicle* veh, int device, lmp
     bool any = false;
     for (int k = 0; k < 6; ++k) any = any || cfg->convex_hull_slack[k] > 0.0;
     for (int k = 0; k < 6; ++k)
-      if (any && !(cfg->convex_hull_slack[k] > 0.0))
-        return fail(h, LMPC_ERR_UNSUPPORTED, "convex_hull_slack must be positive in every component");
+      if (cfg->convex_hull_slack[k] < 0.0) return fail(h, LMPC_ERR_ARGUMENT, "convex_hull_slack must be non-negative");
+    // a zero component is a free slack component (racing_mpc.cpp:497-499: its cost weight is zero); only ALL zero turns
+    // the hull row into an equality (:501), which is not built
     if (!any) return fail(h, LMPC_ERR_UNSUPPORTED, "hard convex-hull equality (all-zero convex_hull_slack, racing_mpc.cpp:501)");
   }
   h->cfg = *cfg;

@@ -1405,7 +1405,7 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
             aB[r] = av[r];
           }
 #pragma unroll
-          for (int k = 0; k < 6; ++k) F[k * 6 + k] += 1.0 / TT[TL_E + k];
+          for (int k = 0; k < 6; ++k) F[k * 6 + k] += 1.0 / fmax(TT[TL_E + k], treal(1e-30));  // (a zero weight: that component of eps is free)
           term_factor_u(TT, lane, F, aB, av[6], m);
         }
         if (lane < 6) {

@@ -842,3 +842,32 @@ def test_euler_integrator_solves_against_the_dense_optimum(pkg):
     assert_contract(out, ref, margin, certified)
     rk = to_np(pkg.Solver(pkg.presets.barc_tracking_mpc(12), pkg.presets.barc_vehicle(), device=0).solve(inp))
     assert np.abs(rk["X_optm"] - out["X_optm"]).max() > 1e-6                 # and it is a different problem from RK4's
+
+
+def test_zero_components_of_the_hull_slack_weight_on_the_device(pkg, golden):
+    """convex_hull_slack = [40, 0, 4, 40, 0, 4] (racing_mpc.cpp:497-499: the zero components of the slack are free):
+    accepted, and the kernel lands on the dense optimum of that QP; all-zero (the hard equality, :501) is still refused."""
+    import dataclasses
+    import lmpc_scenario as LS
+    import torch
+    g = golden("qp_barc_lmpc_n20")
+    chs = [40.0, 0.0, 4.0, 40.0, 0.0, 4.0]
+    preset = pkg.presets.barc_lmpc(20, 3)
+    preset["convex_hull_slack"] = chs
+    solver = pkg.Solver(preset, pkg.presets.barc_vehicle(), device=0)
+    solver.set_safe_set(LS.load_laps(), LS.L_BARC_SS)
+    ss_x, ss_j, _ = solver.ss_query(g["query"])
+    out = solver.alloc_outputs(16)
+    out["convex_combi_optm"] = torch.zeros((96, 16), dtype=torch.float64, device="cuda")
+    o = to_np(solver.solve(g, out, ss_x=ss_x, ss_j=ss_j))
+    assert (o["status"] == 0).all()
+    veh, cfg = P.barc_vehicle(), dataclasses.replace(P.barc_lmpc(20, 3), convex_hull_slack=np.array(chs))
+    for b in range(0, 16, 3):
+        qp = Q.build_qp(cfg, veh, S.problem(g, b), ss_x=g["ss_x"][:, :, b], ss_j=g["ss_j"][:, b])
+        y, info = Q.solve_dense(qp)
+        ex = qp.split(y)
+        assert np.abs((o["X_optm"][:, :, b] - ex["X_optm"]) / P.SCALE_X[:, None]).max() < 2e-6, b
+        assert np.abs((o["U_optm"][:, :, b] - ex["U_optm"]) / P.SCALE_U[:, None]).max() < 2e-6, b
+    preset["convex_hull_slack"] = [0.0] * 6
+    with pytest.raises(pkg.LmpcError, match="hard convex-hull equality"):
+        pkg.Solver(preset, pkg.presets.barc_vehicle(), device=0)

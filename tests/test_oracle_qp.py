@@ -81,3 +81,22 @@ def test_lmpc_golden_and_c_twin(golden):
     assert scaled_err(out["dU_optm"], g["dU_optm"], P.SCALE_U) < 1e-5
     lam = out["convex_combi_optm"]
     assert np.abs(lam.sum(0) - 1.0).max() < 1e-9 and lam.min() > -1e-12
+
+
+def test_zero_components_of_the_hull_slack_weight(golden):
+    """convex_hull_slack with zero entries (racing_mpc.cpp:497-499): those components of the hull slack are free -- the
+    terminal state is tied to the convex hull only in the weighted components.  Twin against the dense optimum."""
+    import dataclasses
+    g = golden("qp_barc_lmpc_n20")
+    veh = P.barc_vehicle()
+    cfg = dataclasses.replace(P.barc_lmpc(20, 3), convex_hull_slack=np.array([40.0, 0.0, 4.0, 40.0, 0.0, 4.0]))
+    out = cbind.solve_batch(cfg, veh, g, ss_x=g["ss_x"], ss_j=g["ss_j"], b1=6)
+    assert (out["status"][:6] == 0).all()
+    for b in range(6):
+        qp = Q.build_qp(cfg, veh, S.problem(g, b), ss_x=g["ss_x"][:, :, b], ss_j=g["ss_j"][:, b])
+        y, info = Q.solve_dense(qp)
+        assert info["status"] == 0
+        ex = qp.split(y)
+        assert np.abs((out["X_optm"][:, :, b] - ex["X_optm"]) / P.SCALE_X[:, None]).max() < 2e-6, b
+        assert np.abs((out["U_optm"][:, :, b] - ex["U_optm"]) / P.SCALE_U[:, None]).max() < 2e-6, b
+        assert np.abs(ex["X_optm"][:, :, ] - g["X_optm"][:, :, b]).max() > 1e-6      # and it is a different problem
