@@ -409,17 +409,15 @@ __device__ __forceinline__ void chol_solve6(const real* Lc, real (&x)[MA_MAX]) {
 }
 
 // F = E^-1 + T_B (full 6x6), a_B, s_B, m explicit points (their u, theta already in T[TL_UA], T[TL_THA]).
-// Writes F_B^-1, W_A, the factor of C_A, x1, g, a_B, s11 and PT = F^-1 + g g'/s11.
-// Every lane computes everything (wave-uniform values), lane 0 stores, later stages read back as broadcast reads: W and
-// F_B^-1 go through LDS between the stages so that they are not live together with the factor and with Y -- kept in
-// registers throughout, the block pushed 200 registers of the iteration's row state to scratch (LMPC batch: 4.0 ms).
-// (A version that dealt the 6x6 products to 36 lanes, one element each, was 25 % faster still and NOT reproducible from
-// run to run; the single-writer pattern used everywhere else in this kernel is.)
+// Writes F_B^-1, W_A, the factor of C_A, x1, g, a_B, s11 and PT = F^-1 + g g'/s11 to the LDS tail.
+// The two Cholesky factors are wave-uniform arithmetic in registers (every lane holds the sums they start from); the
+// products in between run one OUTPUT per lane -- a column of F_B^-1, an element of W_A, C_A, PT -- on operands fetched
+// from LDS in one batch per stage, results to LDS (each cell has one writer), a fence, next stage.  An earlier form
+// computed everything in every lane with lane 0 storing: ~300 dependent LDS round trips per call, 26 k cycles per
+// iteration at one wave per SIMD.  Per output the operations and their order are the same: bit-identical results.
 template <typename real>
 __device__ __forceinline__ void term_factor_u(real* T, int lane, const real (&F)[36], const real (&aB)[6], real sB, int m) {
-  // Loops over the explicit points / the columns are deliberately NOT unrolled: their operands come from LDS by a
-  // run-time index, so only one 6x6 triangular factor is ever live in registers.
-  {  // F_B^-1 by Cholesky, one column at a time straight into LDS (the inverse is never held in registers)
+  {  // F_B^-1 by Cholesky: lane c < 6 solves for column c
     real Lf[36];
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
@@ -436,27 +434,25 @@ __device__ __forceinline__ void term_factor_u(real* T, int lane, const real (&F)
         Lf[i * 6 + j] = t * id;
       }
     }
-#pragma nounroll
-    for (int c = 0; c < 6; ++c) {
-      real y[6], x[6];
+    const int c = lane < 6 ? lane : 0;
+    real y[6], x[6];
 #pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        real t = (i == c) ? real(1) : real(0);
+    for (int i = 0; i < 6; ++i) {
+      real t = (i == c) ? real(1) : real(0);
 #pragma unroll
-        for (int k = 0; k < i; ++k) t -= Lf[i * 6 + k] * y[k];
-        y[i] = t * Lf[i * 6 + i];
-      }
+      for (int k = 0; k < i; ++k) t -= Lf[i * 6 + k] * y[k];
+      y[i] = t * Lf[i * 6 + i];
+    }
 #pragma unroll
-      for (int i = 5; i >= 0; --i) {
-        real t = y[i];
+    for (int i = 5; i >= 0; --i) {
+      real t = y[i];
 #pragma unroll
-        for (int k = i + 1; k < 6; ++k) t -= Lf[k * 6 + i] * x[k];
-        x[i] = t * Lf[i * 6 + i];
-      }
-      if (lane == 0) {
+      for (int k = i + 1; k < 6; ++k) t -= Lf[k * 6 + i] * x[k];
+      x[i] = t * Lf[i * 6 + i];
+    }
+    if (lane < 6) {
 #pragma unroll
-        for (int i = 0; i < 6; ++i) T[TL_FB + i * 6 + c] = x[i];
-      }
+      for (int i = 0; i < 6; ++i) T[TL_FB + i * 6 + lane] = x[i];
     }
     if (lane == 0) {
 #pragma unroll
@@ -464,35 +460,33 @@ __device__ __forceinline__ void term_factor_u(real* T, int lane, const real (&F)
     }
   }
   wave_fence();
-  // W[a][r] = sum_c F_B^-1[r][c] u_a[c]
-#pragma nounroll
-  for (int a = 0; a < MA_MAX; ++a) {
-    real ua[6];
+  {  // W[a][r] = sum_c F_B^-1[r][c] u_a[c]: lane 6a + r
+    const int l = lane < 6 * MA_MAX ? lane : 0, a = (l * 43) >> 8, r = l - 6 * a;
+    real fb[6], ua[6];
 #pragma unroll
-    for (int c = 0; c < 6; ++c) ua[c] = T[TL_UA + a * 6 + c];
-#pragma unroll
-    for (int r = 0; r < 6; ++r) {
-      real v = 0.0;
-#pragma unroll
-      for (int c = 0; c < 6; ++c) v += T[TL_FB + r * 6 + c] * ua[c];
-      if (lane == 0) T[TL_WA + a * 6 + r] = v;
+    for (int c = 0; c < 6; ++c) {
+      fb[c] = T[TL_FB + r * 6 + c];
+      ua[c] = T[TL_UA + a * 6 + c];
     }
+    real v = 0.0;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) v += fb[c] * ua[c];
+    if (lane < 6 * MA_MAX) T[TL_WA + lane] = v;
   }
   wave_fence();
-  // C_A = Theta_A + U_A'W_A, staged through the factor's cells
-#pragma nounroll
-  for (int a = 0; a < MA_MAX; ++a) {
-    real ua[6];
+  {  // C_A = Theta_A + U_A'W_A, staged through the factor's cells: lane 4a + b
+    static_assert(MA_MAX == 4, "lane mapping of C_A");
+    const int l = lane & 15, a = l >> 2, bq = l & 3;
+    real ua[6], wb[6];
 #pragma unroll
-    for (int c = 0; c < 6; ++c) ua[c] = T[TL_UA + a * 6 + c];
-    const real tha = T[TL_THA + a];
-#pragma unroll
-    for (int bq = 0; bq < MA_MAX; ++bq) {
-      real v = (a == bq) ? tha : real(0);
-#pragma unroll
-      for (int r = 0; r < 6; ++r) v += ua[r] * T[TL_WA + bq * 6 + r];
-      if (lane == 0) T[TL_LC + a * 6 + bq] = v;
+    for (int r = 0; r < 6; ++r) {
+      ua[r] = T[TL_UA + a * 6 + r];
+      wb[r] = T[TL_WA + bq * 6 + r];
     }
+    real v = (a == bq) ? T[TL_THA + a] : real(0);
+#pragma unroll
+    for (int r = 0; r < 6; ++r) v += ua[r] * wb[r];
+    if (lane < 16) T[TL_LC + a * 6 + bq] = v;
   }
   wave_fence();
   // its Cholesky factor, reciprocal pivots on the diagonal; a jitter for identical points (the padding repeats the last
@@ -519,114 +513,149 @@ __device__ __forceinline__ void term_factor_u(real* T, int lane, const real (&F)
     }
   }
   wave_fence();
-  // x1 = C_A^-1 (1_A - W_A'a_B), z1 = a_B + U_A x1, g = F_B^-1 z1, s11 = 1_A'x1 + s_B - a_B'g
-  real g[6];
+  // x1 = C_A^-1 (1_A - W_A'a_B), z1 = a_B + U_A x1, g = F_B^-1 z1, s11 = 1_A'x1 + s_B - a_B'g: a row per lane, the
+  // vectors from one product to the next through v_readlane
   real s11 = sB;
   {
-    real x1[MA_MAX];
-#pragma unroll
-    for (int a = 0; a < MA_MAX; ++a) {
-      real v = a < m ? real(1) : real(0);
-#pragma unroll
-      for (int r = 0; r < 6; ++r) v -= T[TL_WA + a * 6 + r] * aB[r];
-      x1[a] = v;
-    }
-    chol_solve6(Lc, x1);
-    real z1[6];
-#pragma unroll
-    for (int r = 0; r < 6; ++r) z1[r] = aB[r];
-#pragma unroll
-    for (int a = 0; a < MA_MAX; ++a) {
-#pragma unroll
-      for (int r = 0; r < 6; ++r) z1[r] += T[TL_UA + a * 6 + r] * x1[a];
-      s11 += a < m ? x1[a] : real(0);
-    }
+    const int la = lane & 3, lr = lane < 6 ? lane : 0;
+    real wa[6], fb[6], ua[MA_MAX];
 #pragma unroll
     for (int r = 0; r < 6; ++r) {
+      wa[r] = T[TL_WA + la * 6 + r];
+      fb[r] = T[TL_FB + lr * 6 + r];
+    }
+#pragma unroll
+    for (int a = 0; a < MA_MAX; ++a) ua[a] = T[TL_UA + a * 6 + lr];
+    real x1[MA_MAX], g[6];
+    {
+      real v = la < m ? real(1) : real(0);
+#pragma unroll
+      for (int r = 0; r < 6; ++r) v -= wa[r] * aB[r];
+#pragma unroll
+      for (int a = 0; a < MA_MAX; ++a) x1[a] = lane_bcast(v, a);
+    }
+    chol_solve6(Lc, x1);
+    real z1u[6];
+    {
+      real z = aB[0];
+#pragma unroll
+      for (int k = 1; k < 6; ++k) z = (lr == k) ? aB[k] : z;
+#pragma unroll
+      for (int a = 0; a < MA_MAX; ++a) {
+        z += ua[a] * x1[a];
+        s11 += a < m ? x1[a] : real(0);
+      }
+#pragma unroll
+      for (int c = 0; c < 6; ++c) z1u[c] = lane_bcast(z, c);
+    }
+    {
       real v = 0.0;
 #pragma unroll
-      for (int c = 0; c < 6; ++c) v += T[TL_FB + r * 6 + c] * z1[c];
-      g[r] = v;
-      s11 -= aB[r] * v;
+      for (int c = 0; c < 6; ++c) v += fb[c] * z1u[c];
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+        g[r] = lane_bcast(v, r);
+        s11 -= aB[r] * g[r];
+      }
     }
     if (lane == 0) {
 #pragma unroll
-      for (int k = 0; k < 6; ++k) {
-        T[TL_X1 + k] = x1[k];
-        T[TL_G + k] = g[k];
-      }
-      T[TL_S11] = s11;
+      for (int k = 0; k < 6; ++k) T[TL_G + k] = g[k];
 #pragma unroll
-      for (int a = 0; a < MA_MAX; ++a)
+      for (int a = 0; a < MA_MAX; ++a) {
+        T[TL_X1 + a] = x1[a];
 #pragma unroll
         for (int bq = 0; bq <= a; ++bq) T[TL_LC + a * 6 + bq] = Lc[a * 6 + bq];
+      }
+      T[TL_S11] = s11;
     }
   }
-  // PT = F_B^-1 - W_A C_A^-1 W_A' + g g'/s11, column by column
-  const real is11 = real(1) / s11;
-#pragma nounroll
-  for (int c = 0; c < 6; ++c) {
-    real t[MA_MAX];
+  wave_fence();
+  {  // PT = F_B^-1 - W_A C_A^-1 W_A' + g g'/s11: lane 6r + c
+    const real is11 = real(1) / s11;
+    const int l = lane < 36 ? lane : 0, r = (l * 43) >> 8, c = l - 6 * r;
+    real t[MA_MAX], wr[MA_MAX];
 #pragma unroll
-    for (int a = 0; a < MA_MAX; ++a) t[a] = T[TL_WA + a * 6 + c];
-    chol_solve6(Lc, t);
-    const real gc = T[TL_G + c];
-#pragma unroll
-    for (int r = 0; r < 6; ++r) {
-      real v = T[TL_FB + r * 6 + c] + g[r] * gc * is11;
-#pragma unroll
-      for (int a = 0; a < MA_MAX; ++a) v -= T[TL_WA + a * 6 + r] * t[a];
-      if (lane == 0) T[TL_PT + r * 6 + c] = v;
+    for (int a = 0; a < MA_MAX; ++a) {
+      t[a] = T[TL_WA + a * 6 + c];
+      wr[a] = T[TL_WA + a * 6 + r];
     }
+    const real gc = T[TL_G + c], gr = T[TL_G + r], fbrc = T[TL_FB + r * 6 + c];
+    chol_solve6(Lc, t);
+    real v = fbrc + gr * gc * is11;
+#pragma unroll
+    for (int a = 0; a < MA_MAX; ++a) v -= wr[a] * t[a];
+    if (lane < 36) T[TL_PT + lane] = v;
   }
   wave_fence();
 }
 
 // One right-hand side: beta = U_B Th_B^-1 r_B, sig = 1'Th_B^-1 r_B (wave sums over B), r_A in T[TL_RA], simplex
 // residual r1.  Returns h = E U dlambda and nu; writes the explicit points' step to T[TL_XA] (lane 0).
+// The operands (rows of W_A, U_A, F_B^-1, the factor of C_A, a_B, g) do not depend on the right-hand side: every lane
+// fetches the row it works on in ONE batch of LDS reads, the four short products run one output per lane, and what the
+// next product needs of the previous one travels through v_readlane (scalar registers), not through LDS -- at one wave
+// per SIMD every dependent LDS round trip is ~100 idle cycles, and the all-lanes-compute-everything form of this
+// routine had ~100 of them.  Same operations in the same order per output: results are bit-identical to that form.
 template <typename real>
 __device__ __forceinline__ void term_solve_u(real* T, int lane, int m, const real (&beta)[6], real sig, real r1, real (&h)[6],
                                              real& nu) {
-  real xa[MA_MAX];
-#pragma unroll
-  for (int a = 0; a < MA_MAX; ++a) {
-    real v = T[TL_RA + a];
-#pragma unroll
-    for (int r = 0; r < 6; ++r) v -= T[TL_WA + a * 6 + r] * beta[r];
-    xa[a] = v;
-  }
-  {
-    real Lc[36];
-#pragma unroll
-    for (int i = 0; i < MA_MAX; ++i)
-#pragma unroll
-      for (int k = 0; k <= i; ++k) Lc[i * 6 + k] = T[TL_LC + i * 6 + k];
-    chol_solve6(Lc, xa);
-  }
-  real z[6], num = sig - r1;
-#pragma unroll
-  for (int r = 0; r < 6; ++r) z[r] = beta[r];
-#pragma unroll
-  for (int a = 0; a < MA_MAX; ++a) {
-#pragma unroll
-    for (int r = 0; r < 6; ++r) z[r] += T[TL_UA + a * 6 + r] * xa[a];
-    num += a < m ? xa[a] : real(0);
-  }
-  real Fz[6];
+  const int la = lane & 3, lr = lane < 6 ? lane : 0;
+  real wa[6], fb[6], ua[MA_MAX], Lc[36], ab[6], gg[6], x1[MA_MAX];
 #pragma unroll
   for (int r = 0; r < 6; ++r) {
+    wa[r] = T[TL_WA + la * 6 + r];
+    fb[r] = T[TL_FB + lr * 6 + r];
+    ab[r] = T[TL_AB + r];
+    gg[r] = T[TL_G + r];
+  }
+  const real ra = T[TL_RA + la], s11 = T[TL_S11];
+#pragma unroll
+  for (int a = 0; a < MA_MAX; ++a) {
+    ua[a] = T[TL_UA + a * 6 + lr];
+    x1[a] = T[TL_X1 + a];
+#pragma unroll
+    for (int k = 0; k <= a; ++k) Lc[a * 6 + k] = T[TL_LC + a * 6 + k];
+  }
+  real xa[MA_MAX];
+  {
+    real v = ra;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) v -= wa[r] * beta[r];
+#pragma unroll
+    for (int a = 0; a < MA_MAX; ++a) xa[a] = lane_bcast(v, a);
+  }
+  chol_solve6(Lc, xa);
+  real num = sig - r1;
+  real zu[6];
+  {
+    real z = beta[0];
+#pragma unroll
+    for (int k = 1; k < 6; ++k) z = (lr == k) ? beta[k] : z;
+#pragma unroll
+    for (int a = 0; a < MA_MAX; ++a) {
+      z += ua[a] * xa[a];
+      num += a < m ? xa[a] : real(0);
+    }
+#pragma unroll
+    for (int c = 0; c < 6; ++c) zu[c] = lane_bcast(z, c);
+  }
+  {
     real v = 0.0;
 #pragma unroll
-    for (int c = 0; c < 6; ++c) v += T[TL_FB + r * 6 + c] * z[c];
-    Fz[r] = v;
-    num -= T[TL_AB + r] * v;
-  }
-  nu = num / T[TL_S11];
+    for (int c = 0; c < 6; ++c) v += fb[c] * zu[c];
 #pragma unroll
-  for (int r = 0; r < 6; ++r) h[r] = Fz[r] - nu * T[TL_G + r];
+    for (int r = 0; r < 6; ++r) {
+      h[r] = lane_bcast(v, r);
+      num -= ab[r] * h[r];
+    }
+  }
+  nu = num / s11;
+#pragma unroll
+  for (int r = 0; r < 6; ++r) h[r] = h[r] - nu * gg[r];
   if (lane == 0) {
 #pragma unroll
-    for (int a = 0; a < MA_MAX; ++a) T[TL_XA + a] = xa[a] - nu * T[TL_X1 + a];
+    for (int a = 0; a < MA_MAX; ++a) T[TL_XA + a] = xa[a] - nu * x1[a];
   }
   wave_fence();
 }
@@ -1306,6 +1335,7 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
         }
       }
       if constexpr (KS > 0) {
+        PT_MARK(2)
         // ---- which points stay explicit this iteration: the (at most MA_MAX) smallest theta below tau ----
         treal thq[KS];
 #pragma unroll
@@ -1349,6 +1379,7 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
         }
         sx.m = m;
         wave_fence();
+        PT_MARK(13)
         // ---- sums over the eliminated points: T_B (21), a_B (6), s_B; and over all points: U lambda (6), sum lambda ----
         treal tt[21], av[14];
 #pragma unroll
@@ -1406,7 +1437,9 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
           }
 #pragma unroll
           for (int k = 0; k < 6; ++k) F[k * 6 + k] += 1.0 / fmax(TT[TL_E + k], treal(1e-30));  // (a zero weight: that component of eps is free)
+          PT_MARK(14)
           term_factor_u(TT, lane, F, aB, av[6], m);
+          PT_MARK(15)
         }
         if (lane < 6) {
           treal e = 0.0;
@@ -1813,6 +1846,10 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
   template __global__ void lmpc_solve_kernel<REAL, KQ, KS, IO>(lmpc_params, int, const IO*, const IO*, const IO*,        \
                                                                 const IO*, const IO*, const IO*, const IO*, const IO*,    \
                                                                 const IO*, IO*, IO*, IO*, IO*, int*, int*, IO*);
+#ifdef LMPC_SINGLE_INSTANCE  // (ISA inspection: hipcc -S -DLMPC_SINGLE_INSTANCE="double, 4, 3, double")
+#define LMPC_INSTANTIATE_X(...) LMPC_INSTANTIATE(__VA_ARGS__)
+LMPC_INSTANTIATE_X(LMPC_SINGLE_INSTANCE)
+#else
 LMPC_INSTANTIATE(double, 2, 0, double)
 LMPC_INSTANTIATE(double, 4, 0, double)
 LMPC_INSTANTIATE(double, 7, 0, double)
@@ -1839,3 +1876,4 @@ LMPC_INSTANTIATE(float, 11, 0, double)  // iac_car_tracking_mpc.param.yaml ships
 LMPC_INSTANTIATE(float, 14, 0, double)
 LMPC_INSTANTIATE(float, 4, 2, double)  // the learning problem, N <= 23 (BASELINE configs[4])
 LMPC_INSTANTIATE(float, 4, 3, double)
+#endif
