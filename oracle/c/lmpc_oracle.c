@@ -419,7 +419,9 @@ static inline double slot_val(double (*z)[8], double (*v)[2], int i, int sl) {
  * damped the step of exactly the points that matter, so problems with two or three supporting points crawled or stalled,
  * and at IAC scale the iterate stopped 1e-3 .. 1e-2 from the optimum with mu -> 0.) */
 /* complementarity below which the factorisation switches to the stabilised form (riccati_factor) */
+#ifndef JOSEPH_MU
 #define JOSEPH_MU 1e-8
+#endif
 /* complementarity below which a step that does not lower it ends the solve (ipm_solve) */
 #define STALL_MU 1e-9
 #define MA_MAX 4
