@@ -42,6 +42,49 @@ def measured_traffic_bytes(pmc_file="r02_pmc.json", kernel="lmpc_solve_kernel<do
         return None
 
 
+def live_traffic_bytes(workload_argv, kernel):
+    """HBM bytes per launch of the QP kernel measured NOW: two rocprofv3 --pmc passes of this same script (FETCH_SIZE and
+    WRITE_SIZE do not fit one pass, MI355X_MICROARCH.md; counters only, no trace domains), --steps 5, one stream, summed
+    from the per-dispatch records of the kernel.  Units and corrections as measured_traffic_bytes.  None when rocprofv3 is
+    missing or a pass fails (the committed passes are reported instead, and `traffic_source` says so)."""
+    import shutil
+    import signal
+    import sqlite3
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    total = 0.0
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["TMPDIR"] = "/tmp"
+    try:
+        with tempfile.TemporaryDirectory(dir="/tmp") as d:
+            for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+                out = os.path.join(d, counter)
+                cmd = [exe, "--pmc", counter, "-d", out, "-o", "run", "--", sys.executable, str(ROOT / "bench.py"), "--steps", "5",
+                       "--warmup", "1", "--no-cpu-baseline", "--no-batch1", "--streams", "1", "--no-pmc"] + workload_argv
+                proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+                try:
+                    proc.wait(timeout=180)
+                except subprocess.TimeoutExpired:
+                    os.killpg(proc.pid, signal.SIGKILL)  # the exact process group started above
+                    return None
+                dbs = [os.path.join(r, f) for r, _, fs in os.walk(out) for f in fs if f.endswith("_results.db")]
+                if proc.returncode != 0 or not dbs:
+                    return None
+                con = sqlite3.connect(dbs[0])
+                row = con.execute("select avg(value), count(*) from counters_collection where counter_name = ? and kernel_name like ?",
+                                  (counter, "%" + kernel + "%")).fetchone()
+                con.close()
+                if not row or not row[1]:
+                    return None
+                total += float(row[0]) * 1024.0
+        return total
+    except Exception:
+        return None
+
+
 def engine_utilisation(kernel_ms, pmc_file="r02_pmc.json", kernel="lmpc_solve_kernel<double, 4, 0"):
     """What actually bounds the QP kernel: busy fractions of the FP64 VALU and of the LDS pipeline from the same
     committed PMC passes (SQ_ACTIVE_INST_VALU is in 4-cycle units summed over waves, one VALU per SIMD, 4 SIMDs x
@@ -188,6 +231,8 @@ def main():
                          "each), so the tail of one batch overlaps the head of the next; 1 = strictly one batch at a time")
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL result gather for N > 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="do not run the two rocprofv3 --pmc passes that measure the QP kernel's HBM "
+                    "traffic (N = 1 only, ~30 s); roofline.traffic then comes from the committed passes in profiles/")
     ap.add_argument("--no-batch1", action="store_true", help="skip the single-car latency probe (profiling runs: keeps every "
                                                              "launch of the QP kernel at the bench batch size)")
     args = ap.parse_args()
@@ -420,6 +465,16 @@ def main():
         achieved = algo_bytes * B / (sol_avg * 1e-3) / 1e9
         # committed PMC passes of this command: tracking, or the learning problem with 160 safe-set points
         pmc_sel = ("r02_pmc_lmpc.json", "lmpc_solve_kernel<double, 4, 3") if lmpc else ("r02_pmc.json", "lmpc_solve_kernel<double, 4, 0")
+        pmc_shape = not (N != 20 or B != 4096 or iac or f32 or mixed)  # the shape the committed passes were taken on
+        traffic, traffic_source = None, None
+        if world == 1 and not args.no_pmc:
+            wl_argv = ["--batch", str(B), "--horizon", str(N), "--workload", args.workload, "--precision", args.precision]
+            kname = "lmpc_solve_kernel<%s, " % ("float" if (f32 or mixed) else "double")
+            traffic = live_traffic_bytes(wl_argv, kname)
+            traffic_source = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, two passes of this command at --steps 5, measured in this run"
+        if traffic is None and pmc_shape:
+            traffic = measured_traffic_bytes(*pmc_sel)
+            traffic_source = "profiles/%s (committed rocprofv3 --pmc passes of this command)" % pmc_sel[0]
         res = {
             "metric": "QP solves/sec (nx=6,nu=2,N=%d)" % N, "value": value, "unit": "solves/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -443,11 +498,11 @@ def main():
                         "resident_problems_per_cu": None, "note": "fp32 records are half the fp64 size"} if (f32 or mixed) else solver.launch_info()),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None if (N != 20 or B != 4096 or iac or f32 or mixed) else measured_traffic_bytes(*pmc_sel),
+                         "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_solve": algo_bytes,
                          "note": "algorithmic bytes x batch / lmpc_solve_kernel time; the kernel is "
                                  "FP64-VALU issue / LDS-pipeline bound (DESIGN.md), HBM fraction is reported as required",
-                         "engines": None if (N != 20 or B != 4096 or iac or f32 or mixed) else engine_utilisation(sol_avg, *pmc_sel)},
+                         "engines": engine_utilisation(sol_avg, *pmc_sel) if pmc_shape else None},
         }
         if ss_ms:
             # safe-set query kernel: per query 2 doubles in, 7 S doubles out (ss_x [6][S], ss_j [S]); the lap store

@@ -1,7 +1,7 @@
 #!/bin/bash
 # round-2 measurement set (run on the GPU box from the repo root)
 mkdir -p gpurun_out/r02
-B="python bench.py --no-cpu-baseline"
+B="python bench.py --no-cpu-baseline --no-pmc"
 python bench.py > gpurun_out/r02/bench_tracking.json 2> gpurun_out/r02/bench_tracking.err
 $B --streams 1 > gpurun_out/r02/bench_tracking_s1.json 2>/dev/null
 $B --batch 65536 --steps 10 --warmup 2 > gpurun_out/r02/bench_tracking_b65536.json 2>/dev/null
