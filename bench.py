@@ -230,6 +230,9 @@ def main():
                     help="consecutive steps alternate between this many HIP streams (one handle, workspace and output buffer "
                          "each), so the tail of one batch overlaps the head of the next; 1 = strictly one batch at a time")
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL result gather for N > 1")
+    ap.add_argument("--regression", action="store_true", help="--workload lmpc only: switch the error-dynamics regression on "
+                    "(safe_set.cpp:182-245; BASELINE configs[4]: 'LMPC + error-dynamics residual term') -- 2200 recorded sample pairs "
+                    "from a plant with 15 %% less grip, every stage of every problem regressed before its QP")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="do not run the two rocprofv3 --pmc passes that measure the QP kernel's HBM "
                     "traffic (N = 1 only, ~30 s); roofline.traffic then comes from the committed passes in profiles/")
@@ -295,9 +298,27 @@ def main():
         cfgd = pkg.presets.barc_lmpc(N, 5)  # 5 laps stored, 32 per lap -> 160 points
         laps = pkg.workloads.synthetic_laps(tr, 5)
 
+        reg_laps = []
+        if args.regression:
+            # recorded data of a plant that differs from the model: states around the stored laps, their successors one
+            # 30 ms period later from the PLANT step kernel of a second handle (15 % less grip) -- two-sample laps
+            pv = dict(pkg.presets.barc_vehicle())
+            pv["mu"] *= 0.85
+            plant = pkg.Solver(cfgd, pv, device=local)
+            rng = np.random.default_rng(7)
+            xa = np.concatenate(laps) + rng.normal(0, 1, (sum(l.shape[0] for l in laps), 6)) * np.array([0.0, 0.02, 0.02, 0.1, 0.03, 0.2])
+            ua = np.stack([rng.uniform(-0.005, 0.005, xa.shape[0]), rng.uniform(-0.15, 0.15, xa.shape[0])], axis=1)
+            ka = np.interp(xa[:, 0], np.arange(tr["M"]) * tr["L"] / tr["M"], tr["curvature"], period=tr["L"])
+            xb = plant.plant_step(tr, torch.as_tensor(xa.T.copy(), device=dev), torch.as_tensor(ua.T.copy(), device=dev), 0.03).cpu().numpy().T
+            reg_laps = [(np.stack([xa[j], xb[j]]), np.stack([ua[j], ua[j]]), np.array([ka[j], ka[j]]), np.array([0.0, 0.03]))
+                        for j in range(xa.shape[0])]
+            plant.close()
+
         def make_solver():
             sv = pkg.Solver(cfgd, pkg.presets.barc_vehicle(), device=local)
             sv.set_safe_set(laps, tr["L"])
+            if reg_laps:
+                sv.set_regression_laps(reg_laps, dist_max=0.6)
             return sv
         solver = make_solver()
         x, u = pkg.workloads.sample_states_near_laps(laps, B, tr["L"], seed=rank)
@@ -485,7 +506,9 @@ def main():
                                     ("IAC Putnam tracking MPC, batch=%d per GPU, N=%d, fp32 (BASELINE configs[3])" if f32 else
                                      "IAC Putnam tracking MPC, batch=%d per GPU, N=%d, fp64 (problem of BASELINE configs[3])") if iac else
                                     "BARC tracking MPC, batch=%d random x0 per GPU, N=%d, fp64 (BASELINE configs[1])") % (B, N)
-                                   + (" -- mixed precision: fp32 Riccati / interior point between fp64 arrays (BASELINE configs[4])" if mixed else ""),
+                                   + (" -- mixed precision: fp32 Riccati / interior point between fp64 arrays (BASELINE configs[4])" if mixed else "")
+                                   + (" -- error-dynamics regression on: %d recorded sample pairs, every stage regressed before its QP" % len(reg_laps)
+                                      if (lmpc and reg_laps) else ""),
                        "batch_per_gpu": B, "horizon": N, "streams": S, "result_gather": "rccl all_gather (async)" if gather else "none",
                        "ranks_seen": ranks_seen},
             "p50_solve_ms": float(np.percentile(lat, 50)), "p99_solve_ms": float(np.percentile(lat, 99)),

@@ -30,9 +30,10 @@ __global__ void lmpc_ss_query_kernel(int, int, int, int, const int*, const int*,
                                      double*, double*, int*, double*);
 __global__ void lmpc_reg_residual_kernel(lmpc_vehicle, int, int, const int*, const double*, const double*, const double*,
                                          const double*, double*);
+__global__ void lmpc_reg_pack_kernel(lmpc_regression_spec, int, int, const int*, const double*, const double*, const double*, double*);
 template <int NF, int NOUT, bool WS_LAYOUT>
-__global__ void lmpc_regress_kernel(int, int, lmpc_regression_spec, int, const int*, const double*, const double*,
-                                    const double*, const double*, const double*, double*, double*, double*);
+__global__ void lmpc_regress_kernel(int, int, lmpc_regression_spec, int, const double*, const double*, const double*, double*,
+                                    double*, double*);
 struct lmpc_sqp_arrays;
 __global__ void lmpc_sqp_linesearch_kernel(lmpc_params, int, lmpc_sqp_arrays, int, double);
 __global__ void lmpc_sqp_accumulate_kernel(int, const int*, int*);
@@ -61,6 +62,8 @@ struct lmpc_handle {
   double* reg_x = nullptr;  // [total][6]
   double* reg_u = nullptr;  // [total][2]
   double* reg_y = nullptr;  // [total][6]
+  double* reg_tab = nullptr;  // [reg_npad][NF + NOUT]: features and regressed residuals of the samples that have a successor
+  int reg_npad = 0;           // their number, padded to a multiple of four with unreachable rows
   lmpc_regression_spec reg_spec{};
   // staging for the single-problem host entry points (lmpc_solve_host, lmpc_ss_query_host): device buffers and PINNED
   // host mirrors, all sized and allocated by lmpc_create -- the per-step path of one controller allocates nothing
@@ -176,17 +179,18 @@ int launch_solve(lmpc_handle* h, const void* fn, const solve_args& a) {
 
 
 namespace {
-// one wavefront per (problem, stage); WS: the handle's workspace, otherwise the caller's A/B/g arrays
+// one lane per (problem, stage); WS: the handle's workspace, otherwise the caller's A/B/g arrays
 template <bool WS>
 int launch_regress(lmpc_handle* h, int batch, const double* X_ref, const double* U_ref, double* A, double* Bm, double* g) {
   const int nf = h->reg_spec.n_in_state + h->reg_spec.n_in_ctrl;
-  const dim3 grid((unsigned)batch * (h->P.N - 1)), block(64);
+  const long long queries = (long long)batch * (h->P.N - 1);
+  const dim3 grid((unsigned)((queries + 63) / 64)), block(64);
   if (nf == 5 && h->reg_spec.n_out == 3)
-    hipLaunchKernelGGL((lmpc_regress_kernel<5, 3, WS>), grid, block, 0, h->stream, h->P.N, batch, h->reg_spec, h->reg_total,
-                       h->reg_end, h->reg_x, h->reg_u, h->reg_y, X_ref, U_ref, A, Bm, g);
+    hipLaunchKernelGGL((lmpc_regress_kernel<5, 3, WS>), grid, block, 0, h->stream, h->P.N, batch, h->reg_spec, h->reg_npad,
+                       h->reg_tab, X_ref, U_ref, A, Bm, g);
   else
-    hipLaunchKernelGGL((lmpc_regress_kernel<8, 6, WS>), grid, block, 0, h->stream, h->P.N, batch, h->reg_spec, h->reg_total,
-                       h->reg_end, h->reg_x, h->reg_u, h->reg_y, X_ref, U_ref, A, Bm, g);
+    hipLaunchKernelGGL((lmpc_regress_kernel<8, 6, WS>), grid, block, 0, h->stream, h->P.N, batch, h->reg_spec, h->reg_npad,
+                       h->reg_tab, X_ref, U_ref, A, Bm, g);
   HIP_TRY(h, hipGetLastError());
   return LMPC_OK;
 }
@@ -296,6 +300,7 @@ void lmpc_destroy(lmpc_handle* h) {
   if (h->reg_x) (void)hipFree(h->reg_x);
   if (h->reg_u) (void)hipFree(h->reg_u);
   if (h->reg_y) (void)hipFree(h->reg_y);
+  if (h->reg_tab) (void)hipFree(h->reg_tab);
   if (h->stage_dev) (void)hipFree(h->stage_dev);
   if (h->stage_int) (void)hipFree(h->stage_int);
   if (h->sqp_ws) (void)hipFree(h->sqp_ws);
@@ -862,10 +867,11 @@ int lmpc_set_regression_laps(lmpc_handle* h, int32_t n_laps, const int32_t* n_pt
   if (!h) return LMPC_ERR_ARGUMENT;
   HIP_TRY(h, hipSetDevice(h->device));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
-  for (void* p : {(void*)h->reg_end, (void*)h->reg_x, (void*)h->reg_u, (void*)h->reg_y})
+  for (void* p : {(void*)h->reg_end, (void*)h->reg_x, (void*)h->reg_u, (void*)h->reg_y, (void*)h->reg_tab})
     if (p) HIP_TRY(h, hipFree(p));
   h->reg_end = nullptr;
-  h->reg_x = h->reg_u = h->reg_y = nullptr;
+  h->reg_x = h->reg_u = h->reg_y = h->reg_tab = nullptr;
+  h->reg_npad = 0;
   h->reg_on = false;
   h->reg_total = 0;
   if (n_laps == 0 || !spec) return LMPC_OK;
@@ -904,6 +910,23 @@ int lmpc_set_regression_laps(lmpc_handle* h, int32_t n_laps, const int32_t* n_pt
   hipLaunchKernelGGL(lmpc_reg_residual_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, h->P.veh,
                      (int)total, spec->as_written ? 1 : 0, h->reg_end, h->reg_x, h->reg_u, dk, dt, h->reg_y);
   HIP_TRY(h, hipGetLastError());
+  {  // dense table of the samples that have a successor (what the per-solve kernel streams)
+    std::vector<int> valid;
+    valid.reserve(total);
+    for (size_t j = 0; j < total; ++j)
+      if (!end[j]) valid.push_back((int)j);
+    const int nvalid = (int)valid.size(), npad = (nvalid + 3) / 4 * 4;
+    int* dvalid = nullptr;
+    HIP_TRY(h, hipMalloc(&dvalid, (size_t)nvalid * sizeof(int)));
+    HIP_TRY(h, hipMalloc(&h->reg_tab, (size_t)npad * (size_t)(nf + spec->n_out) * sizeof(double)));
+    HIP_TRY(h, hipMemcpy(dvalid, valid.data(), (size_t)nvalid * sizeof(int), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(lmpc_reg_pack_kernel, dim3((unsigned)((npad + 255) / 256)), dim3(256), 0, h->stream, *spec, nvalid, npad, dvalid,
+                       h->reg_x, h->reg_u, h->reg_y, h->reg_tab);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipFree(dvalid));
+    h->reg_npad = npad;
+  }
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   HIP_TRY(h, hipFree(dk));
   HIP_TRY(h, hipFree(dt));

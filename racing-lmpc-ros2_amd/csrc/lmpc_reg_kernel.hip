@@ -17,9 +17,18 @@
 // from the data; spec.as_written = 1 reproduces that literally, the default is the regression that reduces the one-step
 // error (include/lmpc_hip.h).
 //
-// Two kernels: lmpc_reg_residual_kernel (once per lap upload: one thread per sample) and lmpc_regress_kernel (one
-// wavefront per (problem, stage): lanes stride over the samples, 21 + 6 NOUT weighted sums per lane in registers,
-// one batched wave reduction, the (ns+nc+1)^2 SPD solve done redundantly in registers).
+// Three kernels.  Once per lap upload: lmpc_reg_residual_kernel (one thread per sample) and lmpc_reg_pack_kernel, which
+// gathers the samples that have a successor into one dense table  tab[v] = [z (NF) | y (NOUT)]  (64 B per sample for
+// (5, 3)), padded to a multiple of four with rows no query can reach.  Per solve: lmpc_regress_kernel with ONE LANE PER
+// QUERY (problem, stage) -- stages of a problem on neighbouring lanes, they are neighbours in feature space too -- and
+// the sample loop wave-uniform: a sample's row arrives by scalar loads (s_load, four samples in flight), every lane
+// tests its own distance and, when any lane of the wave is within the bandwidth, adds w m m' and w y m' to its own
+// 21 + 6 NOUT sums as FMAs with scalar operands.  No cross-lane reduction, no per-lane gather; each lane then factors
+// its own (NF+1)^2 system.  The accumulation is the product W Phi (queries x samples times samples x 39) and would map
+// onto v_mfma_f64_16x16x4 -- whose rate on gfx950 equals the vector FMA rate, with 39 columns padded to 48: no gain.
+// (The first version ran one wavefront per query with the lanes striding the samples: three dependent gathers per
+// iteration behind two branches and a 39-value shuffle reduction -- latency-bound at 13 ms per 32768 x 19 queries over
+// 2200 samples; this one is FP64-issue-bound.)
 #include <hip/hip_runtime.h>
 
 #include "lmpc_device.h"
@@ -45,64 +54,94 @@ __global__ void lmpc_reg_residual_kernel(lmpc_vehicle veh, int total, int as_wri
   for (int c = 0; c < 6; ++c) y[(size_t)j * 6 + c] = r[c];
 }
 
+// tab[v][NF + NOUT] for the valid samples (valid[v] = index of a sample that is not the last of its lap), v < nvalid;
+// rows nvalid .. npad-1: features 1e30 (out of every bandwidth), residuals 0
+__global__ void lmpc_reg_pack_kernel(lmpc_regression_spec spec, int nvalid, int npad, const int* __restrict__ valid,
+                                     const double* __restrict__ x, const double* __restrict__ u, const double* __restrict__ y,
+                                     double* __restrict__ tab) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= npad) return;
+  const int ns = spec.n_in_state, nf = ns + spec.n_in_ctrl, nrow = nf + spec.n_out;
+  double* row = tab + (size_t)v * nrow;
+  if (v >= nvalid) {
+    for (int f = 0; f < nf; ++f) row[f] = 1e30;
+    for (int o = 0; o < spec.n_out; ++o) row[nf + o] = 0.0;
+    return;
+  }
+  const int j = valid[v];
+  for (int f = 0; f < nf; ++f) row[f] = f < ns ? x[(size_t)j * 6 + spec.in_state[f]] : u[(size_t)j * 2 + spec.in_ctrl[f - ns]];
+  for (int o = 0; o < spec.n_out; ++o) row[nf + o] = y[(size_t)j * 6 + spec.out[o]];
+}
+
 // WS_LAYOUT: update the handle's linearisation workspace [B][N-1][54]; otherwise the A/B/g arrays of lmpc_linearize_batch.
 template <int NF, int NOUT, bool WS_LAYOUT>
-__global__ __launch_bounds__(64) void lmpc_regress_kernel(int N, int B, lmpc_regression_spec spec, int total,
-                                                          const int* __restrict__ lap_end, const double* __restrict__ x,
-                                                          const double* __restrict__ u, const double* __restrict__ yres,
-                                                          const double* __restrict__ X_ref, const double* __restrict__ U_ref,
-                                                          double* __restrict__ outA, double* __restrict__ outB,
-                                                          double* __restrict__ outg) {
+__global__ __launch_bounds__(64) void lmpc_regress_kernel(int N, int B, lmpc_regression_spec spec, int npad,
+                                                          const double* __restrict__ tab, const double* __restrict__ X_ref,
+                                                          const double* __restrict__ U_ref, double* __restrict__ outA,
+                                                          double* __restrict__ outB, double* __restrict__ outg) {
   constexpr int NM = NF + 1;
   constexpr int NQ = NM * (NM + 1) / 2;
+  constexpr int NROW = NF + NOUT;
+  constexpr int UNR = 4;
   const int NS = N - 1;
-  const int b = blockIdx.x / NS, i = blockIdx.x - b * NS;
-  const int lane = threadIdx.x;
+  const long long gq = (long long)blockIdx.x * 64 + threadIdx.x;
+  const bool live = gq < (long long)B * NS;
+  const long long gqc = live ? gq : 0;
+  const int b = (int)(gqc / NS), i = (int)(gqc - (long long)b * NS);
   const int ns = spec.n_in_state;
   double q[NF];
 #pragma unroll
   for (int f = 0; f < NF; ++f)
     q[f] = f < ns ? X_ref[((size_t)spec.in_state[f] * N + i) * B + b] : U_ref[((size_t)spec.in_ctrl[f - ns] * NS + i) * B + b];
-  const double h = spec.dist_max, ih = 1.0 / h;
+  const double h = spec.dist_max, h2 = h * h, ih2 = 1.0 / h2, c0 = 0.75 / h;
   double acc[NQ + NOUT * NM];
 #pragma unroll
   for (int a = 0; a < NQ + NOUT * NM; ++a) acc[a] = 0.0;
-  for (int j = lane; j < total; j += 64) {
-    if (lap_end[j]) continue;
-    double m[NM];
-    double d2 = 0.0;
+  for (int j0 = 0; j0 < npad; j0 += UNR) {
+    double row[UNR][NROW], d2[UNR];
 #pragma unroll
-    for (int f = 0; f < NF; ++f) {
-      m[f] = f < ns ? x[(size_t)j * 6 + spec.in_state[f]] : u[(size_t)j * 2 + spec.in_ctrl[f - ns]];
-      const double e = m[f] - q[f];
-      d2 += e * e;
+    for (int t = 0; t < UNR; ++t)
+#pragma unroll
+      for (int c = 0; c < NROW; ++c) row[t][c] = tab[(size_t)(j0 + t) * NROW + c];  // wave-uniform address: scalar loads
+#pragma unroll
+    for (int t = 0; t < UNR; ++t) {
+      double s = 0.0;
+#pragma unroll
+      for (int f = 0; f < NF; ++f) {
+        const double e = row[t][f] - q[f];
+        s += e * e;
+      }
+      d2[t] = s;
     }
-    m[NF] = 1.0;
-    const double d = sqrt(d2);
-    if (!(d < h)) continue;
-    const double s = 1.0 - (d * ih) * (d * ih);
-    const double w = 0.75 * ih * s * s;
-    int a = 0;
 #pragma unroll
-    for (int r = 0; r < NM; ++r)
+    for (int t = 0; t < UNR; ++t) {
+      const bool hit = live && d2[t] < h2;   // K = 0.75/h (1 - (d/h)^2)^2 inside the bandwidth (safe_set.cpp:84-87)
+      if (!__any(hit)) continue;
+      const double sq = 1.0 - d2[t] * ih2;
+      const double w = hit ? c0 * sq * sq : 0.0;
+      double wm[NM];
 #pragma unroll
-      for (int c = r; c < NM; ++c) acc[a++] += w * m[r] * m[c];
+      for (int r = 0; r < NF; ++r) wm[r] = w * row[t][r];
+      wm[NF] = w;
+      int a = 0;
 #pragma unroll
-    for (int o = 0; o < NOUT; ++o) {
-      const double wy = w * yres[(size_t)j * 6 + spec.out[o]];
+      for (int r = 0; r < NM; ++r)
 #pragma unroll
-      for (int r = 0; r < NM; ++r) acc[a++] += wy * m[r];
+        for (int c = r; c < NM; ++c) {
+          acc[a] += c < NF ? wm[r] * row[t][c] : wm[r];
+          ++a;
+        }
+#pragma unroll
+      for (int o = 0; o < NOUT; ++o) {
+        const double yo = row[t][NF + o];
+#pragma unroll
+        for (int r = 0; r < NM; ++r) acc[a++] += wm[r] * yo;
+      }
     }
-  }
-  // wave reduction of all sums in lock-step
-#pragma unroll
-  for (int msk = 32; msk >= 1; msk >>= 1) {
-#pragma unroll
-    for (int a = 0; a < NQ + NOUT * NM; ++a) acc[a] += __shfl_xor(acc[a], msk);
   }
   // "if there are no points left, skip the regression" (safe_set.cpp:207-210): the weight sum is M'KM's last entry
-  if (!(acc[NQ - 1] > 0.0)) return;
-  // Cholesky of Q = M'KM + 1e-3 I (every lane, wave-uniform data)
+  if (!live || !(acc[NQ - 1] > 0.0)) return;
+  // Cholesky of Q = M'KM + 1e-3 I, this lane's own system
   double Lc[NM * NM];
   {
     double Q[NM * NM];
@@ -148,36 +187,31 @@ __global__ __launch_bounds__(64) void lmpc_regress_kernel(int N, int B, lmpc_reg
       for (int k = r + 1; k < NM; ++k) tt -= Lc[k * NM + r] * R[k];
       R[r] = tt * Lc[r * NM + r];
     }
-    // lane f adds coefficient f of row spec.out[o]
-    const int row = spec.out[o];
-    double val = 0.0;
+    const int rowo = spec.out[o];
 #pragma unroll
-    for (int f = 0; f < NM; ++f)
-      if (f == lane) val = R[f];
-    if (lane < NM) {
-      if (lane < NF) {
-        const int col = lane < ns ? spec.in_state[lane] : 6 + spec.in_ctrl[lane - ns];  // column of [A B]
+    for (int f = 0; f < NM; ++f) {
+      if (f < NF) {
+        const int col = f < ns ? spec.in_state[f] : 6 + spec.in_ctrl[f - ns];  // column of [A B]
         if (WS_LAYOUT)
-          outA[((size_t)b * NS + i) * LMPC_LIN_RECORD + col * 6 + row] += val;
+          outA[((size_t)b * NS + i) * LMPC_LIN_RECORD + col * 6 + rowo] += R[f];
         else if (col < 6)
-          outA[((size_t)(row * 6 + col) * NS + i) * B + b] += val;
+          outA[((size_t)(rowo * 6 + col) * NS + i) * B + b] += R[f];
         else
-          outB[((size_t)(row * 2 + (col - 6)) * NS + i) * B + b] += val;
+          outB[((size_t)(rowo * 2 + (col - 6)) * NS + i) * B + b] += R[f];
       } else {
         if (WS_LAYOUT)
-          outA[((size_t)b * NS + i) * LMPC_LIN_RECORD + 48 + row] += val;
+          outA[((size_t)b * NS + i) * LMPC_LIN_RECORD + 48 + rowo] += R[f];
         else
-          outg[((size_t)row * NS + i) * B + b] += val;
+          outg[((size_t)rowo * NS + i) * B + b] += R[f];
       }
     }
   }
 }
 
-template __global__ void lmpc_regress_kernel<5, 3, true>(int, int, lmpc_regression_spec, int, const int*, const double*, const double*,
-                                                         const double*, const double*, const double*, double*, double*, double*);
-template __global__ void lmpc_regress_kernel<5, 3, false>(int, int, lmpc_regression_spec, int, const int*, const double*, const double*,
-                                                          const double*, const double*, const double*, double*, double*, double*);
-template __global__ void lmpc_regress_kernel<8, 6, true>(int, int, lmpc_regression_spec, int, const int*, const double*, const double*,
-                                                         const double*, const double*, const double*, double*, double*, double*);
-template __global__ void lmpc_regress_kernel<8, 6, false>(int, int, lmpc_regression_spec, int, const int*, const double*, const double*,
-                                                          const double*, const double*, const double*, double*, double*, double*);
+#define LMPC_REG_INSTANTIATE(NF, NOUT, WS)                                                                                    \
+  template __global__ void lmpc_regress_kernel<NF, NOUT, WS>(int, int, lmpc_regression_spec, int, const double*, const double*, \
+                                                             const double*, double*, double*, double*);
+LMPC_REG_INSTANTIATE(5, 3, true)
+LMPC_REG_INSTANTIATE(5, 3, false)
+LMPC_REG_INSTANTIATE(8, 6, true)
+LMPC_REG_INSTANTIATE(8, 6, false)
