@@ -914,11 +914,13 @@ __device__ void riccati_factor(const Lds<real>& L, int lane, const ptreal* PT) {
 // running vector makes one trip through LDS (one write, broadcast b128 reads), the 2-vector a stage
 // condenses to (B'p, du) is spread with v_readlane, and the stage operands are fetched one stage ahead.
 // Lanes >= 8 NRHS mirror lanes below and write to dead cells of the factor work matrices.
-template <int NRHS, typename real>
+// NP > 1 (lmpc_solve_kernel_g4): the wave carries the sweeps of NP problems at once -- lane (p, s, r), L.base is then a
+// per-lane value (problem p's records) and the 2-vector spread stays inside a group of 8 lanes for either NRHS.
+template <int NRHS, int NP = 1, typename real>
 __device__ void riccati_solve(const Lds<real>& L, int lane, Prof& pf) {
   const int N = L.N;
   const int r = lane & 7, s = (lane >> 3) & (NRHS - 1);
-  const bool own = lane < 8 * NRHS;
+  const bool own = lane < 8 * NRHS * NP;
   const int reg = KN_R0 + 10 * s;
   real* T = L.tail();
   real* const junk0 = T + TL_W + lane;  // 64 + 64 dead cells: W (80) and Y (80) are contiguous
@@ -926,7 +928,7 @@ __device__ void riccati_solve(const Lds<real>& L, int lane, Prof& pf) {
   real* const pvec = T + TL_PV + 8 * s;
   real* const pdst = own ? pvec + r : junk0;
   auto spread2 = [&](real v, real& a, real& b) {  // values of lanes (s, 6) and (s, 7) to the whole group
-    if constexpr (NRHS == 2) {
+    if constexpr (NRHS == 2 || NP > 1) {
       a = group_bcast<0x00D8>(v);
       b = group_bcast<0x00F8>(v);
     } else {

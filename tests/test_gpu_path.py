@@ -871,3 +871,24 @@ def test_zero_components_of_the_hull_slack_weight_on_the_device(pkg, golden):
     preset["convex_hull_slack"] = [0.0] * 6
     with pytest.raises(pkg.LmpcError, match="hard convex-hull equality"):
         pkg.Solver(preset, pkg.presets.barc_vehicle(), device=0)
+
+
+def test_grouped_kernel_matches_the_golden_vectors_and_the_default_kernel(pkg, golden, monkeypatch):
+    """lmpc_solve_kernel_g4 (opt-in, LMPC_GROUPED=1 at lmpc_create: four problems per workgroup, one wave runs the Riccati
+    vector sweeps of all four) is the same algorithm per problem: the golden vectors to the contract, the default kernel's
+    answers to the twin tolerance, and a batch that does not fill its last group (6 = 4 + 2: two surplus waves)."""
+    g = golden("qp_barc_tracking_n20")
+    veh, cfg, solver, *_ = make(pkg, "barc20", 1, 0)
+    base = to_np(solver.solve(g))
+    monkeypatch.setenv("LMPC_GROUPED", "1")
+    grouped = pkg.Solver(pkg.presets.barc_tracking_mpc(20), pkg.presets.barc_vehicle(), device=0)
+    monkeypatch.delenv("LMPC_GROUPED")
+    out = to_np(grouped.solve(g))
+    assert_contract(out, g, g["margin"], g["certified"], who="grouped kernel")
+    assert_same_iterations(out["iters"], base["iters"])
+    for k, sc, tol in (("X_optm", P.SCALE_X, TOL_TWIN), ("U_optm", P.SCALE_U, TOL_TWIN), ("dU_optm", P.SCALE_U, TOL_DU)):
+        assert scaled_err(out[k], base[k], sc) < tol, k
+    six = {k: (v[..., :6].copy() if isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[-1] == g["x_ic"].shape[-1] else v) for k, v in g.items()}
+    o6 = to_np(grouped.solve(six))
+    assert (o6["status"] == 0).all()
+    assert np.array_equal(o6["X_optm"], out["X_optm"][..., :6]) and np.array_equal(o6["iters"], out["iters"][:6])
