@@ -32,6 +32,7 @@
 #include <hip/hip_runtime.h>
 
 #include <type_traits>
+#include <utility>
 
 #include "lmpc_device.h"
 
@@ -905,19 +906,151 @@ __device__ void riccati_factor(const Lds<real>& L, int lane, const ptreal* PT) {
   }
 }
 
+// Lanes 0..CNT-1 (or 6 and 7) of every 16-lane row to the whole row (DPP row_newbcast, gfx90a+; v_mov_b64_dpp for
+// doubles): register-to-register broadcasts.  Written as one asm block per group: through __builtin_amdgcn_update_dpp the
+// tied "old" operand costs a v_mov of a constant per broadcast, a fifth of the sweeps' VALU instructions.  The block opens
+// with the two wait states a DPP read of a just-written VGPR needs (the hazard recogniser does not look inside asm).
+#define LMPC_DPP64(K) "v_mov_b64_dpp %" #K ", %[src] row_newbcast:" #K " row_mask:0xf bank_mask:0xf\n\t"
+#define LMPC_DPP32(K) "v_mov_b32_dpp %" #K ", %[src] row_newbcast:" #K " row_mask:0xf bank_mask:0xf\n\t"
+__device__ __forceinline__ void row_bcast6(double v, double (&o)[6]) {
+  asm("s_nop 1\n\t" LMPC_DPP64(0) LMPC_DPP64(1) LMPC_DPP64(2) LMPC_DPP64(3) LMPC_DPP64(4) LMPC_DPP64(5)
+      : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5])
+      : [src] "v"(v));
+}
+__device__ __forceinline__ void row_bcast6(float v, float (&o)[6]) {
+  asm("s_nop 1\n\t" LMPC_DPP32(0) LMPC_DPP32(1) LMPC_DPP32(2) LMPC_DPP32(3) LMPC_DPP32(4) LMPC_DPP32(5)
+      : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5])
+      : [src] "v"(v));
+}
+__device__ __forceinline__ void row_bcast8(double v, double (&o)[8]) {
+  asm("s_nop 1\n\t" LMPC_DPP64(0) LMPC_DPP64(1) LMPC_DPP64(2) LMPC_DPP64(3) LMPC_DPP64(4) LMPC_DPP64(5) LMPC_DPP64(6) LMPC_DPP64(7)
+      : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7])
+      : [src] "v"(v));
+}
+__device__ __forceinline__ void row_bcast8(float v, float (&o)[8]) {
+  asm("s_nop 1\n\t" LMPC_DPP32(0) LMPC_DPP32(1) LMPC_DPP32(2) LMPC_DPP32(3) LMPC_DPP32(4) LMPC_DPP32(5) LMPC_DPP32(6) LMPC_DPP32(7)
+      : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7])
+      : [src] "v"(v));
+}
+__device__ __forceinline__ void row_bcast67(double v, double& a, double& b) {  // lanes 6 and 7
+  asm("s_nop 1\n\t"
+      "v_mov_b64_dpp %0, %[src] row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+      "v_mov_b64_dpp %1, %[src] row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+      : "=&v"(a), "=&v"(b)
+      : [src] "v"(v));
+}
+__device__ __forceinline__ void row_bcast67(float v, float& a, float& b) {
+  asm("s_nop 1\n\t"
+      "v_mov_b32_dpp %0, %[src] row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+      "v_mov_b32_dpp %1, %[src] row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+      : "=&v"(a), "=&v"(b)
+      : [src] "v"(v));
+}
+
 // Riccati vector solve for NRHS (1 or 2) right-hand sides held in the knots' rhs regions
 // (q_z @ +0..7, q_v @ +8,9 of region s); the step (dz, dv) overwrites them.  dz_0 = 0.
 //
-// Both sweeps are strictly serial over the knots and organised for latency and for few VALU issues:
-// lane (s, r) = ((lane >> 3) % NRHS, lane & 7) carries component r of right-hand side s, so the
-// predictor step and the boundary-slack Schur vector share one instruction stream.  Per stage the
-// running vector makes one trip through LDS (one write, broadcast b128 reads), the 2-vector a stage
-// condenses to (B'p, du) is spread with v_readlane, and the stage operands are fetched one stage ahead.
-// Lanes >= 8 NRHS mirror lanes below and write to dead cells of the factor work matrices.
+// Both sweeps are strictly serial over the knots: one dependent chain of N - 1 stages each, and the chain's length, not
+// the instruction count, is what a solve waits for.  Lane (s, r) = ((lane >> 4) % NRHS, lane & 7): each right-hand side
+// has a 16-lane DPP row of its own (lanes 8..15 of a row, and the rows above NRHS, mirror lanes below and write to dead
+// cells), the running vector lives in ONE register per lane, and a stage gets the other components by row_newbcast --
+// nothing on the chain goes through LDS (it did until round 2: one write + broadcast reads per stage, and a ds_swizzle
+// for the condensed 2-vector; ~400 cycles per stage under load).  Stage operands are fetched one stage ahead; the
+// results a stage leaves behind (kff, dz, dv) are stored off the chain.
+template <int NRHS, typename real>
+__device__ void riccati_solve(const Lds<real>& L, int lane, Prof& pf) {
+  const int N = L.N;
+  const int r = lane & 7, s = (lane >> 4) & (NRHS - 1);
+  const bool own = (lane & 8) == 0 && lane < 16 * NRHS;
+  const int reg = KN_R0 + 10 * s;
+  real* T = L.tail();
+  real* const junk0 = T + TL_W + lane;  // 64 + 64 dead cells: W (80) and Y (80) are contiguous
+  real* const junk1 = T + TL_W + 80 + lane;
+  const real m6 = (r >= 6) ? real(1) : real(0);  // rows 6, 7 (the input rows of z) take an extra term: a multiplier, not a select
+  // kff = H^-1 hv: lane r = 0 takes row (h00, h01), the others row (h01, h11) -- picked by the address, not by a select
+  const int o_ha = r == 0 ? ST_HI : ST_HI + 1, o_hb = r == 0 ? ST_HI + 1 : ST_HI11;
+  // ---- backward: p_i = q_i + Abar' p_{i+1} - K' (q_v + Bbar' p_{i+1});  kff_i = H^-1 (q_v + Bbar' p_{i+1})
+  real p = L.kn(N - 1)[reg + r];
+  real row[6];  // [A B](:, r), fetched one stage ahead
+  {
+    const real* st = L.st(N - 2);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) row[k] = st[ST_ROW(r) + k];
+  }
+  for (int i = N - 2; i >= 0; --i) {
+    real* st = L.st(i);
+    const real* kn = L.kn(i);
+    const real k0r = st[ST_ROW(r) + 6], k1r = st[ST_ROW(r) + 7], t = st[ST_DT];
+    const real qz = kn[reg + r], qv0 = kn[reg + 8], qv1 = kn[reg + 9];
+    const real ha = st[o_ha], hb = st[o_hb];
+    real pb[6];
+    row_bcast6(p, pb);
+    real w = m6 * p;  // w = Abar' p: rows 6,7 also take p_u
+#pragma unroll
+    for (int k = 0; k < 6; ++k) w = rfma(row[k], pb[k], w);
+    real w6, w7;
+    row_bcast67(w, w6, w7);
+    {
+      const real* stn = L.st(i > 0 ? i - 1 : 0);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) row[k] = stn[ST_ROW(r) + k];
+    }
+    const real hv0 = rfma(t, w6, qv0);
+    const real hv1 = rfma(t, w7, qv1);
+    p = qz + w - (k0r * hv0 + k1r * hv1);  // (not used after stage 0)
+    const real kff = ha * hv0 + hb * hv1;
+    *((own && r < 2) ? st + ST_KFF(s) + r : junk1) = kff;
+  }
+  wave_sync();
+  PT_MARK(8 + NRHS - 1)
+  // ---- forward: dv_i = -kff_i - K dz_i,  dz_{i+1} = Abar dz_i + Bbar dv_i
+  // lanes r < 6 take a state row, lanes 6, 7 the two rows of K: column k of M is [A B](:, k) | K(:, k)
+  *(own ? L.kn(0) + reg + r : junk0) = 0.0;
+  real d = 0.0;     // component r of dz_i
+  real col[8], a0;  // M(r, :) and the feed-forward term, fetched one stage ahead
+  {
+    const real* st = L.st(0);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) col[k] = st[ST_ROW(k) + r];
+    a0 = st[ST_KFF(s) + (r & 1)];
+  }
+  for (int i = 0; i < N - 1; ++i) {
+    const real* st = L.st(i);
+    real* kn = L.kn(i);
+    const real b0 = st[ST_ROW(6) + r], b1 = st[ST_ROW(7) + r], t = st[ST_DT];
+    real dz[8];
+    row_bcast8(d, dz);
+    real acc = m6 * a0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) acc = rfma(col[k], dz[k], acc);
+    const real ax = acc;  // state rows: A dz_x
+    acc = rfma(col[6], dz[6], acc);
+    acc = rfma(col[7], dz[7], acc);
+    const real dv = -acc;  // lanes 6, 7
+    const real du = rfma(t, dv, d);  // (lanes 6, 7: their own component of dz is u_{i-1})
+    real du0, du1;
+    row_bcast67(du, du0, du1);
+    {
+      const real* stn = L.st(i < N - 2 ? i + 1 : i);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) col[k] = stn[ST_ROW(k) + r];
+      a0 = stn[ST_KFF(s) + (r & 1)];
+    }
+    const real nx = rfma(b1, du1, rfma(b0, du0, ax));
+    d = (r < 6) ? nx : du;
+    *(own ? kn + LMPC_KNOT_STRIDE + reg + r : junk0) = d;
+    *((own && r >= 6) ? kn + reg + 2 + r : junk1) = dv;
+  }
+  wave_sync();
+  PT_MARK(10 + NRHS - 1)
+}
+
+// The same solve with the running vector exchanged through LDS (what riccati_solve did until round 2): kept for the grouped
+// kernel, whose lanes (problem, rhs, component) do not fit one right-hand side per DPP row.
 // NP > 1 (lmpc_solve_kernel_g4): the wave carries the sweeps of NP problems at once -- lane (p, s, r), L.base is then a
 // per-lane value (problem p's records) and the 2-vector spread stays inside a group of 8 lanes for either NRHS.
 template <int NRHS, int NP = 1, typename real>
-__device__ void riccati_solve(const Lds<real>& L, int lane, Prof& pf) {
+__device__ void riccati_solve_lds(const Lds<real>& L, int lane, Prof& pf) {
   const int N = L.N;
   const int r = lane & 7, s = (lane >> 3) & (NRHS - 1);
   const bool own = lane < 8 * NRHS * NP;

@@ -27,7 +27,6 @@ __global__ __launch_bounds__(256, 2) void lmpc_solve_kernel_g4(
   const int N = P.N, NS = N - 1;
   typedef typename vec2<real>::type real2;
   typedef double treal;
-  constexpr int KS = 0;
   typedef ipm_limits<real> lim;
   const real inf = real(INFINITY), marg = real(P.marg), qsig = real(P.qsig), tol = lim::tol(P.tol);
   const io s_shift = io(0);
@@ -263,7 +262,7 @@ __global__ __launch_bounds__(256, 2) void lmpc_solve_kernel_g4(
     }
 
     real sigc = 0.0, alpha = 1.0, dsigma = 0.0;
-    bool numerics_failed = false, stalled = false;
+    bool stalled = false;
     real d_val[KQ];
     const int npass = ipm ? 2 : 1;
     for (int pass = 0; pass < npass; ++pass) {
@@ -315,10 +314,10 @@ __global__ __launch_bounds__(256, 2) void lmpc_solve_kernel_g4(
       if (wv == (solves & 3)) {
         if (pass == 0 && ipm && has_sigma) {
           const Lds<real> Lp{lds_group + (lane >> 4) * PBD, N};
-          riccati_solve<2, 4>(Lp, lane, pf);
+          riccati_solve_lds<2, 4>(Lp, lane, pf);
         } else {
           const Lds<real> Lp{lds_group + ((lane >> 3) & 3) * PBD, N};
-          riccati_solve<1, 4>(Lp, lane, pf);
+          riccati_solve_lds<1, 4>(Lp, lane, pf);
         }
       }
       ++solves;
@@ -359,12 +358,6 @@ __global__ __launch_bounds__(256, 2) void lmpc_solve_kernel_g4(
         dsigma = uni(-(qsg + red[0]) / (hsig + ce));
       }
       // ======== row steps; largest feasible step as 1 / max(1, max -dt/t, max -dlam/lam) ========
-      auto row_step = [&](bool on, treal t, treal lam, treal pprod, treal rd, treal cdy, treal& dt_, treal& dl_,
-                          treal& it_) {  // (the simplex rows: always fp64)
-        it_ = frcp(t);
-        dt_ = on ? (-rd - cdy) : 0.0;
-        dl_ = on ? (-lam + (treal(smu) - treal(pm) * pprod) * it_ - lam * it_ * dt_) : 0.0;
-      };
       real dtu[KQ], dlu[KQ], dtl[KQ], dll[KQ];
       real rmax = 1.0;
       bool finite_step = true;
@@ -391,7 +384,6 @@ __global__ __launch_bounds__(256, 2) void lmpc_solve_kernel_g4(
       if (!(rmax < inf) || !(dsigma == dsigma)) {
         // a Newton step that is not a number (the Schur complement of sigma or the 2x2 H cancelled completely -- in
         // practice single precision on its last iteration): keep the iterate, report it by what it has reached
-        numerics_failed = true;
         status = (mu <= real(10) * tol && rdmax <= lim::rd_ok) ? LMPC_SOLVE_OPTIMAL : LMPC_SOLVE_MAX_ITER;
         done = true;
         it_done = it;

@@ -6,9 +6,14 @@ if len(sys.argv) > 2 and sys.argv[1] == "child":
     sys.path.insert(0, "/root/repo")
     from __graft_entry__ import load_package
     pkg = load_package()
+    import importlib
+    capi = importlib.import_module(pkg.__name__ + ".capi")
+    _orig = capi.library_path
+    capi.library_path = lambda: _orig().with_name(os.environ.get("LMPC_LIB", "liblmpc_hip.so"))
     B = int(sys.argv[3])
+    NH = int(os.environ.get("LMPC_N", "20"))
     tr = pkg.workloads.synthetic_track("barc")
-    solver = pkg.Solver(pkg.presets.barc_tracking_mpc(20), pkg.presets.barc_vehicle(), device=0)
+    solver = pkg.Solver(pkg.presets.barc_tracking_mpc(NH), pkg.presets.barc_vehicle(), device=0)
     P = solver.config
     u_lo = [max(P["u_min"][0], -0.015), max(P["u_min"][1], -0.314159)]
     u_hi = [min(P["u_max"][0], 0.015), min(P["u_max"][1], 0.314159)]
@@ -42,9 +47,12 @@ if len(sys.argv) > 2 and sys.argv[1] == "child":
     sys.exit(0)
 B = sys.argv[1] if len(sys.argv) > 1 else "4096"
 outs = []
-for gflag in ("0", "1"):
-    o = "/tmp/g4_%s.npz" % gflag
-    subprocess.run([sys.executable, __file__, "child", o, B], env=dict(os.environ, LMPC_GROUPED=gflag), check=True)
+# default: grouped against ungrouped kernel of the current library; "libs": the base build against the current one
+variants = [dict(LMPC_GROUPED="0"), dict(LMPC_GROUPED="1")] if len(sys.argv) < 3 else [dict(LMPC_LIB="liblmpc_hip_base.so"), dict(LMPC_LIB="liblmpc_hip.so")]
+for k, v in enumerate(variants):
+    o = "/tmp/g4_%d.npz" % k
+    print(v)
+    subprocess.run([sys.executable, __file__, "child", o, B], env=dict(os.environ, **v), check=True)
     outs.append(np.load(o))
 for n in outs[0].files:
     a, b = outs[0][n], outs[1][n]
