@@ -745,6 +745,9 @@ __device__ void riccati_factor(const Lds<real>& L, int lane, const ptreal* PT) {
   real* MY = T + TL_Y;
   const real* ct = T + TL_CT;
   const bool diag = r == c;
+  // per-lane 0/1 multipliers instead of selects (exact: the products are the operand or zero)
+  const real m_diag = diag ? real(1) : real(0), m_r1 = r == 1 ? real(1) : real(0);
+  const real m_r6 = r >= 6 ? real(1) : real(0), m_c6 = c >= 6 ? real(1) : real(0);
   const real qmid = qz_entry(ct, false, r, c);
   real pown;
   {
@@ -795,7 +798,7 @@ __device__ void riccati_factor(const Lds<real>& L, int lane, const ptreal* PT) {
     // phase-3 operands of this stage, queued behind the P row
     const real t = st[ST_DT], thr = kn[KN_R0 + r], ey = kn[KN_EY], thv0 = kn[KN_R0 + 8], thv1 = kn[KN_R0 + 9];
     ISSUE_ORDER();
-    real w = (r >= 6) ? pown : 0.0;
+    real w = m_r6 * pown;
 #pragma unroll
     for (int k = 0; k < 6; ++k) w += ar[k] * pr[k];
     MW[r * MROW + c] = w;
@@ -804,7 +807,7 @@ __device__ void riccati_factor(const Lds<real>& L, int lane, const ptreal* PT) {
     real wr[6];
 #pragma unroll
     for (int k = 0; k < 6; ++k) wr[k] = MW[r * MROW + k];
-    real y = (c >= 6) ? w : 0.0;
+    real y = m_c6 * w;
 #pragma unroll
     for (int k = 0; k < 6; ++k) y += wr[k] * ac[k];
     MY[r * MROW + c] = y;
@@ -896,8 +899,8 @@ __device__ void riccati_factor(const Lds<real>& L, int lane, const ptreal* PT) {
     } else {
       pn = qmid + y - t * (y6r * k0c + y7r * k1c);
     }
-    const real th = thr + (r == 1 ? ey : real(0));
-    if (diag) pn += th;
+    const real th = rfma(m_r1, ey, thr);
+    pn = rfma(m_diag, th, pn);
     *p_dst0 = pn;  // (not used after stage 0)
     *p_dst1 = pn;
     const real res = lane < 8 ? k0c : (lane < 16 ? k1c : (lane == 16 ? hi00 : (lane == 17 ? hi01 : hi11)));
