@@ -204,14 +204,29 @@ struct op_min {
 template <class OP, int NV, typename real>
 __device__ __forceinline__ void wave_reduce_n(real (&v)[NV]) {
   const real id = OP::template id<real>();
+  // the rotations write every lane, so their "old" operand is a don't-care: handing them the previous stage's (dead)
+  // exchange value instead of the identity saves the two v_mov that would materialise it, per value and stage
+  real x[NV];
 #pragma unroll
-  for (int k = 0; k < NV; ++k) v[k] = OP::f(v[k], dpp_move<DPP_ROW_ROR(8), 0xf>(v[k], id));
+  for (int k = 0; k < NV; ++k) {
+    x[k] = dpp_move<DPP_ROW_ROR(8), 0xf>(v[k], id);
+    v[k] = OP::f(v[k], x[k]);
+  }
 #pragma unroll
-  for (int k = 0; k < NV; ++k) v[k] = OP::f(v[k], dpp_move<DPP_ROW_ROR(4), 0xf>(v[k], id));
+  for (int k = 0; k < NV; ++k) {
+    x[k] = dpp_move<DPP_ROW_ROR(4), 0xf>(v[k], x[k]);
+    v[k] = OP::f(v[k], x[k]);
+  }
 #pragma unroll
-  for (int k = 0; k < NV; ++k) v[k] = OP::f(v[k], dpp_move<DPP_ROW_ROR(2), 0xf>(v[k], id));
+  for (int k = 0; k < NV; ++k) {
+    x[k] = dpp_move<DPP_ROW_ROR(2), 0xf>(v[k], x[k]);
+    v[k] = OP::f(v[k], x[k]);
+  }
 #pragma unroll
-  for (int k = 0; k < NV; ++k) v[k] = OP::f(v[k], dpp_move<DPP_ROW_ROR(1), 0xf>(v[k], id));
+  for (int k = 0; k < NV; ++k) {
+    x[k] = dpp_move<DPP_ROW_ROR(1), 0xf>(v[k], x[k]);
+    v[k] = OP::f(v[k], x[k]);
+  }
 #pragma unroll
   for (int k = 0; k < NV; ++k) v[k] = OP::f(v[k], dpp_move<DPP_ROW_BCAST15, 0xa>(v[k], id));
 #pragma unroll
