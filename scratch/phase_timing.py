@@ -12,6 +12,7 @@ capi._LIB = None
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 LMPC = len(sys.argv) > 3 and sys.argv[3] == "lmpc"
+MIXED = len(sys.argv) > 4 and sys.argv[4] == "mixed"
 tr = pkg.workloads.synthetic_track("barc")
 kw = {}
 if LMPC:
@@ -33,7 +34,7 @@ if LMPC:
 out = solver.alloc_outputs(B)
 out["kkt"] = torch.zeros((20, B), dtype=torch.float64, device="cuda")
 for _ in range(3):
-    solver.solve(inp, out, **kw)
+    solver.solve(inp, out, mixed=MIXED, **kw)
 torch.cuda.synchronize()
 k = out["kkt"].cpu().numpy()
 it = out["iters"].cpu().numpy()
