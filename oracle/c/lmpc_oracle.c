@@ -419,6 +419,8 @@ static inline double slot_val(double (*z)[8], double (*v)[2], int i, int sl) {
  * damped the step of exactly the points that matter, so problems with two or three supporting points crawled or stalled,
  * and at IAC scale the iterate stopped 1e-3 .. 1e-2 from the optimum with mu -> 0.) */
 /* complementarity below which the factorisation switches to the stabilised form (riccati_factor) */
+#define NBHD_GAMMA 1e-2
+#define NBHD_TRIALS 3
 #ifndef JOSEPH_MU
 #define JOSEPH_MU 1e-8
 #endif
@@ -919,6 +921,8 @@ static int ipm_solve(prob_t* p, work_t* w, int* iters_out, double* kkt_out) {
   double mu = 0.0, rdmax = 0.0, rd_check = 0.0;
 
   /* ================= phase 1: interior point ================= */
+  int distress = 0; /* the complementarity has gone up once: the wide-neighbourhood rule applies from then on */
+  double mu_prev = INFINITY;
   for (it = 0; it <= p->max_iter; ++it) {
     double musum = 0.0;
     rdmax = 0.0;
@@ -939,6 +943,9 @@ static int ipm_solve(prob_t* p, work_t* w, int* iters_out, double* kkt_out) {
       w->thl[j] = p->ll[j] / p->tl[j];
     }
     mu = musum / m;
+    /* (see the step-length rule; far from feasibility mu may rise legitimately) */
+    if (it >= 1 && mu >= mu_prev && rdmax <= 1e-6) distress = 1;
+    mu_prev = mu;
     if (!(mu == mu) || !(rdmax == rdmax)) {
       status = LMPC_SOLVE_INFEASIBLE;
       break;
@@ -1026,17 +1033,36 @@ static int ipm_solve(prob_t* p, work_t* w, int* iters_out, double* kkt_out) {
       } else {
         alpha = tau * amax;
         if (alpha > 1.0) alpha = 1.0;
+        /* For a problem whose mu has risen once (distress): cut the step back until no complementarity product falls
+         * below NBHD_GAMMA times their mean (the wide neighbourhood of the central path).  Without it Mehrotra's iteration can leave the neighbourhood and cycle:
+         * seen on a learning problem whose safe set offers two nearly exchangeable points (products at 0.01 and 300
+         * times mu, mu bouncing between 6e-6 and 2e-5 up to the iteration cap while the dense solver finds the
+         * optimum; 19 iterations with the rule).  1e-3 does not stop that cycle.  Problems whose mu falls monotonically
+         * never take the cut.  The same rule as the kernel. */
+        double s = 0.0;
+        for (int trial = 0;; ++trial) {
+          double pmin = INFINITY;
+          s = 0.0;
+          for (int i = 0; i < N; ++i)
+            for (int sl = 0; sl < NSLOT; ++sl)
+              for (int sd = 0; sd < 2; ++sd)
+                if (p->act[i][sl][sd]) {
+                  const double pr = (p->t[i][sl][sd] + alpha * p->dtt[i][sl][sd]) * (p->lam[i][sl][sd] + alpha * p->dlam[i][sl][sd]);
+                  s += pr;
+                  if (pr < pmin) pmin = pr;
+                }
+          for (int j = 0; j < S; ++j) {
+            const double pr = (p->tl[j] + alpha * p->dtl[j]) * (p->ll[j] + alpha * p->dll[j]);
+            s += pr;
+            if (pr < pmin) pmin = pr;
+          }
+          if (!distress || trial == NBHD_TRIALS || pmin >= NBHD_GAMMA * s / m) break;
+          alpha *= 0.6;
+        }
         /* no further progress: with the rows feasible and the complementarity already small, a corrector step that
          * would not lower it (the Newton direction has reached the accuracy of the factorisation; seen on learning
          * problems whose speed rides its bound over most of the horizon) ends the solve at the current iterate
          * instead of letting mu wander upwards until the iteration cap */
-        double s = 0.0;
-        for (int i = 0; i < N; ++i)
-          for (int sl = 0; sl < NSLOT; ++sl)
-            for (int sd = 0; sd < 2; ++sd)
-              if (p->act[i][sl][sd])
-                s += (p->t[i][sl][sd] + alpha * p->dtt[i][sl][sd]) * (p->lam[i][sl][sd] + alpha * p->dlam[i][sl][sd]);
-        for (int j = 0; j < S; ++j) s += (p->tl[j] + alpha * p->dtl[j]) * (p->ll[j] + alpha * p->dll[j]);
         if (rdmax <= 1e-9 && mu <= STALL_MU && s / m >= mu) stalled = 1;
       }
     }

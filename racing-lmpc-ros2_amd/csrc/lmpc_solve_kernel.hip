@@ -122,6 +122,10 @@ struct Prof {};
 #define MA_MAX 4       // explicit points at most (the smallest theta below tau); supports of 1-3 points are what occurs
 #define TAU_REL 1e-5   // tau = TAU_REL * max_j u_j'E u_j: cond(F_B) <= ~1e5 whatever the iteration does
 #define STALL_MU 1e-9  // complementarity below which a step that does not lower it ends the solve
+#define NBHD_GAMMA 1e-2  // once mu has risen: no complementarity product below this fraction of their mean after a step (1e-3
+                        // does not stop the cycle the rule is there for; applied to every problem 3e-2 costs 13 % more iterations)
+#define NBHD_TRIALS 3   // cuts of the step length by 0.6 at most (two are what the cycling problem needs; bounded so that a point already
+                        // outside the neighbourhood cannot freeze the iteration)
 #define F_UP 1
 #define F_LO 2
 #define F_SIG 4
@@ -343,10 +347,12 @@ template <typename real> struct ipm_limits;
 template <> struct ipm_limits<double> {
   static __device__ __forceinline__ double tol(double cfg) { return cfg; }
   static constexpr double rd_ok = 1e-9, rd_infeasible = 1e-6, tiny = 1e-300;
+  static constexpr double rd_distress = 1e-6;  // a rise of mu counts as distress only in the (nearly) feasible end game
 };
 template <> struct ipm_limits<float> {
   static __device__ __forceinline__ float tol(double cfg) { return fmaxf((float)cfg, 2e-6f); }
   static constexpr float rd_ok = 1e-4f, rd_infeasible = 1e-2f, tiny = 1e-30f;
+  static constexpr float rd_distress = 1e-4f;
 };
 template <typename real> struct vec2;
 template <> struct vec2<double> { typedef double2 type; };
@@ -1468,7 +1474,8 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
 
   const real tau = 0.995, mu0 = 0.1, thr_frac = 0.5;
   int status = LMPC_SOLVE_MAX_ITER, it = 0;
-  real mu = 0.0, rdmax = 0.0, rd_check = 0.0, last_step = 0.0, hsig = 0.0, ce = 0.0;
+  real mu = 0.0, rdmax = 0.0, rd_check = 0.0, last_step = 0.0, hsig = 0.0, ce = 0.0, mu_prev = inf;
+  bool distress = false;
   const int max_iter = feasible ? P.max_iter : 0;
 
   // it == -1 is the start-point Newton step (all row weights zero, full step); it >= 0 the
@@ -1621,6 +1628,9 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
       rdmax = wave_max(rdl);
       hsig = uni(hsig);
       mu = uni(musum * inv_m);
+      // (see the step-length rule; far from feasibility mu may rise legitimately: IAC at 60 m/s into a corner)
+      if (it >= 1 && mu >= mu_prev && rdmax <= lim::rd_distress) distress = true;
+      mu_prev = mu;
       if (!(mu == mu) || !(rdmax == rdmax)) {
         status = LMPC_SOLVE_INFEASIBLE;
         break;
@@ -1862,39 +1872,75 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
         break;
       }
       const real amax = uni(real(1) / rmax);
-      if (pass == 1) alpha = uni(fmin(real(1), tau * amax));
       real sacc = 0.0;
+      if (pass == 0) {
 #pragma unroll
-      for (int q = 0; q < KQ; ++q) {
-        if (pass == 0) {
+        for (int q = 0; q < KQ; ++q) {
           sacc += (s_tu[q] + amax * dtu[q]) * (s_lu[q] + amax * dlu[q]) + (s_tl[q] + amax * dtl[q]) * (s_ll[q] + amax * dll[q]);
           s_pu[q] = dtu[q] * dlu[q];
           s_pl[q] = dtl[q] * dll[q];
-        } else {
+        }
+        if constexpr (KS > 0) {
+#pragma unroll
+          for (int q = 0; q < KS; ++q) {
+            treal dt_, dl_, it_;
+            row_step(sx.on[q], sx.t[q], sx.l[q], sx.p[q], -sx.lm[q] + sx.t[q], -sx.dl[q], dt_, dl_, it_);
+            sacc += sx.on[q] ? real((sx.t[q] + treal(amax) * dt_) * (sx.l[q] + treal(amax) * dl_)) : real(0);
+            sx.p[q] = dt_ * dl_;
+          }
+        }
+      } else {
+        alpha = uni(fmin(real(1), tau * amax));
+        if (distress) {
+          // A problem whose complementarity has gone UP once gets the wide-neighbourhood rule from then on: the step is
+          // cut back until no complementarity product falls below NBHD_GAMMA times their mean.  Mehrotra's iteration can
+          // otherwise leave the neighbourhood of the central path and cycle -- seen on a learning problem whose safe set
+          // offers two nearly exchangeable points: products at 0.01 and 300 times mu, mu bouncing between 6e-6 and 2e-5
+          // up to the iteration cap while the dense solver finds the optimum (19 iterations with the rule).  Problems
+          // whose mu falls monotonically (all but a few per thousand) never enter this branch.
+          for (int trial = 0; trial < NBHD_TRIALS; ++trial) {
+            real sl = 0.0, pmin = inf;
+#pragma unroll
+            for (int q = 0; q < KQ; ++q) {
+              const int f = flags(q);
+              const real pu = (s_tu[q] + alpha * dtu[q]) * (s_lu[q] + alpha * dlu[q]);
+              const real pl = (s_tl[q] + alpha * dtl[q]) * (s_ll[q] + alpha * dll[q]);
+              sl += pu + pl;  // (an absent row has lam = 0, d lam = 0: no contribution)
+              pmin = fmin(pmin, fmin((f & F_UP) ? pu : inf, (f & F_LO) ? pl : inf));
+            }
+            if constexpr (KS > 0) {
+#pragma unroll
+              for (int q = 0; q < KS; ++q) {
+                treal dt_, dl_, it_;
+                row_step(sx.on[q], sx.t[q], sx.l[q], sx.p[q], -sx.lm[q] + sx.t[q], -sx.dl[q], dt_, dl_, it_);
+                const real pr = real((sx.t[q] + treal(alpha) * dt_) * (sx.l[q] + treal(alpha) * dl_));
+                sl += sx.on[q] ? pr : real(0);
+                pmin = fmin(pmin, sx.on[q] ? pr : inf);
+              }
+            }
+            if (wave_min(pmin) >= real(NBHD_GAMMA) * wave_sum(sl) * inv_m) break;
+            alpha = uni(alpha * real(0.6));
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) {
           s_tu[q] += alpha * dtu[q];
           s_lu[q] += alpha * dlu[q];
           s_tl[q] += alpha * dtl[q];
           s_ll[q] += alpha * dll[q];
           sacc += s_tu[q] * s_lu[q] + s_tl[q] * s_ll[q];
         }
-      }
-      if constexpr (KS > 0) {
+        if constexpr (KS > 0) {
 #pragma unroll
-        for (int q = 0; q < KS; ++q) {
-          treal dt_, dl_, it_;
-          row_step(sx.on[q], sx.t[q], sx.l[q], sx.p[q], -sx.lm[q] + sx.t[q], -sx.dl[q], dt_, dl_, it_);
-          if (pass == 0) {
-            sacc += sx.on[q] ? real((sx.t[q] + treal(amax) * dt_) * (sx.l[q] + treal(amax) * dl_)) : real(0);
-            sx.p[q] = dt_ * dl_;
-          } else {
+          for (int q = 0; q < KS; ++q) {
+            treal dt_, dl_, it_;
+            row_step(sx.on[q], sx.t[q], sx.l[q], sx.p[q], -sx.lm[q] + sx.t[q], -sx.dl[q], dt_, dl_, it_);
             sx.t[q] += treal(alpha) * dt_;
             sx.l[q] += treal(alpha) * dl_;
             sx.lm[q] += treal(alpha) * sx.dl[q];
             sacc += sx.on[q] ? real(sx.t[q] * sx.l[q]) : real(0);
           }
         }
-      }
-      if (pass == 1) {
         // no further progress: rows feasible, complementarity already small, and the corrector step would not lower it
         // (the Newton direction has reached the accuracy of the factorisation): keep the current primal iterate
         sacc = wave_sum(sacc);

@@ -192,7 +192,8 @@ __global__ __launch_bounds__(256, 2) void lmpc_solve_kernel_g4(
   const real tau = 0.995, mu0 = 0.1, thr_frac = 0.5;
   int status = LMPC_SOLVE_MAX_ITER, it = 0, it_done = 0, solves = 0;
   bool done = false;  // this wave's problem has left the iteration (status and it_done are final)
-  real mu = 0.0, rdmax = 0.0, rd_check = 0.0, last_step = 0.0, hsig = 0.0, ce = 0.0;
+  real mu = 0.0, rdmax = 0.0, rd_check = 0.0, last_step = 0.0, hsig = 0.0, ce = 0.0, mu_prev = inf;
+  bool distress = false;
   const int max_iter = feasible ? P.max_iter : 0;
 
   // it == -1 is the start-point Newton step (all row weights zero, full step); it >= 0 the
@@ -232,6 +233,9 @@ __global__ __launch_bounds__(256, 2) void lmpc_solve_kernel_g4(
       rdmax = wave_max(rdl);
       hsig = uni(hsig);
       mu = uni(musum * inv_m);
+      // (see the step-length rule; far from feasibility mu may rise legitimately: IAC at 60 m/s into a corner)
+      if (it >= 1 && mu >= mu_prev && rdmax <= lim::rd_distress) distress = true;
+      mu_prev = mu;
       if (!(mu == mu) || !(rdmax == rdmax)) {
         status = LMPC_SOLVE_INFEASIBLE;
         done = true;
@@ -390,23 +394,45 @@ __global__ __launch_bounds__(256, 2) void lmpc_solve_kernel_g4(
         continue;
       }
       const real amax = uni(real(1) / rmax);
-      if (pass == 1) alpha = uni(fmin(real(1), tau * amax));
       real sacc = 0.0;
+      if (pass == 0) {
 #pragma unroll
-      for (int q = 0; q < KQ; ++q) {
-        if (pass == 0) {
+        for (int q = 0; q < KQ; ++q) {
           sacc += (s_tu[q] + amax * dtu[q]) * (s_lu[q] + amax * dlu[q]) + (s_tl[q] + amax * dtl[q]) * (s_ll[q] + amax * dll[q]);
           s_pu[q] = dtu[q] * dlu[q];
           s_pl[q] = dtl[q] * dll[q];
-        } else {
+        }
+      } else {
+        alpha = uni(fmin(real(1), tau * amax));
+        if (distress) {
+          // A problem whose complementarity has gone UP once gets the wide-neighbourhood rule from then on: the step is
+          // cut back until no complementarity product falls below NBHD_GAMMA times their mean.  Mehrotra's iteration can
+          // otherwise leave the neighbourhood of the central path and cycle -- seen on a learning problem whose safe set
+          // offers two nearly exchangeable points: products at 0.01 and 300 times mu, mu bouncing between 6e-6 and 2e-5
+          // up to the iteration cap while the dense solver finds the optimum (19 iterations with the rule).  Problems
+          // whose mu falls monotonically (all but a few per thousand) never enter this branch.
+          for (int trial = 0; trial < NBHD_TRIALS; ++trial) {
+            real sl = 0.0, pmin = inf;
+#pragma unroll
+            for (int q = 0; q < KQ; ++q) {
+              const int f = flags(q);
+              const real pu = (s_tu[q] + alpha * dtu[q]) * (s_lu[q] + alpha * dlu[q]);
+              const real pl = (s_tl[q] + alpha * dtl[q]) * (s_ll[q] + alpha * dll[q]);
+              sl += pu + pl;  // (an absent row has lam = 0, d lam = 0: no contribution)
+              pmin = fmin(pmin, fmin((f & F_UP) ? pu : inf, (f & F_LO) ? pl : inf));
+            }
+            if (wave_min(pmin) >= real(NBHD_GAMMA) * wave_sum(sl) * inv_m) break;
+            alpha = uni(alpha * real(0.6));
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) {
           s_tu[q] += alpha * dtu[q];
           s_lu[q] += alpha * dlu[q];
           s_tl[q] += alpha * dtl[q];
           s_ll[q] += alpha * dll[q];
           sacc += s_tu[q] * s_lu[q] + s_tl[q] * s_ll[q];
         }
-      }
-      if (pass == 1) {
         // no further progress: rows feasible, complementarity already small, and the corrector step would not lower it
         // (the Newton direction has reached the accuracy of the factorisation): keep the current primal iterate
         sacc = wave_sum(sacc);

@@ -117,3 +117,30 @@ def test_learning_solve_with_the_regression_switched_on(pkg, mixed):
     assert np.abs(with_reg["X_optm"] - base["X_optm"])[:, :, ok].max() > 1e-4     # the corrected model reaches the QP
     again = _solve(sv, inp, ss_x, ss_j, mixed)
     assert np.array_equal(again["X_optm"], base["X_optm"])                        # and switching it off restores it
+
+
+def test_learning_problem_at_full_size_in_fp64(pkg):
+    """BASELINE configs[2] as bench.py runs it: batch 4096, 5 stored laps (160 safe-set points), N = 20, fp64.
+    Size-independent properties on the whole batch, the contract against the DENSE optimum on a sample."""
+    from parity import assert_contract, dense_reference
+    B = 4096
+    sv, tr, laps, inp, ss_x, ss_j = _s160(pkg, B)
+    o = _solve(sv, inp, ss_x, ss_j, False)
+    ok = o["status"] == 0
+    assert ok.mean() > 0.999, np.bincount(o["status"])
+    lam = o["convex_combi_optm"]
+    assert lam[:, ok].min() > -1e-12 and np.abs(lam[:, ok].sum(0) - 1.0).max() < 1e-9          # the simplex (racing_mpc.cpp:489-491)
+    A, Bm, g = (t.cpu().numpy() for t in sv.linearize(inp))
+    X, U = o["X_optm"], o["U_optm"]
+    pred = np.einsum("rcib,cib->rib", A, X[:, :-1]) + np.einsum("rcib,cib->rib", Bm, U) + g
+    assert np.abs(pred - X[:, 1:])[:, :, ok].max() < 1e-8                                       # x_{i+1} = A x_i + B u_i + g
+    npinp = {k: (v.cpu().numpy() if hasattr(v, "cpu") else v) for k, v in inp.items()}
+    sample = list(range(0, B, B // 12))[:12]
+    ref, margin, certified, _, _ = dense_reference(P.barc_lmpc(20, 5), P.barc_vehicle(), npinp, sample, ss_x.cpu().numpy(), ss_j.cpu().numpy())
+    frac = assert_contract({k: o[k][..., sample] for k in ("X_optm", "U_optm", "dU_optm", "status")}, ref, margin, certified,
+                           who="learning kernel, 160 points")
+    for b in np.where(~ok)[0][:4]:   # status parity: what the kernel gives up on, the dense solver does not solve either
+        qp = Q.build_qp(P.barc_lmpc(20, 5), P.barc_vehicle(), S.problem(npinp, int(b)), ss_x=ss_x.cpu().numpy()[:, :, b], ss_j=ss_j.cpu().numpy()[:, b])
+        _, info = Q.solve_dense(qp)
+        assert info["status"] != 0, (int(b), int(o["status"][b]), "kernel failed where the dense solver succeeds")
+    print("learning problem at full size: solved %.5f, degenerate among the sample %.2f" % (ok.mean(), frac))
