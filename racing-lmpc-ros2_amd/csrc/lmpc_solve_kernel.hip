@@ -1872,32 +1872,17 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
         break;
       }
       const real amax = uni(real(1) / rmax);
-      real sacc = 0.0;
-      if (pass == 0) {
-#pragma unroll
-        for (int q = 0; q < KQ; ++q) {
-          sacc += (s_tu[q] + amax * dtu[q]) * (s_lu[q] + amax * dlu[q]) + (s_tl[q] + amax * dtl[q]) * (s_ll[q] + amax * dll[q]);
-          s_pu[q] = dtu[q] * dlu[q];
-          s_pl[q] = dtl[q] * dll[q];
-        }
-        if constexpr (KS > 0) {
-#pragma unroll
-          for (int q = 0; q < KS; ++q) {
-            treal dt_, dl_, it_;
-            row_step(sx.on[q], sx.t[q], sx.l[q], sx.p[q], -sx.lm[q] + sx.t[q], -sx.dl[q], dt_, dl_, it_);
-            sacc += sx.on[q] ? real((sx.t[q] + treal(amax) * dt_) * (sx.l[q] + treal(amax) * dl_)) : real(0);
-            sx.p[q] = dt_ * dl_;
-          }
-        }
-      } else {
+      if (pass == 1) {
         alpha = uni(fmin(real(1), tau * amax));
-        if (distress) {
+        if (sizeof(real) == 8 && distress) {  // (fp64 arithmetic only: see below)
           // A problem whose complementarity has gone UP once gets the wide-neighbourhood rule from then on: the step is
           // cut back until no complementarity product falls below NBHD_GAMMA times their mean.  Mehrotra's iteration can
           // otherwise leave the neighbourhood of the central path and cycle -- seen on a learning problem whose safe set
           // offers two nearly exchangeable points: products at 0.01 and 300 times mu, mu bouncing between 6e-6 and 2e-5
           // up to the iteration cap while the dense solver finds the optimum (19 iterations with the rule).  Problems
-          // whose mu falls monotonically (all but a few per thousand) never enter this branch.
+          // whose mu falls monotonically (all but a few per thousand) never enter this branch.  The single-precision
+          // instantiations do without it: their mu is noisy at its floor, and the branch costs the mixed learning kernel
+          // 280 B of scratch per lane at two waves per SIMD (3.13 -> 2.89 M solves/s).
           for (int trial = 0; trial < NBHD_TRIALS; ++trial) {
             real sl = 0.0, pmin = inf;
 #pragma unroll
@@ -1922,25 +1907,39 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
             alpha = uni(alpha * real(0.6));
           }
         }
+      }
+      real sacc = 0.0;
 #pragma unroll
-        for (int q = 0; q < KQ; ++q) {
+      for (int q = 0; q < KQ; ++q) {
+        if (pass == 0) {
+          sacc += (s_tu[q] + amax * dtu[q]) * (s_lu[q] + amax * dlu[q]) + (s_tl[q] + amax * dtl[q]) * (s_ll[q] + amax * dll[q]);
+          s_pu[q] = dtu[q] * dlu[q];
+          s_pl[q] = dtl[q] * dll[q];
+        } else {
           s_tu[q] += alpha * dtu[q];
           s_lu[q] += alpha * dlu[q];
           s_tl[q] += alpha * dtl[q];
           s_ll[q] += alpha * dll[q];
           sacc += s_tu[q] * s_lu[q] + s_tl[q] * s_ll[q];
         }
-        if constexpr (KS > 0) {
+      }
+      if constexpr (KS > 0) {
 #pragma unroll
-          for (int q = 0; q < KS; ++q) {
-            treal dt_, dl_, it_;
-            row_step(sx.on[q], sx.t[q], sx.l[q], sx.p[q], -sx.lm[q] + sx.t[q], -sx.dl[q], dt_, dl_, it_);
+        for (int q = 0; q < KS; ++q) {
+          treal dt_, dl_, it_;
+          row_step(sx.on[q], sx.t[q], sx.l[q], sx.p[q], -sx.lm[q] + sx.t[q], -sx.dl[q], dt_, dl_, it_);
+          if (pass == 0) {
+            sacc += sx.on[q] ? real((sx.t[q] + treal(amax) * dt_) * (sx.l[q] + treal(amax) * dl_)) : real(0);
+            sx.p[q] = dt_ * dl_;
+          } else {
             sx.t[q] += treal(alpha) * dt_;
             sx.l[q] += treal(alpha) * dl_;
             sx.lm[q] += treal(alpha) * sx.dl[q];
             sacc += sx.on[q] ? real(sx.t[q] * sx.l[q]) : real(0);
           }
         }
+      }
+      if (pass == 1) {
         // no further progress: rows feasible, complementarity already small, and the corrector step would not lower it
         // (the Newton direction has reached the accuracy of the factorisation): keep the current primal iterate
         sacc = wave_sum(sacc);

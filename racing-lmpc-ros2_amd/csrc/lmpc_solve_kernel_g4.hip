@@ -394,17 +394,9 @@ __global__ __launch_bounds__(256, 2) void lmpc_solve_kernel_g4(
         continue;
       }
       const real amax = uni(real(1) / rmax);
-      real sacc = 0.0;
-      if (pass == 0) {
-#pragma unroll
-        for (int q = 0; q < KQ; ++q) {
-          sacc += (s_tu[q] + amax * dtu[q]) * (s_lu[q] + amax * dlu[q]) + (s_tl[q] + amax * dtl[q]) * (s_ll[q] + amax * dll[q]);
-          s_pu[q] = dtu[q] * dlu[q];
-          s_pl[q] = dtl[q] * dll[q];
-        }
-      } else {
+      if (pass == 1) {
         alpha = uni(fmin(real(1), tau * amax));
-        if (distress) {
+        if (sizeof(real) == 8 && distress) {  // (fp64 arithmetic only)
           // A problem whose complementarity has gone UP once gets the wide-neighbourhood rule from then on: the step is
           // cut back until no complementarity product falls below NBHD_GAMMA times their mean.  Mehrotra's iteration can
           // otherwise leave the neighbourhood of the central path and cycle -- seen on a learning problem whose safe set
@@ -425,14 +417,23 @@ __global__ __launch_bounds__(256, 2) void lmpc_solve_kernel_g4(
             alpha = uni(alpha * real(0.6));
           }
         }
+      }
+      real sacc = 0.0;
 #pragma unroll
-        for (int q = 0; q < KQ; ++q) {
+      for (int q = 0; q < KQ; ++q) {
+        if (pass == 0) {
+          sacc += (s_tu[q] + amax * dtu[q]) * (s_lu[q] + amax * dlu[q]) + (s_tl[q] + amax * dtl[q]) * (s_ll[q] + amax * dll[q]);
+          s_pu[q] = dtu[q] * dlu[q];
+          s_pl[q] = dtl[q] * dll[q];
+        } else {
           s_tu[q] += alpha * dtu[q];
           s_lu[q] += alpha * dlu[q];
           s_tl[q] += alpha * dtl[q];
           s_ll[q] += alpha * dll[q];
           sacc += s_tu[q] * s_lu[q] + s_tl[q] * s_ll[q];
         }
+      }
+      if (pass == 1) {
         // no further progress: rows feasible, complementarity already small, and the corrector step would not lower it
         // (the Newton direction has reached the accuracy of the factorisation): keep the current primal iterate
         sacc = wave_sum(sacc);
