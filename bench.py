@@ -66,7 +66,7 @@ def live_traffic_bytes(workload_argv, kernel):
                        "--warmup", "1", "--no-cpu-baseline", "--no-batch1", "--streams", "1", "--no-pmc"] + workload_argv
                 proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
                 try:
-                    proc.wait(timeout=180)
+                    proc.wait(timeout=90)
                 except subprocess.TimeoutExpired:
                     os.killpg(proc.pid, signal.SIGKILL)  # the exact process group started above
                     return None

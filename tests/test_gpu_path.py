@@ -644,20 +644,16 @@ def test_lmpc_at_other_horizons_matches_the_twin(pkg, N, n_laps):
     out["convex_combi_optm"] = torch.zeros((S_pts, 32), dtype=torch.float64, device="cuda")
     o = to_np(solver.solve(inp, out, ss_x=ss_x, ss_j=ss_j))
     twin = cbind.solve_batch(cfg, veh, inp, ss_x=rx, ss_j=rj)
-    assert (o["status"] == twin["status"]).mean() > 0.9 and (o["status"] == 0).mean() > 0.85, (o["status"], twin["status"])
-    ok = (o["status"] == 0) & (twin["status"] == 0)
+    assert (o["status"] == twin["status"]).all() and (o["status"] == 0).all(), (o["status"], twin["status"])
+    ok = o["status"] == 0
     # (the wave sums of the terminal block run in a different order than the twin's serial loops: at the accuracy floor
     #  the stopping rules can fire an iteration or two apart on an odd problem)
-    assert np.abs(o["iters"][ok] - twin["iters"][ok]).max() <= 2 and (o["iters"][ok] == twin["iters"][ok]).mean() >= (0.9 if N <= 60 else 0.8)
+    assert np.abs(o["iters"][ok] - twin["iters"][ok]).max() <= 2 and (o["iters"][ok] == twin["iters"][ok]).mean() >= 0.8
     e = np.abs((o["X_optm"] - twin["X_optm"]) / P.SCALE_X[:, None, None]).max(axis=(0, 1))[ok]
-    if N <= 60:       # the shipped horizons (barc_lmpc 40, iac_car_lmpc 60).  The learning cost has no tracking terms, so
-        #               the trajectory is flat in more directions than the tracking problem's: kernel and twin sit a few
-        #               1e-6 apart at N = 60 (measured p90 5e-6) while agreeing to 1e-8 in the median
-        assert np.median(e) < 1e-6 and np.percentile(e, 90) < 5 * TOL_TWIN and e.max() < TOL_DEGENERATE
-    else:             # N = 80: two seconds of an open-loop unstable model in one recursion; kernel and twin agree to
-        #               1e-8 on most problems and both drift to 1e-3 .. 1e-2 from the dense optimum on a few
-        #               (scratch/lmpc_n80_check.py, DESIGN.md "Numerics")
-        assert np.median(e) < 1e-6 and np.percentile(e, 75) < TOL_TWIN and e.max() < 5e-2
+    # The learning cost has no tracking terms, so the optimum is flat in more directions than the tracking problem's:
+    # kernel and twin agree to 1e-8 in the median and sit up to a few 1e-6 apart on the flattest problems; both are
+    # within 2e-9 of the DENSE optimum where that was computed (test_lmpc_at_long_horizons_against_the_dense_optimum).
+    assert np.median(e) < 1e-6 and np.percentile(e, 90) < 5 * TOL_TWIN and e.max() < TOL_DEGENERATE, (np.median(e), np.percentile(e, 90), e.max())
     lam = o["convex_combi_optm"][:, ok]
     assert np.abs(lam.sum(0) - 1.0).max() < 1e-8 and lam.min() > -1e-10
 
@@ -892,3 +888,34 @@ def test_grouped_kernel_matches_the_golden_vectors_and_the_default_kernel(pkg, g
     o6 = to_np(grouped.solve(six))
     assert (o6["status"] == 0).all()
     assert np.array_equal(o6["X_optm"], out["X_optm"][..., :6]) and np.array_equal(o6["iters"], out["iters"][:6])
+
+
+@pytest.mark.parametrize("N,n_laps,n_dense", [(40, 3, 6), (80, 5, 3)])
+def test_lmpc_at_long_horizons_against_the_dense_optimum(pkg, N, n_laps, n_dense):
+    """barc_lmpc.param.yaml ships N = 40; N = 80 is the longest instantiation.  Not the twin but the DENSE optimum, with the
+    contract of tests/tolerances.py (strictly complementary problems to 1e-6)."""
+    import lmpc_scenario as LS
+    import torch
+    from parity import dense_reference
+
+    B = 32
+    veh, cfg, tr, laps, inp, q = LS.make(B, 70 + N, N=N, n_laps=min(n_laps, 3))
+    cfg = P.barc_lmpc(N, n_laps)
+    stored = (laps * 2)[:n_laps]
+    solver = pkg.Solver(pkg.presets.barc_lmpc(N, n_laps), pkg.presets.barc_vehicle(), device=0)
+    solver.set_safe_set(stored, LS.L_BARC_SS)
+    ss_x, ss_j, nf = solver.ss_query(q)
+    out = solver.alloc_outputs(B)
+    out["convex_combi_optm"] = torch.zeros((32 * n_laps, B), dtype=torch.float64, device="cuda")
+    o = to_np(solver.solve(inp, out, ss_x=ss_x, ss_j=ss_j))
+    assert (o["status"] == 0).all(), o["status"]
+    sample = list(range(0, B, B // n_dense))[:n_dense]
+    ref, margin, certified, _, _ = dense_reference(cfg, veh, inp, sample, ss_x.cpu().numpy(), ss_j.cpu().numpy())
+    # (the learning cost has no tracking terms: most of these optima have a strict-complementarity margin below 1e-4 or an
+    #  active-set polish that was not accepted, so they are held to the degenerate bound; the strict ones to 1e-6)
+    exu, ed = per_problem_err({k: o[k][..., sample] for k in ("X_optm", "U_optm", "dU_optm")}, ref)
+    strict = (margin >= Q.DEGENERATE_MARGIN) & certified
+    assert (exu[strict] < TOL_XU).all() and (exu[~strict] < TOL_DEGENERATE).all(), (exu, margin, certified)
+    assert (ed[strict] < TOL_DU).all() and (ed[~strict] < 40 * TOL_DEGENERATE).all(), (ed, margin)
+    print("N = %d: %d dense optima, %d strict, worst strict %.1e, worst degenerate %.1e" % (
+        N, n_dense, strict.sum(), exu[strict].max() if strict.any() else 0.0, exu[~strict].max() if (~strict).any() else 0.0))
