@@ -590,7 +590,7 @@ def test_longer_horizons_match_the_twin(pkg, N):
     inp = S.cold_start_inputs(cfg, veh, tr, x, u, 0.025)
     out = to_np(solver.solve(inp))
     twin = cbind.solve_batch(cfg, veh, inp)
-    assert (out["status"] == twin["status"]).mean() > 0.95 and (out["status"] == 0).mean() > 0.9
+    assert (out["status"] == twin["status"]).all() and (out["status"] == 0).mean() > 0.95, (out["status"], twin["status"])
     ok = (out["status"] == 0) & (twin["status"] == 0)
     assert_same_iterations(out["iters"][ok], twin["iters"][ok])
     e = np.abs((out["X_optm"] - twin["X_optm"]) / P.SCALE_X[:, None, None]).max(axis=(0, 1))[ok]
@@ -615,7 +615,7 @@ def test_horizons_at_the_row_layout_boundaries_match_the_twin(pkg, N):
     out = to_np(solver.solve(inp))
     twin = cbind.solve_batch(cfg, veh, inp)
     assert out["X_optm"].shape == (6, N, 24) and out["U_optm"].shape == (2, N - 1, 24)
-    assert (out["status"] == twin["status"]).mean() > 0.9 and (out["status"] == 0).mean() > 0.85, (out["status"], twin["status"])
+    assert (out["status"] == twin["status"]).all() and (out["status"] == 0).mean() > 0.95, (out["status"], twin["status"])
     ok = (out["status"] == 0) & (twin["status"] == 0)
     assert_same_iterations(out["iters"][ok], twin["iters"][ok])
     e = np.abs((out["X_optm"] - twin["X_optm"]) / P.SCALE_X[:, None, None]).max(axis=(0, 1))[ok]
