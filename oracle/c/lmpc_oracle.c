@@ -944,7 +944,8 @@ static int ipm_solve(prob_t* p, work_t* w, int* iters_out, double* kkt_out) {
     }
     mu = musum / m;
     /* (see the step-length rule; far from feasibility mu may rise legitimately) */
-    if (it >= 1 && mu >= mu_prev && rdmax <= 1e-6) distress = 1;
+    if (it >= 1 && mu >= mu_prev && rdmax <= 1e-6 && N <= 40) distress = 1; /* (N <= 40: the kernel's instantiations
+                                                                              * for longer horizons do without the rule) */
     mu_prev = mu;
     if (!(mu == mu) || !(rdmax == rdmax)) {
       status = LMPC_SOLVE_INFEASIBLE;

@@ -208,29 +208,14 @@ struct op_min {
 template <class OP, int NV, typename real>
 __device__ __forceinline__ void wave_reduce_n(real (&v)[NV]) {
   const real id = OP::template id<real>();
-  // the rotations write every lane, so their "old" operand is a don't-care: handing them the previous stage's (dead)
-  // exchange value instead of the identity saves the two v_mov that would materialise it, per value and stage
-  real x[NV];
 #pragma unroll
-  for (int k = 0; k < NV; ++k) {
-    x[k] = dpp_move<DPP_ROW_ROR(8), 0xf>(v[k], id);
-    v[k] = OP::f(v[k], x[k]);
-  }
+  for (int k = 0; k < NV; ++k) v[k] = OP::f(v[k], dpp_move<DPP_ROW_ROR(8), 0xf>(v[k], id));
 #pragma unroll
-  for (int k = 0; k < NV; ++k) {
-    x[k] = dpp_move<DPP_ROW_ROR(4), 0xf>(v[k], x[k]);
-    v[k] = OP::f(v[k], x[k]);
-  }
+  for (int k = 0; k < NV; ++k) v[k] = OP::f(v[k], dpp_move<DPP_ROW_ROR(4), 0xf>(v[k], id));
 #pragma unroll
-  for (int k = 0; k < NV; ++k) {
-    x[k] = dpp_move<DPP_ROW_ROR(2), 0xf>(v[k], x[k]);
-    v[k] = OP::f(v[k], x[k]);
-  }
+  for (int k = 0; k < NV; ++k) v[k] = OP::f(v[k], dpp_move<DPP_ROW_ROR(2), 0xf>(v[k], id));
 #pragma unroll
-  for (int k = 0; k < NV; ++k) {
-    x[k] = dpp_move<DPP_ROW_ROR(1), 0xf>(v[k], x[k]);
-    v[k] = OP::f(v[k], x[k]);
-  }
+  for (int k = 0; k < NV; ++k) v[k] = OP::f(v[k], dpp_move<DPP_ROW_ROR(1), 0xf>(v[k], id));
 #pragma unroll
   for (int k = 0; k < NV; ++k) v[k] = OP::f(v[k], dpp_move<DPP_ROW_BCAST15, 0xa>(v[k], id));
 #pragma unroll
@@ -1749,10 +1734,21 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
       wave_sync();
       // ======== Newton step: predictor together with the Schur vector, then the corrector ========
       PT_MARK(4)
-      if (pass == 0 && ipm && has_sigma)
-        riccati_solve<2>(L, lane, pf);
-      else
-        riccati_solve<1>(L, lane, pf);
+      // N > 40 (KQ >= 11): the sweeps with the LDS exchange.  Those instantiations spill 0.8-1.7 KB of row state per lane and
+      // gain nothing from the DPP form (N = 60: 11.03 against 11.05 ms), and the largest of them (KQ = 14, KS = 3) was NOT
+      // reproducible from run to run with it (wider wait states around the asm groups did not help; every other
+      // instantiation is bitwise reproducible, scratch/r2_n80.py, r2_det_trk.py).
+      if constexpr (KQ >= 11) {
+        if (pass == 0 && ipm && has_sigma)
+          riccati_solve_lds<2>(L, lane, pf);
+        else
+          riccati_solve_lds<1>(L, lane, pf);
+      } else {
+        if (pass == 0 && ipm && has_sigma)
+          riccati_solve<2>(L, lane, pf);
+        else
+          riccati_solve<1>(L, lane, pf);
+      }
       PT_MARK(5)
       // ======== step of every constrained value; boundary slack by Schur complement ========
       real dz0[KQ], dz1[KQ], val[KQ];
@@ -1874,7 +1870,7 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
       const real amax = uni(real(1) / rmax);
       if (pass == 1) {
         alpha = uni(fmin(real(1), tau * amax));
-        if (sizeof(real) == 8 && distress) {  // (fp64 arithmetic only: see below)
+        if (sizeof(real) == 8 && KQ <= 7 && distress) {  // (fp64 arithmetic, N <= 40: see below)
           // A problem whose complementarity has gone UP once gets the wide-neighbourhood rule from then on: the step is
           // cut back until no complementarity product falls below NBHD_GAMMA times their mean.  Mehrotra's iteration can
           // otherwise leave the neighbourhood of the central path and cycle -- seen on a learning problem whose safe set
@@ -1882,7 +1878,8 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
           // up to the iteration cap while the dense solver finds the optimum (19 iterations with the rule).  Problems
           // whose mu falls monotonically (all but a few per thousand) never enter this branch.  The single-precision
           // instantiations do without it: their mu is noisy at its floor, and the branch costs the mixed learning kernel
-          // 280 B of scratch per lane at two waves per SIMD (3.13 -> 2.89 M solves/s).
+          // 280 B of scratch per lane at two waves per SIMD (3.13 -> 2.89 M solves/s).  Nor do the N > 40 instantiations,
+          // which already spill their row state: the branch costs them another 260 B per lane (N = 60: +9 % time).
           for (int trial = 0; trial < NBHD_TRIALS; ++trial) {
             real sl = 0.0, pmin = inf;
 #pragma unroll

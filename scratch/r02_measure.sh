@@ -9,6 +9,7 @@ $B --workload lmpc > gpurun_out/r02/bench_lmpc.json 2>/dev/null
 $B --workload lmpc --batch 32768 --steps 10 --warmup 2 > gpurun_out/r02/bench_lmpc_b32768.json 2>/dev/null
 $B --workload lmpc --batch 32768 --steps 10 --warmup 2 --precision mixed > gpurun_out/r02/bench_lmpc_b32768_mixed.json 2>/dev/null
 $B --workload lmpc --batch 32768 --steps 10 --warmup 2 --precision mixed --regression > gpurun_out/r02/bench_lmpc_b32768_mixed_regression.json 2>/dev/null
+$B --workload lmpc --horizon 40 --steps 10 --warmup 2 > gpurun_out/r02/bench_lmpc_n40.json 2>/dev/null
 $B --workload iac --horizon 40 --batch 8192 > gpurun_out/r02/bench_iac_n40.json 2>/dev/null
 $B --workload iac --horizon 40 --batch 8192 --precision mixed > gpurun_out/r02/bench_iac_n40_mixed.json 2>/dev/null
 $B --workload iac --horizon 40 --batch 8192 --precision f32 > gpurun_out/r02/bench_iac_n40_f32.json 2>/dev/null

@@ -919,3 +919,32 @@ def test_lmpc_at_long_horizons_against_the_dense_optimum(pkg, N, n_laps, n_dense
     assert (ed[strict] < TOL_DU).all() and (ed[~strict] < 40 * TOL_DEGENERATE).all(), (ed, margin)
     print("N = %d: %d dense optima, %d strict, worst strict %.1e, worst degenerate %.1e" % (
         N, n_dense, strict.sum(), exu[strict].max() if strict.any() else 0.0, exu[~strict].max() if (~strict).any() else 0.0))
+
+
+@pytest.mark.parametrize("N,n_laps", [(20, 0), (40, 0), (80, 0), (20, 5), (40, 5), (80, 5)])
+def test_solves_are_bitwise_reproducible_from_run_to_run(pkg, N, n_laps):
+    """Cross-lane exchange inside the single-wave workgroup (LDS with wave fences, DPP) must not depend on timing: the same
+    inputs give the same bits, for every row layout and both problems.  (The KQ = 14, KS = 3 instantiation was not
+    reproducible with the DPP form of the vector sweeps: N > 40 keeps the LDS exchange)"""
+    import lmpc_scenario as LS
+    import torch
+    if n_laps:
+        veh, cfg, tr, laps, inp, q = LS.make(32, 70 + N, N=N, n_laps=3)
+        solver = pkg.Solver(pkg.presets.barc_lmpc(N, n_laps), pkg.presets.barc_vehicle(), device=0)
+        solver.set_safe_set((laps * 2)[:n_laps], LS.L_BARC_SS)
+        ss_x, ss_j, _ = solver.ss_query(q)
+        kw = dict(ss_x=ss_x, ss_j=ss_j)
+    else:
+        veh, cfg = P.barc_vehicle(), P.barc_tracking_mpc(N)
+        solver = pkg.Solver(pkg.presets.barc_tracking_mpc(N), pkg.presets.barc_vehicle(), device=0)
+        tr = pkg.workloads.synthetic_track("barc")
+        u_lo, u_hi, _, _ = Q.effective_bounds(cfg, veh)
+        x, u = pkg.workloads.sample_initial_states("barc", 128, tr["L"], u_lo, u_hi, 5)
+        inp = S.cold_start_inputs(cfg, veh, tr, x, u, 0.025)
+        kw = {}
+    runs = []
+    for _ in range(6):
+        o = solver.solve(inp, **kw)
+        runs.append((o["X_optm"].clone(), o["U_optm"].clone(), o["iters"].clone(), o["status"].clone()))
+    for r in runs[1:]:
+        assert all(torch.equal(a, b) for a, b in zip(r, runs[0]))
