@@ -915,45 +915,32 @@ __device__ void riccati_factor(const Lds<real>& L, int lane, const ptreal* PT) {
   }
 }
 
-// Lanes 0..CNT-1 (or 6 and 7) of every 16-lane row to the whole row (DPP row_newbcast, gfx90a+; v_mov_b64_dpp for
-// doubles): register-to-register broadcasts.  Written as one asm block per group: through __builtin_amdgcn_update_dpp the
-// tied "old" operand costs a v_mov of a constant per broadcast, a fifth of the sweeps' VALU instructions.  The block opens
-// with the two wait states a DPP read of a just-written VGPR needs (the hazard recogniser does not look inside asm).
-#define LMPC_DPP64(K) "v_mov_b64_dpp %" #K ", %[src] row_newbcast:" #K " row_mask:0xf bank_mask:0xf\n\t"
-#define LMPC_DPP32(K) "v_mov_b32_dpp %" #K ", %[src] row_newbcast:" #K " row_mask:0xf bank_mask:0xf\n\t"
-__device__ __forceinline__ void row_bcast6(double v, double (&o)[6]) {
-  asm("s_nop 1\n\t" LMPC_DPP64(0) LMPC_DPP64(1) LMPC_DPP64(2) LMPC_DPP64(3) LMPC_DPP64(4) LMPC_DPP64(5)
-      : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5])
-      : [src] "v"(v));
+// Lane K of every 16-lane row to the whole row (DPP row_newbcast, gfx90a+; v_mov_b64_dpp for doubles): a register-to-
+// register broadcast.  bound_ctrl:1 with full row / bank masks tells the compiler that the tied "old" operand is never
+// read, so it is not materialised (with bound_ctrl:0 every broadcast costs a v_mov of a constant first -- a fifth of the
+// sweeps' VALU instructions).  (An inline-asm form of the same instructions measured the same speed and was NOT safe: in
+// the most register-starved instantiation, KQ = 14 with KS = 3, it gave wrong and run-to-run different results that wider
+// wait states did not cure, while this builtin form is bitwise reproducible there -- the compiler has to see DPP.)
+template <int K>
+__device__ __forceinline__ double row_bcast(double v) { return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + K, 0xf, 0xf, true); }
+template <int K>
+__device__ __forceinline__ float row_bcast(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150 + K, 0xf, 0xf, true));
 }
-__device__ __forceinline__ void row_bcast6(float v, float (&o)[6]) {
-  asm("s_nop 1\n\t" LMPC_DPP32(0) LMPC_DPP32(1) LMPC_DPP32(2) LMPC_DPP32(3) LMPC_DPP32(4) LMPC_DPP32(5)
-      : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5])
-      : [src] "v"(v));
+template <typename real>
+__device__ __forceinline__ void row_bcast6(real v, real (&o)[6]) {
+  o[0] = row_bcast<0>(v); o[1] = row_bcast<1>(v); o[2] = row_bcast<2>(v);
+  o[3] = row_bcast<3>(v); o[4] = row_bcast<4>(v); o[5] = row_bcast<5>(v);
 }
-__device__ __forceinline__ void row_bcast8(double v, double (&o)[8]) {
-  asm("s_nop 1\n\t" LMPC_DPP64(0) LMPC_DPP64(1) LMPC_DPP64(2) LMPC_DPP64(3) LMPC_DPP64(4) LMPC_DPP64(5) LMPC_DPP64(6) LMPC_DPP64(7)
-      : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7])
-      : [src] "v"(v));
+template <typename real>
+__device__ __forceinline__ void row_bcast8(real v, real (&o)[8]) {
+  o[0] = row_bcast<0>(v); o[1] = row_bcast<1>(v); o[2] = row_bcast<2>(v); o[3] = row_bcast<3>(v);
+  o[4] = row_bcast<4>(v); o[5] = row_bcast<5>(v); o[6] = row_bcast<6>(v); o[7] = row_bcast<7>(v);
 }
-__device__ __forceinline__ void row_bcast8(float v, float (&o)[8]) {
-  asm("s_nop 1\n\t" LMPC_DPP32(0) LMPC_DPP32(1) LMPC_DPP32(2) LMPC_DPP32(3) LMPC_DPP32(4) LMPC_DPP32(5) LMPC_DPP32(6) LMPC_DPP32(7)
-      : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7])
-      : [src] "v"(v));
-}
-__device__ __forceinline__ void row_bcast67(double v, double& a, double& b) {  // lanes 6 and 7
-  asm("s_nop 1\n\t"
-      "v_mov_b64_dpp %0, %[src] row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
-      "v_mov_b64_dpp %1, %[src] row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
-      : "=&v"(a), "=&v"(b)
-      : [src] "v"(v));
-}
-__device__ __forceinline__ void row_bcast67(float v, float& a, float& b) {
-  asm("s_nop 1\n\t"
-      "v_mov_b32_dpp %0, %[src] row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
-      "v_mov_b32_dpp %1, %[src] row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
-      : "=&v"(a), "=&v"(b)
-      : [src] "v"(v));
+template <typename real>
+__device__ __forceinline__ void row_bcast67(real v, real& a, real& b) {  // lanes 6 and 7
+  a = row_bcast<6>(v);
+  b = row_bcast<7>(v);
 }
 
 // Riccati vector solve for NRHS (1 or 2) right-hand sides held in the knots' rhs regions
