@@ -1721,11 +1721,13 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
       wave_sync();
       // ======== Newton step: predictor together with the Schur vector, then the corrector ========
       PT_MARK(4)
-      // N > 40 (KQ >= 11): the sweeps with the LDS exchange.  Those instantiations spill 0.8-1.7 KB of row state per lane and
-      // gain nothing from the DPP form (N = 60: 11.03 against 11.05 ms), and the largest of them (KQ = 14, KS = 3) was NOT
-      // reproducible from run to run with it (wider wait states around the asm groups did not help; every other
-      // instantiation is bitwise reproducible, scratch/r2_n80.py, r2_det_trk.py).
-      if constexpr (KQ >= 11) {
+      // The DPP form of the sweeps only in the instantiations built for two or more waves per SIMD (tracking up to N = 23
+      // in fp64, the fp32 / mixed kernels up to N = 40): they fit the architectural VGPRs.  The others -- one wave per SIMD,
+      // AGPRs as spill space, up to 1.7 KB of scratch per lane -- keep the LDS exchange: they gain little from DPP (N = 60:
+      // 11.03 against 11.05 ms; the learning kernel 3 %), and the most register-starved of them (KQ = 14, KS = 3) was NOT
+      // reproducible from run to run with it, for a reason that was not found -- so none of that
+      // family takes the risk.  Every instantiation as built is bitwise reproducible (scratch/r2_det_all.sh).
+      if constexpr (lmpc_waves_per_simd(sizeof(real), KQ, KS) < 2) {
         if (pass == 0 && ipm && has_sigma)
           riccati_solve_lds<2>(L, lane, pf);
         else
