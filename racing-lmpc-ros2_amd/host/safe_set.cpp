@@ -86,59 +86,69 @@ SSResult SafeSetManager::query(const SSQuery& query) {
 }
 
 SafeSetRecorder::SafeSetRecorder(SafeSetManager& manager, const bool& to_file, const std::string& file_prefix)
-    : manager_(manager), last_x_valid_(false), initialized_(false), to_file_(to_file), file_prefix_(file_prefix), lap_count_(0) {}
+    : manager_(manager), to_file_(to_file), file_prefix_(file_prefix) {}
 
+// Lap files (safe_set.cpp:260-276 upstream): `<stem>_{x,u,k,t}.txt`, one sample per row.  A lap that cannot be read is
+// reported and skipped; the others still load.
 void SafeSetRecorder::load(const std::vector<std::string>& from_files, const double& total_length) {
-  for (const auto& filename : from_files) {
+  static const char* const kinds[4] = {"_x.txt", "_u.txt", "_k.txt", "_t.txt"};
+  for (const std::string& stem : from_files) {
+    std::cout << "Loading lap from " << stem << std::endl;
     try {
-      std::cout << "Loading lap from " << filename << std::endl;
-      const DM x = transpose(read_txt(filename + "_x.txt"));
-      const DM u = transpose(read_txt(filename + "_u.txt"));
-      const DM k = transpose(read_txt(filename + "_k.txt"));
-      const DM t = transpose(read_txt(filename + "_t.txt"));
-      manager_.add_lap(x, u, k, t, total_length);
-      lap_count_++;
-    } catch (const std::exception& e) {
-      std::cout << "Failed to load lap from " << filename << std::endl;
-      std::cout << e.what() << std::endl;
+      DM part[4];
+      for (int i = 0; i < 4; ++i) part[i] = transpose(read_txt(stem + kinds[i]));
+      manager_.add_lap(part[0], part[1], part[2], part[3], total_length);
+      ++lap_count_;
+    } catch (const std::exception& err) {
+      std::cout << "Failed to load lap from " << stem << std::endl << err.what() << std::endl;
     }
   }
 }
 
+void SafeSetRecorder::Lap::restart(const DM& x0, const DM& u0, const DM& k0, const DM& t0) {
+  x = x0;
+  u = u0;
+  k = k0;
+  t = t0;
+}
+
+void SafeSetRecorder::Lap::push(const DM& xi, const DM& ui, const DM& ki, const DM& ti) {
+  x.append_column(xi);
+  u.append_column(ui);
+  k.append_column(ki);
+  t.append_column(ti);
+}
+
+void SafeSetRecorder::finish_lap(double total_length) {
+  std::cout << "Lap " << lap_count_ << " completed. Adding to safe set." << std::endl;
+  manager_.add_lap(lap_.x, lap_.u, lap_.k, lap_.t, total_length);
+  if (!to_file_) return;
+  const std::string stem = file_prefix_ + "lap_" + std::to_string(lap_count_);
+  std::cout << "Saving lap to " << stem << std::endl;
+  write_txt(transpose(lap_.x), stem + "_x.txt");
+  write_txt(transpose(lap_.u), stem + "_u.txt");
+  write_txt(transpose(lap_.t), stem + "_t.txt");
+  write_txt(transpose(lap_.k), stem + "_k.txt");
+}
+
+// One control period (safe_set.cpp:278-322 upstream).  Laps are cut where the abscissa falls by more than half the track
+// length from one sample to the next.  The stretch before the first crossing is a partial lap and is dropped; the lap
+// counter counts crossings, so the first complete lap is number 1 -- file names and console lines as upstream.
 void SafeSetRecorder::step(const DM& x, const DM& u, const DM& k, const DM& t, const double& total_length) {
-  if (!last_x_valid_) {  // the very first sample only seeds the abscissa (safe_set.cpp:278-282)
-    last_x_ = x;
-    last_x_valid_ = true;
+  if (!seeded_) {  // the first sample only provides the abscissa to compare the second one with
+    lap_.x = x;
+    seeded_ = true;
     return;
   }
-  const double px = x(0, 0);
-  const double px_last = last_x_(0, last_x_.cols - 1);
-  if (px_last - px > 0.5 * total_length) {  // crossed the start line
-    if (initialized_) {
-      std::cout << "Lap " << lap_count_ << " completed. Adding to safe set." << std::endl;
-      manager_.add_lap(last_x_, last_u_, last_k_, last_t_, total_length);
-      if (to_file_) {
-        const std::string filename = file_prefix_ + "lap_" + std::to_string(lap_count_);
-        std::cout << "Saving lap to " << filename << std::endl;
-        write_txt(transpose(last_x_), filename + "_x.txt");
-        write_txt(transpose(last_u_), filename + "_u.txt");
-        write_txt(transpose(last_t_), filename + "_t.txt");
-        write_txt(transpose(last_k_), filename + "_k.txt");
-      }
-    } else {
-      initialized_ = true;  // the first, partial lap is discarded
-    }
-    lap_count_++;
-    last_x_ = x;
-    last_u_ = u;
-    last_t_ = t;
-    last_k_ = k;
-  } else {
-    last_x_.append_column(x);
-    last_u_.append_column(u);
-    last_t_.append_column(t);
-    last_k_.append_column(k);
+  const bool crossed_line = lap_.last_abscissa() - x(0, 0) > 0.5 * total_length;
+  if (!crossed_line) {
+    lap_.push(x, u, k, t);
+    return;
   }
+  if (past_first_line_) finish_lap(total_length);
+  past_first_line_ = true;
+  ++lap_count_;
+  lap_.restart(x, u, k, t);
 }
 
 }  // namespace racing_trajectory

@@ -61,11 +61,22 @@ class SafeSetRecorder {
   std::size_t lap_count() const { return lap_count_; }
 
  private:
+  // the lap being driven: one column per control period (state, input, curvature, time stamp)
+  struct Lap {
+    DM x, u, k, t;
+    void restart(const DM& x0, const DM& u0, const DM& k0, const DM& t0);
+    void push(const DM& xi, const DM& ui, const DM& ki, const DM& ti);
+    double last_abscissa() const { return x(0, x.cols - 1); }
+  };
+  void finish_lap(double total_length);  // hand the driven lap to the manager (and to disk)
+
   SafeSetManager& manager_;
-  DM last_x_, last_u_, last_k_, last_t_;
-  bool last_x_valid_, initialized_, to_file_;
+  Lap lap_;
+  bool seeded_ = false;      // a first sample has been seen
+  bool past_first_line_ = false;  // the start line has been crossed once: laps from here on are complete
+  bool to_file_;
   std::string file_prefix_;
-  std::size_t lap_count_;
+  std::size_t lap_count_ = 0;
 };
 
 }  // namespace racing_trajectory

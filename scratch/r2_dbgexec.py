@@ -19,4 +19,4 @@ for rep in range(3):
     out["convex_combi_optm"] = torch.zeros((32 * n_laps, 32), dtype=torch.float64, device="cuda")
     o = solver.solve(inp, out, ss_x=ss_x, ss_j=ss_j)
     k = o["kkt"].cpu().numpy()
-    print("status", o["status"].cpu().numpy()[:12], "exec lo", [hex(int(v)) for v in k[4, :4]], "hi", [hex(int(v)) for v in k[5, :4]])
+    print("status", o["status"].cpu().numpy()[:16], "bwd mismatches", k[4, :16], "fwd mismatches", k[5, :16])

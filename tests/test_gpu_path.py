@@ -925,7 +925,7 @@ def test_lmpc_at_long_horizons_against_the_dense_optimum(pkg, N, n_laps, n_dense
 def test_solves_are_bitwise_reproducible_from_run_to_run(pkg, N, n_laps):
     """Cross-lane exchange inside the single-wave workgroup (LDS with wave fences, DPP) must not depend on timing: the same
     inputs give the same bits, for every row layout and both problems.  (The KQ = 14, KS = 3 instantiation was not
-    reproducible with the DPP form of the vector sweeps: N > 40 keeps the LDS exchange)"""
+    reproducible with the DPP form of the vector sweeps: only the instantiations built for two waves per SIMD use it)"""
     import lmpc_scenario as LS
     import torch
     if n_laps:
