@@ -2072,4 +2072,6 @@ LMPC_INSTANTIATE(float, 11, 0, double)  // iac_car_tracking_mpc.param.yaml ships
 LMPC_INSTANTIATE(float, 14, 0, double)
 LMPC_INSTANTIATE(float, 4, 2, double)  // the learning problem, N <= 23 (BASELINE configs[4])
 LMPC_INSTANTIATE(float, 4, 3, double)
+// (the learning problem at N = 40 in mixed precision was built and measured: 1.16 M solves/s against 0.70 M in fp64, but
+//  median 1.2e-3 / 99th percentile 1.5e-2 from the fp64 answers -- outside the 1e-3 the mixed entry states; not shipped)
 #endif

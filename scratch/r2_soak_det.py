@@ -13,7 +13,9 @@ def soak(name, solve, reps):
         else: bad += int(not all(torch.equal(a, b) for a, b in zip(cur, ref)))
     print(name, "reps", reps, "runs differing from the first:", bad)
 tr = pkg.workloads.synthetic_track("barc")
-for N, reps in ((20, 40), (40, 12)):
+import os
+REPS20 = int(os.environ.get('REPS20', '40'))
+for N, reps in ((20, REPS20), (40, 12)):
     sv = pkg.Solver(pkg.presets.barc_tracking_mpc(N), pkg.presets.barc_vehicle(), device=0)
     x, u = pkg.workloads.sample_initial_states("barc", 4096, tr["L"], [-0.01, -0.314], [0.01, 0.314], seed=0)
     inp = sv.prepare(tr, x.T.copy(), 0.025); inp["u_ic"] = torch.as_tensor(u.T.copy(), dtype=torch.float64, device="cuda")
