@@ -921,13 +921,22 @@ int lmpc_set_regression_laps(lmpc_handle* h, int32_t n_laps, const int32_t* n_pt
     end.resize(total, 0);
     end[total - 1] = 1;
   }
+  // upload-time temporaries: freed on every way out of this function
+  struct scratch_dev {
+    void* p = nullptr;
+    ~scratch_dev() {
+      if (p) (void)hipFree(p);
+    }
+  } tk, tt, tv;
   double *dk = nullptr, *dt = nullptr;
   HIP_TRY(h, hipMalloc(&h->reg_end, total * sizeof(int)));
   HIP_TRY(h, hipMalloc(&h->reg_x, total * 6 * sizeof(double)));
   HIP_TRY(h, hipMalloc(&h->reg_u, total * 2 * sizeof(double)));
   HIP_TRY(h, hipMalloc(&h->reg_y, total * 6 * sizeof(double)));
-  HIP_TRY(h, hipMalloc(&dk, total * sizeof(double)));
-  HIP_TRY(h, hipMalloc(&dt, total * sizeof(double)));
+  HIP_TRY(h, hipMalloc(&tk.p, total * sizeof(double)));
+  HIP_TRY(h, hipMalloc(&tt.p, total * sizeof(double)));
+  dk = static_cast<double*>(tk.p);
+  dt = static_cast<double*>(tt.p);
   HIP_TRY(h, hipMemcpy(h->reg_end, end.data(), total * sizeof(int), hipMemcpyHostToDevice));
   HIP_TRY(h, hipMemcpy(h->reg_x, x, total * 6 * sizeof(double), hipMemcpyHostToDevice));
   HIP_TRY(h, hipMemcpy(h->reg_u, u, total * 2 * sizeof(double), hipMemcpyHostToDevice));
@@ -942,20 +951,17 @@ int lmpc_set_regression_laps(lmpc_handle* h, int32_t n_laps, const int32_t* n_pt
     for (size_t j = 0; j < total; ++j)
       if (!end[j]) valid.push_back((int)j);
     const int nvalid = (int)valid.size(), npad = (nvalid + 3) / 4 * 4;
-    int* dvalid = nullptr;
-    HIP_TRY(h, hipMalloc(&dvalid, (size_t)nvalid * sizeof(int)));
+    HIP_TRY(h, hipMalloc(&tv.p, (size_t)nvalid * sizeof(int)));
+    int* dvalid = static_cast<int*>(tv.p);
     HIP_TRY(h, hipMalloc(&h->reg_tab, (size_t)npad * (size_t)(nf + spec->n_out) * sizeof(double)));
     HIP_TRY(h, hipMemcpy(dvalid, valid.data(), (size_t)nvalid * sizeof(int), hipMemcpyHostToDevice));
     hipLaunchKernelGGL(lmpc_reg_pack_kernel, dim3((unsigned)((npad + 255) / 256)), dim3(256), 0, h->stream, *spec, nvalid, npad, dvalid,
                        h->reg_x, h->reg_u, h->reg_y, h->reg_tab);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    HIP_TRY(h, hipFree(dvalid));
     h->reg_npad = npad;
   }
   HIP_TRY(h, hipStreamSynchronize(h->stream));
-  HIP_TRY(h, hipFree(dk));
-  HIP_TRY(h, hipFree(dt));
   h->reg_total = (int)total;
   h->reg_spec = *spec;
   h->reg_on = true;
