@@ -229,6 +229,10 @@ def main():
     ap.add_argument("--streams", type=int, default=3,
                     help="consecutive steps alternate between this many HIP streams (one handle, workspace and output buffer "
                          "each), so the tail of one batch overlaps the head of the next; 1 = strictly one batch at a time")
+    ap.add_argument("--launch-order", choices=["default", "previous"], default="default",
+                    help="previous: start the QP kernel's workgroups longest-first by the iteration counts of the previous solve of "
+                         "the same batch (lmpc_set_launch_order) -- what a closed loop has; the bench repeats one batch, so here the "
+                         "prediction is perfect, and the figure is labelled as such (never the default)")
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL result gather for N > 1")
     ap.add_argument("--regression", action="store_true", help="--workload lmpc only: switch the error-dynamics regression on "
                     "(safe_set.cpp:182-245; BASELINE configs[4]: 'LMPC + error-dynamics residual term') -- 2200 recorded sample pairs "
@@ -369,7 +373,19 @@ def main():
         gbuf = [torch.empty_like(gbuf[0]) for _ in range(S)]
     torch.cuda.synchronize()
 
+    orders = {}
+    if args.launch_order == "previous":
+        for sv in solvers:
+            orders[id(sv)] = torch.arange(B, dtype=torch.int32, device=dev)
+            sv.set_launch_order(orders[id(sv)])
+
     def solve_step(k, sv=None):
+        o = solve_step_(k, sv)
+        if orders:
+            (sv or solver).launch_order_from_iters(o["iters"], orders[id(sv or solver)])
+        return o
+
+    def solve_step_(k, sv=None):
         sv = sv or solver
         o = outs[k % len(outs)]
         if f32:
@@ -509,7 +525,9 @@ def main():
                                    + (" -- mixed precision: fp32 Riccati / interior point between fp64 arrays (BASELINE configs[4])" if mixed else "")
                                    + (" -- error-dynamics regression on: %d recorded sample pairs, every stage regressed before its QP" % len(reg_laps)
                                       if (lmpc and reg_laps) else ""),
-                       "batch_per_gpu": B, "horizon": N, "streams": S, "result_gather": "rccl all_gather (async)" if gather else "none",
+                       "batch_per_gpu": B, "horizon": N, "streams": S,
+                       "launch_order": ("longest first by the previous solve's iteration counts of the SAME batch (perfect foresight here)"
+                                        if orders else "default"), "result_gather": "rccl all_gather (async)" if gather else "none",
                        "ranks_seen": ranks_seen},
             "p50_solve_ms": float(np.percentile(lat, 50)), "p99_solve_ms": float(np.percentile(lat, 99)),
             "latency_samples": len(lat), "value_one_stream": one_stream_value,

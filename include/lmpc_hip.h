@@ -324,6 +324,16 @@ int lmpc_plant_step_batch(lmpc_handle* h, int32_t batch, const lmpc_track* track
 
 /* Grow the handle's device workspace (stage linearisations, 432 B per stage per problem) so
  * that no later *_batch call with batch <= max_batch allocates. */
+/* Launch order of the QP kernel's workgroups (no counterpart upstream: a scheduling aid for closed-loop batches).  The
+ * hardware starts workgroups in index order and a batch of 4096 fills the GPU twice, so the kernel's duration is that of
+ * the problems that happen to start last.  With `order` -- DEVICE int32 [batch], a permutation of 0 .. batch-1 -- workgroup w
+ * solves problem order[w]; lmpc_launch_order_from_iters fills it from the iteration counts of the previous solve of the same
+ * cars, longest first (runs on the handle's stream, graph-capturable).  Results per problem do not depend on the order.
+ * NULL (the default) restores the XCD-aware mapping.  The pointer is kept, not copied: it must stay valid and hold `batch`
+ * entries for every later lmpc_solve_batch* call. */
+int lmpc_set_launch_order(lmpc_handle* h, const int32_t* order);
+int lmpc_launch_order_from_iters(lmpc_handle* h, int32_t batch, const int32_t* iters, int32_t* order);
+
 int lmpc_reserve(lmpc_handle* h, int32_t max_batch);
 
 /* Library/kernel facts for harnesses: bytes of LDS one problem occupies, threads per problem. */

@@ -20,7 +20,7 @@ _ABI_SYMBOLS = ("lmpc_create", "lmpc_destroy", "lmpc_last_error", "lmpc_set_stre
                 "lmpc_prepare_batch", "lmpc_reserve", "lmpc_query_launch", "lmpc_enable_timing",
                 "lmpc_last_kernel_ms", "lmpc_query_residency", "lmpc_solve_host", "lmpc_shift_batch",
                 "lmpc_plant_step_batch", "lmpc_solve_full_dynamics_batch", "lmpc_solve_full_dynamics_host", "lmpc_set_regression_laps", "lmpc_regress_batch", "lmpc_ss_query_host", "lmpc_solve_batch_f32",
-                "lmpc_solve_batch_mixed", "lmpc_prepare_failed_batch")
+                "lmpc_solve_batch_mixed", "lmpc_prepare_failed_batch", "lmpc_set_launch_order", "lmpc_launch_order_from_iters")
 
 
 class LmpcError(RuntimeError):
@@ -254,6 +254,23 @@ class Solver:
                                                                 "bound_right", "curvatures", "vel_ref")])
         self._check(rc, "lmpc_shift_batch")
         return out
+
+    # ---- launch order (longest job first; include/lmpc_hip.h) ----
+    def set_launch_order(self, order):
+        """order: int32 device tensor [batch] (kept alive here) or None for the default mapping."""
+        self._launch_order = None if order is None else self._torch.as_tensor(order, dtype=self._torch.int32, device=self.device).contiguous()
+        self._check(self.lib.lmpc_set_launch_order(self._h, _ptr(self._launch_order)), "lmpc_set_launch_order")
+
+    def launch_order_from_iters(self, iters, order=None):
+        """Fills (and returns) `order` from the iteration counts of the previous solve of the same batch, longest first."""
+        torch = self._torch
+        self.use_current_stream()
+        iters = torch.as_tensor(iters, dtype=torch.int32, device=self.device).contiguous()
+        if order is None:
+            order = torch.empty_like(iters)
+        self._check(self.lib.lmpc_launch_order_from_iters(self._h, C.c_int32(iters.numel()), _ptr(iters), _ptr(order)),
+                    "lmpc_launch_order_from_iters")
+        return order
 
     # ---- plant (racing_simulator.cpp:97-112) ----
     def plant_step(self, track: dict, x, u, dt_sim: float, n_sub: int = 1):

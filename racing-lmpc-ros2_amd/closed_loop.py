@@ -10,7 +10,7 @@ from __future__ import annotations
 
 
 def run(solver, track: dict, x0, u0, steps: int, dt: float = 0.025, n_sub: int = 2, speed_scale: float = 0.9,
-        record_every: int = 0, restart_failed: bool = True, graph: bool = False):
+        record_every: int = 0, restart_failed: bool = True, graph: bool = False, longest_first: bool = False):
     """x0 [6][B], u0 [2][B] (torch, device).  Returns final state and statistics (torch tensors on device).
 
     One control period = solve, apply the first input of the plan (on failure: of the shifted previous plan,
@@ -19,7 +19,11 @@ def run(solver, track: dict, x0, u0, steps: int, dt: float = 0.025, n_sub: int =
     make the next QP fail too.  Nothing in a period reads device data on the host.
 
     graph=True captures the period once as a HIP graph and replays it: a period is ~25 small launches around the QP
-    kernel, and eager dispatch (~2 ms of host time) costs more than the 0.9 ms the GPU needs for them."""
+    kernel, and eager dispatch (~2 ms of host time) costs more than the 0.9 ms the GPU needs for them.
+
+    longest_first=True launches the QP kernel's workgroups in the order of the previous period's iteration counts, longest
+    first (lmpc_set_launch_order): a car's count changes little from one period to the next, and the long problems then
+    no longer start last in the second residency round."""
     import torch
 
     trk = solver.device_track(track)
@@ -35,11 +39,17 @@ def run(solver, track: dict, x0, u0, steps: int, dt: float = 0.025, n_sub: int =
     half_b = float(solver.vehicle["b"]) / 2.0
     keys = ("X_ref", "U_ref", "T_ref", "bound_left", "bound_right", "curvatures", "vel_ref")
     trace = []
+    order = None
+    if longest_first:
+        order = torch.arange(B, dtype=torch.int32, device=x.device)
+        solver.set_launch_order(order)
 
     def period():
         inp["x_ic"] = x
         inp["u_ic"] = u_prev
         solver.solve(inp, out)
+        if order is not None:
+            solver.launch_order_from_iters(out["iters"], order)   # for the next period (in place: the pointer is registered)
         ok = out["status"] == 0
         n_fail.add_((~ok).to(torch.int64))
         u_apply = torch.where(ok[None, :], out["U_optm"][:, 0, :], inp["U_ref"][:, 0, :]).contiguous()
@@ -80,6 +90,9 @@ def run(solver, track: dict, x0, u0, steps: int, dt: float = 0.025, n_sub: int =
             g.replay()
             for _ in range(steps - done):
                 g.replay()
+    if order is not None:
+        torch.cuda.synchronize(x.device)
+        solver.set_launch_order(None)
     return {"x": x, "distance": dist, "worst_excess": worst_excess, "n_fail": n_fail, "trace": trace}
 
 

@@ -39,6 +39,7 @@ __global__ void lmpc_regress_kernel(int, int, lmpc_regression_spec, int, const d
 template <int KQ>
 __global__ void lmpc_solve_kernel_g4(lmpc_params, int, const double*, const double*, const double*, const double*, const double*,
                                      const double*, const double*, double*, double*, double*, int*, int*, double*);
+__global__ void lmpc_launch_order_kernel(int, const int*, int*);
 struct lmpc_sqp_arrays;
 __global__ void lmpc_sqp_linesearch_kernel(lmpc_params, int, lmpc_sqp_arrays, int, double);
 __global__ void lmpc_sqp_accumulate_kernel(int, const int*, int*);
@@ -965,6 +966,22 @@ int lmpc_set_regression_laps(lmpc_handle* h, int32_t n_laps, const int32_t* n_pt
   h->reg_total = (int)total;
   h->reg_spec = *spec;
   h->reg_on = true;
+  return LMPC_OK;
+}
+
+int lmpc_set_launch_order(lmpc_handle* h, const int32_t* order) {
+  if (!h) return LMPC_ERR_ARGUMENT;
+  h->P.launch_order = order;
+  return LMPC_OK;
+}
+
+int lmpc_launch_order_from_iters(lmpc_handle* h, int32_t batch, const int32_t* iters, int32_t* order) {
+  if (!h) return LMPC_ERR_ARGUMENT;
+  if (batch < 0 || !iters || !order) return fail(h, LMPC_ERR_ARGUMENT, "lmpc_launch_order_from_iters: null pointer or negative batch");
+  if (batch == 0) return LMPC_OK;
+  HIP_TRY(h, hipSetDevice(h->device));
+  hipLaunchKernelGGL(lmpc_launch_order_kernel, dim3(1), dim3(1024), 0, h->stream, batch, iters, order);
+  HIP_TRY(h, hipGetLastError());
   return LMPC_OK;
 }
 

@@ -246,3 +246,41 @@ __global__ __launch_bounds__(256) void lmpc_prepare_kernel(lmpc_params P, int B,
     }
   }
 }
+
+// Launch order for the next solve of a closed-loop batch: problems sorted by the iteration count of their last solve,
+// longest first (counting sort over 0 .. 63 iterations; one workgroup; the order inside a bucket is by problem index, so the
+// result is reproducible).
+__global__ __launch_bounds__(1024) void lmpc_launch_order_kernel(int B, const int* __restrict__ iters, int* __restrict__ order) {
+  __shared__ int count[64], start[64];
+  const int tid = threadIdx.x;
+  if (tid < 64) count[tid] = 0;
+  __syncthreads();
+  for (int b = tid; b < B; b += blockDim.x) atomicAdd(&count[min(max(iters[b], 0), 63)], 1);
+  __syncthreads();
+  if (tid == 0) {
+    int acc = 0;
+    for (int k = 63; k >= 0; --k) {  // descending: the longest first
+      start[k] = acc;
+      acc += count[k];
+    }
+  }
+  __syncthreads();
+  // rank inside the bucket = number of problems with the same count and a smaller index (keeps the order deterministic)
+  for (int k = tid; k < 64; k += blockDim.x) count[k] = 0;
+  __syncthreads();
+  for (int base = 0; base < B; base += blockDim.x) {  // chunks in index order; inside a chunk ranks by a prefix over lanes
+    const int b = base + tid;
+    const int key = b < B ? min(max(iters[b], 0), 63) : -1;
+    // serialise per key within the chunk: thread t counts equal keys among threads < t of this chunk
+    __shared__ int keys[1024];
+    keys[tid] = key;
+    __syncthreads();
+    int rank = 0;
+    if (key >= 0)
+      for (int t = 0; t < tid; ++t) rank += keys[t] == key ? 1 : 0;
+    if (key >= 0) order[start[key] + count[key] + rank] = b;
+    __syncthreads();
+    if (key >= 0) atomicAdd(&count[key], 1);
+    __syncthreads();
+  }
+}

@@ -1211,7 +1211,11 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
   // consecutive problems share 64-byte lines in the [field][knot][batch] arrays.  Workgroup w takes problem
   // (w mod 8) * ceil(B / 8) + w / 8, so each XCD owns a contiguous eighth of the batch and the 8-byte strided
   // accesses of neighbouring problems merge in that XCD's L2 instead of reaching HBM as partial lines.
-  const int b = (int)(blockIdx.x & 7) * ((B + 7) >> 3) + (int)(blockIdx.x >> 3);
+  // With a launch order (longest job first from the previous solve's iteration counts, lmpc_set_launch_order) workgroup
+  // w takes problem launch_order[w]: the hardware starts workgroups in index order, so the long problems go first and the
+  // short ones fill the tail of the second residency round.
+  int b = (int)(blockIdx.x & 7) * ((B + 7) >> 3) + (int)(blockIdx.x >> 3);
+  if (P.launch_order) b = (int)blockIdx.x < B ? P.launch_order[blockIdx.x] : B;
   if (b >= B) return;
   const int lane = threadIdx.x;
   const int N = P.N, NS = N - 1;

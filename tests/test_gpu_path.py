@@ -948,3 +948,26 @@ def test_solves_are_bitwise_reproducible_from_run_to_run(pkg, N, n_laps):
         runs.append((o["X_optm"].clone(), o["U_optm"].clone(), o["iters"].clone(), o["status"].clone()))
     for r in runs[1:]:
         assert all(torch.equal(a, b) for a, b in zip(r, runs[0]))
+
+
+def test_launch_order_changes_the_schedule_not_the_answers(pkg):
+    """lmpc_set_launch_order / lmpc_launch_order_from_iters: the order is a permutation sorted by iteration count, longest
+    first, and the solve returns the same bits per problem whatever the order."""
+    import torch
+    veh, cfg, solver, tr, x, u = make(pkg, "barc20", 1000, 4)      # (not a multiple of 8 or 64)
+    inp = S.cold_start_inputs(cfg, veh, tr, x, u, 0.025)
+    base = solver.solve(inp)
+    ref = {k: base[k].clone() for k in ("X_optm", "U_optm", "dU_optm", "iters", "status")}
+    order = solver.launch_order_from_iters(base["iters"])
+    o, it = order.cpu().numpy(), ref["iters"].cpu().numpy()
+    assert sorted(o.tolist()) == list(range(1000))
+    assert (np.diff(it[o]) <= 0).all()                              # longest first
+    same = it[o][:-1] == it[o][1:]
+    assert (np.diff(o)[same] > 0).all()                             # ties by problem index: the order is reproducible
+    solver.set_launch_order(order)
+    again = solver.solve(inp)
+    solver.set_launch_order(torch.arange(999, -1, -1, dtype=torch.int32, device="cuda"))
+    rev = solver.solve(inp)
+    solver.set_launch_order(None)
+    for k in ref:
+        assert torch.equal(again[k], ref[k]) and torch.equal(rev[k], ref[k]), k
