@@ -55,6 +55,10 @@ def live_traffic_bytes(workload_argv, kernel):
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return None
+    # this process is itself running under a profiler (the driver, or scratch/prof.sh): do not nest a second one
+    if any(k in os.environ for k in ("ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB", "ROCPROFILER_LIBRARY_CTOR", "ROCPROF_OUTPUT_PATH")) or \
+            "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None
     total = 0.0
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     env["TMPDIR"] = "/tmp"
