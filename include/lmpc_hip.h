@@ -95,6 +95,9 @@ typedef struct lmpc_config {
   int32_t num_ss_pts_per_lap; /* K                                                          */
   int32_t max_lap_stored;
   int32_t max_iter;           /* interior-point iteration cap (<=0: default 40)             */
+  int32_t polish;             /* active-set polish of the interior-point answer, the role of OSQP's polish = true
+                                 (racing_mpc.cpp:90-95): 0 (default) on, < 0 off               */
+  int32_t reserved;           /* (keeps `tol` 8-byte aligned; set to 0)                      */
   double tol;                 /* complementarity tolerance (<=0: default 3e-14)             */
   double margin;
   double q_contour, q_heading, q_vel, q_vy, q_vyaw, q_boundary;
@@ -160,16 +163,16 @@ int lmpc_solve_batch(lmpc_handle* h, int32_t batch, const double* x_ic, const do
                      const double* ss_j, double* X_optm, double* U_optm, double* dU_optm,
                      double* convex_combi_optm, int32_t* status, int32_t* iters, double* kkt);
 
-/* Mixed precision: same arguments, layouts and fp64 arrays as lmpc_solve_batch, for the tracking problem.  In fp64:
- * the linearisation (discrete_dynamics_jacobian), the error-dynamics regression onto it when
+/* Mixed precision (BASELINE configs[4]: "mixed fp32/fp64 KKT"): same arguments, layouts and fp64 arrays as
+ * lmpc_solve_batch.  In fp64: the linearisation (discrete_dynamics_jacobian), the error-dynamics regression onto it when
  * lmpc_set_regression_laps is in effect, the centring of the abscissa on x_ic[0], the 2x2 pivots of the Riccati
- * recursion, and the results.  In fp32: the stage records in LDS, the Riccati factor and sweeps and the interior-point
- * rows -- half the LDS footprint, so twice the resident problems per CU where fp64 is capacity-bound (N = 40: 2.3x the
- * fp64 rate).  Stopping rule and accuracy as lmpc_solve_batch_f32: fit for well-scaled problems (IAC: 99 % within
- * 6e-4 of the fp64 solution in scaled units), NOT for the BARC problems, whose soft boundary needs complementarity
- * below 1e-9.  learning = 1 returns LMPC_ERR_UNSUPPORTED (BASELINE configs[4] asks for a mixed
- * KKT on the learning problem; the terminal block's condition number ~1e8 rules fp32 out -- measured).
- * Every horizon the fp64 entry accepts (iac_car_tracking_mpc.param.yaml ships N = 80: 3.4x the fp64 rate). */
+ * recursion, the results and -- learning = 1 -- the simplex rows and the whole terminal elimination of the safe-set
+ * block (racing_mpc.cpp:484-504).  In fp32: the stage records in LDS, the Riccati factor and sweeps and the stage rows --
+ * half the LDS footprint, so twice the resident problems per CU where fp64 is capacity-bound.  Horizons: every N the
+ * fp64 entry accepts for the tracking problem (iac_car_tracking_mpc.param.yaml ships N = 80); N <= 23 for the learning
+ * problem (longer: LMPC_ERR_UNSUPPORTED, the fp64 entry serves them).  Stated accuracy: 1e-3 (scaled) of the fp64
+ * answer on every problem; fit for well-scaled problems (IAC) and for the learning problem, NOT for the BARC tracking
+ * problem at low speed, whose soft boundary needs complementarity below 1e-9. */
 int lmpc_solve_batch_mixed(lmpc_handle* h, int32_t batch, const double* x_ic, const double* u_ic,
                            const double* X_ref, const double* U_ref, const double* T_ref,
                            const double* bound_left, const double* bound_right, const double* curvatures,
@@ -324,17 +327,20 @@ int lmpc_plant_step_batch(lmpc_handle* h, int32_t batch, const lmpc_track* track
 
 /* Grow the handle's device workspace (stage linearisations, 432 B per stage per problem) so
  * that no later *_batch call with batch <= max_batch allocates. */
+int lmpc_reserve(lmpc_handle* h, int32_t max_batch);
+
 /* Launch order of the QP kernel's workgroups (no counterpart upstream: a scheduling aid for closed-loop batches).  The
  * hardware starts workgroups in index order and a batch of 4096 fills the GPU twice, so the kernel's duration is that of
- * the problems that happen to start last.  With `order` -- DEVICE int32 [batch], a permutation of 0 .. batch-1 -- workgroup w
- * solves problem order[w]; lmpc_launch_order_from_iters fills it from the iteration counts of the previous solve of the same
- * cars, longest first (runs on the handle's stream, graph-capturable).  Results per problem do not depend on the order.
- * NULL (the default) restores the XCD-aware mapping.  The pointer is kept, not copied: it must stay valid and hold `batch`
- * entries for every later lmpc_solve_batch* call. */
-int lmpc_set_launch_order(lmpc_handle* h, const int32_t* order);
+ * the problems that happen to start last.  With `order` -- DEVICE int32 [batch], a permutation of 0 .. batch-1 (not
+ * checked: an entry outside the range skips that workgroup, a repeated one leaves another problem's outputs untouched) --
+ * workgroup w solves problem order[w]; lmpc_launch_order_from_iters fills it from the iteration counts of the previous
+ * solve of the same cars, longest first (runs on the handle's stream, graph-capturable).  Results per problem do not
+ * depend on the order.  The order applies to lmpc_solve_batch* calls of exactly `batch` problems; calls with any other
+ * batch size (and the single-problem host entry points) keep the default XCD-aware mapping.  order = NULL restores the
+ * default for every size.  The pointer is kept, not copied: it must stay valid, and must not be rewritten while a solve
+ * that reads it is in flight (one buffer per stream). */
+int lmpc_set_launch_order(lmpc_handle* h, const int32_t* order, int32_t batch);
 int lmpc_launch_order_from_iters(lmpc_handle* h, int32_t batch, const int32_t* iters, int32_t* order);
-
-int lmpc_reserve(lmpc_handle* h, int32_t max_batch);
 
 /* Library/kernel facts for harnesses: bytes of LDS one problem occupies, threads per problem. */
 int lmpc_query_launch(const lmpc_handle* h, int32_t* lds_bytes_per_problem,

@@ -850,6 +850,185 @@ static void primal_update(prob_t* p, double alpha) {
   for (int j = 0; j < p->S; ++j) p->lmb[j] += alpha * p->dlmb[j];
 }
 
+/* ---- active-set polish -------------------------------------------------------------------------
+ * What OSQP's polish = true does for the reference (racing_mpc.cpp:90-95): guess the active rows from the interior
+ * point's slacks and multipliers, solve the equality-constrained QP they define, keep the answer if it passes the KKT
+ * test.  Here, on the machinery of the iteration:
+ *   held rows  = rows with lam > t (for the simplex rows lambda_j >= 0: ll > tl, i.e. lambda_j pinned at 0);
+ *   each round = one factorisation with weight POLISH_THETA on the held rows and 0 on the others (stabilised form),
+ *                then POLISH_STEPS multiplier (augmented-Lagrangian) steps on that factor -- gradient
+ *                cf = y + THETA * residual on the held rows, FULL Newton step, y <- y + THETA * (residual + c'dz),
+ *                the residual taken before the step and the row's own increment added (not re-read after the update:
+ *                in single precision the stored value is rounded, its increment is not) -- which converge like
+ *                (curvature / THETA)^k, i.e. at once;
+ *   verify     : held rows met to POLISH_FEAS with multiplier >= -POLISH_DUAL, every other row satisfied to POLISH_FEAS;
+ *   repair     : if a held row has a negative multiplier, release rows -- only those the interior point did not hold
+ *                firmly (lam < POLISH_STRONG t) if there are such, otherwise the most negative ones (a wrong row drags
+ *                its neighbours' multipliers below zero: releasing everything negative wrecks the set) -- and only when
+ *                no multiplier is negative, hold the rows the new point violates.  Every round restarts from the
+ *                interior-point iterate (held rows from its lam, added rows from 0).
+ * The interior point calls it once when mu <= POLISH_MU with rows feasible to POLISH_RD (about two iterations before its
+ * own tolerance) and again at its own exit if that attempt was refused.  A refused polish leaves the iterate and (t, lam)
+ * untouched.  An accepted one is the optimum to the accuracy of the linear solves (1e-9 .. 1e-12 scaled on the bench
+ * distributions, degenerate problems included: a weakly active row may sit on either side of the guess, the solution is
+ * the same).  The terminal block can hold at most MA_MAX free simplex weights explicitly; with more the polish is not
+ * attempted. */
+#define POLISH_THETA 1e8
+#define POLISH_MU 1e-8
+#define POLISH_RD 1e-6
+#define POLISH_ROUNDS 3
+#define POLISH_STEPS 2
+#define POLISH_FEAS 1e-9
+#define POLISH_DUAL 1e-7
+#define POLISH_STRONG 1e3
+typedef struct {
+  double z[NMAX][8], v[NMAX][2], sigma, lmb[SMAX];
+  rows_t y;
+  double yl[SMAX], resl[SMAX];
+  rows_t res;
+  unsigned char held[NMAX][NSLOT][2], heldl[SMAX];
+} polish_t;
+
+/* (no auto-vectorisation: gcc 11 at -O3 -march=x86-64-v3 miscompiles the mixed int / double classification loop) */
+__attribute__((optimize("no-tree-vectorize"))) static int polish(prob_t* p, work_t* w, polish_t* q, int m_rows, int* rounds_out,
+                                                                  double* mu_out) {
+  const int N = p->N, S = p->S;
+  memcpy(q->z, p->z, sizeof(q->z));
+  memcpy(q->v, p->v, sizeof(q->v));
+  memcpy(q->lmb, p->lmb, sizeof(q->lmb));
+  q->sigma = p->sigma;
+  for (int i = 0; i < N; ++i)
+    for (int sl = 0; sl < NSLOT; ++sl)
+      for (int sd = 0; sd < 2; ++sd) q->held[i][sl][sd] = p->act[i][sl][sd] && p->lam[i][sl][sd] > p->t[i][sl][sd];
+  for (int j = 0; j < S; ++j) q->heldl[j] = p->ll[j] > p->tl[j];
+  int ok = 0;
+  for (int round = 0; round < POLISH_ROUNDS && !ok; ++round) {
+    int nfree = 0;
+    for (int j = 0; j < S; ++j) nfree += !q->heldl[j];
+    if (S && nfree > MA_MAX) break;
+    ++*rounds_out;
+    memcpy(p->z, q->z, sizeof(q->z));
+    memcpy(p->v, q->v, sizeof(q->v));
+    memcpy(p->lmb, q->lmb, sizeof(q->lmb));
+    p->sigma = q->sigma;
+    for (int i = 0; i < N; ++i)
+      for (int sl = 0; sl < NSLOT; ++sl)
+        for (int sd = 0; sd < 2; ++sd) {
+          const int h = q->held[i][sl][sd];
+          w->th[i][sl][sd] = h ? POLISH_THETA : 0.0;
+          q->y[i][sl][sd] = (h && p->lam[i][sl][sd] > p->t[i][sl][sd]) ? p->lam[i][sl][sd] : 0.0;
+        }
+    for (int j = 0; j < S; ++j) {
+      w->thl[j] = q->heldl[j] ? POLISH_THETA : 0.0;
+      q->yl[j] = (q->heldl[j] && p->ll[j] > p->tl[j]) ? p->ll[j] : 0.0;
+    }
+    cost_gradient(p, w);
+    newton_factor(p, w, 1);
+    for (int k = 0; k < POLISH_STEPS; ++k) {
+      cost_gradient(p, w);
+      for (int i = 0; i < N; ++i)
+        for (int sl = 0; sl < NSLOT; ++sl)
+          for (int sd = 0; sd < 2; ++sd) {
+            const int h = q->held[i][sl][sd];
+            q->res[i][sl][sd] = h ? row_res(p, i, sl, sd) : 0.0;
+            w->cf[i][sl][sd] = h ? q->y[i][sl][sd] + POLISH_THETA * q->res[i][sl][sd] : 0.0;
+          }
+      for (int j = 0; j < S; ++j) {
+        q->resl[j] = q->heldl[j] ? -p->lmb[j] : 0.0;
+        w->cfl[j] = q->heldl[j] ? q->yl[j] + POLISH_THETA * q->resl[j] : 0.0;
+      }
+      newton_solve(p, w);
+      primal_update(p, 1.0);
+      for (int i = 0; i < N; ++i)
+        for (int sl = 0; sl < NSLOT; ++sl) {
+          const double dval = slot_val(p->dz, p->dv, i, sl);
+          const double dsg = (sl == SL_EY && p->has_sigma) ? p->dsigma : 0.0;
+          for (int sd = 0; sd < 2; ++sd)
+            if (q->held[i][sl][sd]) q->y[i][sl][sd] += POLISH_THETA * (q->res[i][sl][sd] + ((sd == 0 ? dval : -dval) - dsg));
+        }
+      for (int j = 0; j < S; ++j)
+        if (q->heldl[j]) q->yl[j] += POLISH_THETA * (q->resl[j] - p->dlmb[j]);
+    }
+    /* ---- verify ---- */
+    int bad = 0, anyneg = 0, anyweak = 0, anyviol = 0;
+    double ymin = 0.0, comp = 0.0;
+    for (int i = 0; i < N; ++i)
+      for (int sl = 0; sl < NSLOT; ++sl)
+        for (int sd = 0; sd < 2; ++sd) {
+          if (!p->act[i][sl][sd]) continue;
+          const double r = row_res(p, i, sl, sd);
+          if (q->held[i][sl][sd]) {
+            const double y = q->y[i][sl][sd];
+            if (!(fabs(r) <= POLISH_FEAS)) bad = 1; /* (also a NaN) */
+            if (y < -POLISH_DUAL) {
+              anyneg = 1;
+              if (p->lam[i][sl][sd] < POLISH_STRONG * p->t[i][sl][sd]) anyweak = 1;
+            }
+            if (y < ymin) ymin = y;
+            comp += fabs(y * r);
+          } else if (!(r <= POLISH_FEAS)) {
+            anyviol = 1;
+          }
+        }
+    for (int j = 0; j < S; ++j) {
+      if (q->heldl[j]) {
+        if (!(fabs(p->lmb[j]) <= POLISH_FEAS)) bad = 1;
+        if (q->yl[j] < -POLISH_DUAL) {
+          anyneg = 1;
+          if (p->ll[j] < POLISH_STRONG * p->tl[j]) anyweak = 1;
+        }
+        if (q->yl[j] < ymin) ymin = q->yl[j];
+        comp += fabs(q->yl[j] * p->lmb[j]);
+      } else if (!(-p->lmb[j] <= POLISH_FEAS)) {
+        anyviol = 1;
+      }
+    }
+    if (!bad && !anyneg && !anyviol) {
+      ok = 1;
+      *mu_out = comp / m_rows;
+      break;
+    }
+    /* ---- repair the working set ---- */
+    int changed = 0;
+    for (int i = 0; i < N; ++i)
+      for (int sl = 0; sl < NSLOT; ++sl)
+        for (int sd = 0; sd < 2; ++sd) {
+          if (!p->act[i][sl][sd]) continue;
+          if (q->held[i][sl][sd]) {
+            const double y = q->y[i][sl][sd];
+            const int weak = p->lam[i][sl][sd] < POLISH_STRONG * p->t[i][sl][sd];
+            if (y < -POLISH_DUAL && (anyweak ? weak : y <= 0.5 * ymin)) {
+              q->held[i][sl][sd] = 0;
+              changed = 1;
+            }
+          } else if (!anyneg && !(row_res(p, i, sl, sd) <= POLISH_FEAS)) {
+            q->held[i][sl][sd] = 1;
+            changed = 1;
+          }
+        }
+    for (int j = 0; j < S; ++j) {
+      if (q->heldl[j]) {
+        const int weak = p->ll[j] < POLISH_STRONG * p->tl[j];
+        if (q->yl[j] < -POLISH_DUAL && (anyweak ? weak : q->yl[j] <= 0.5 * ymin)) {
+          q->heldl[j] = 0;
+          changed = 1;
+        }
+      } else if (!anyneg && !(-p->lmb[j] <= POLISH_FEAS)) {
+        q->heldl[j] = 1;
+        changed = 1;
+      }
+    }
+    if (!changed) break; /* (the multiplier steps did not converge on a consistent set: nothing to repair) */
+  }
+  if (!ok) {
+    memcpy(p->z, q->z, sizeof(q->z));
+    memcpy(p->v, q->v, sizeof(q->v));
+    memcpy(p->lmb, q->lmb, sizeof(q->lmb));
+    p->sigma = q->sigma;
+  }
+  return ok;
+}
+
 /* Solve the QP with a Mehrotra predictor-corrector interior-point method.  The iteration
  * stops when the average complementarity mu <= tol (default 3e-14) and every row residual is
  * below 1e-9.  Accuracy (DESIGN.md "numerics"): the cost-to-go is kept exactly symmetric and the last
@@ -857,7 +1036,7 @@ static void primal_update(prob_t* p, double alpha) {
  * down to mu ~ 1e-14; against the dense optimum the returned point is within 1e-6 (scaled) wherever strict
  * complementarity holds with a margin >= 1e-4 (oracle/qp.py strict_complementarity) and within ~1e-5 on
  * degenerate problems, where any interior point is O(sqrt(mu)) away.                                 */
-static int ipm_solve(prob_t* p, work_t* w, int* iters_out, double* kkt_out) {
+static int ipm_solve(prob_t* p, work_t* w, polish_t* pq, int* iters_out, double* kkt_out) {
   const int N = p->N, S = p->S;
   const double tau = 0.995, mu0 = 0.1, thr_frac = 0.5;
   memset(w, 0, sizeof(work_t)); /* (the caller owns the allocation: one per range, not one mmap per solve) */
@@ -922,6 +1101,7 @@ static int ipm_solve(prob_t* p, work_t* w, int* iters_out, double* kkt_out) {
 
   /* ================= phase 1: interior point ================= */
   int distress = 0; /* the complementarity has gone up once: the wide-neighbourhood rule applies from then on */
+  int pol_tried = 0, pol_done = 0, pol_rounds = 0; /* the early polish attempt; an accepted polish; rounds spent */
   double mu_prev = INFINITY;
   for (it = 0; it <= p->max_iter; ++it) {
     double musum = 0.0;
@@ -954,6 +1134,20 @@ static int ipm_solve(prob_t* p, work_t* w, int* iters_out, double* kkt_out) {
     if (mu <= p->tol && rdmax <= 1e-9) {
       status = LMPC_SOLVE_OPTIMAL;
       break;
+    }
+    if (pq && !pol_tried && mu <= POLISH_MU && rdmax <= POLISH_RD) { /* the active set is usually settled by now */
+      pol_tried = 1;
+      if (polish(p, w, pq, m, &pol_rounds, &mu)) {
+        status = LMPC_SOLVE_OPTIMAL;
+        pol_done = 1;
+        break;
+      }
+      /* refused: the iterate is untouched; the weights the polish overwrote are the iteration's own again */
+      for (int i = 0; i < N; ++i)
+        for (int sl = 0; sl < NSLOT; ++sl)
+          for (int sd = 0; sd < 2; ++sd)
+            if (p->act[i][sl][sd]) w->th[i][sl][sd] = p->lam[i][sl][sd] / p->t[i][sl][sd];
+      for (int j = 0; j < S; ++j) w->thl[j] = p->ll[j] / p->tl[j];
     }
     /* primal infeasibility: the row residual contracts by (1 - alpha) per iteration on a feasible problem; if it
      * has not lost a tenth over five iterations while still large (step lengths stuck below ~2 %), give up.  (A
@@ -1089,11 +1283,23 @@ static int ipm_solve(prob_t* p, work_t* w, int* iters_out, double* kkt_out) {
     }
   }
 
+  /* the interior point has converged (or stopped at its floor with status OPTIMAL): polish what it reached */
+  if (pq && status == LMPC_SOLVE_OPTIMAL && !pol_done) pol_done = polish(p, w, pq, m, &pol_rounds, &mu);
   /* ---- exit: report the reduced-gradient stationarity for the multipliers reached ---- */
   double rg = 0.0, viol = rdmax;
   if (status != LMPC_SOLVE_INFEASIBLE) {
     cost_gradient(p, w);
-    rg = stationarity(p, w, p->lam, p->ll);
+    rg = pol_done ? stationarity(p, w, pq->y, pq->yl) : stationarity(p, w, p->lam, p->ll);
+  }
+  if (pol_done) {
+    viol = 0.0;
+    for (int i = 0; i < N; ++i)
+      for (int sl = 0; sl < NSLOT; ++sl)
+        for (int sd = 0; sd < 2; ++sd)
+          if (p->act[i][sl][sd]) {
+            const double r = row_res(p, i, sl, sd);
+            if (r > viol) viol = r;
+          }
   }
   if (kkt_out) {
     kkt_out[0] = rg;
@@ -1101,7 +1307,7 @@ static int ipm_solve(prob_t* p, work_t* w, int* iters_out, double* kkt_out) {
     kkt_out[2] = mu;
     kkt_out[3] = p->sigma;
   }
-  *iters_out = it;
+  *iters_out = it + pol_rounds; /* a polish round costs about what an iteration does and is counted as one */
   return status;
 }
 
@@ -1219,9 +1425,11 @@ int lmpc_oracle_solve_range(const lmpc_config* cfg, const lmpc_vehicle* veh, int
   if (cfg->learning && (cfg->num_ss_pts < 1 || cfg->num_ss_pts > SMAX)) return LMPC_ERR_ARGUMENT;
   prob_t* p = malloc(sizeof(prob_t));
   work_t* w = malloc(sizeof(work_t));
-  if (!p || !w) {
+  polish_t* pq = cfg->polish >= 0 ? malloc(sizeof(polish_t)) : NULL; /* lmpc_config.polish: 0 (default) on, < 0 off */
+  if (!p || !w || (cfg->polish >= 0 && !pq)) {
     free(p);
     free(w);
+    free(pq);
     return LMPC_ERR_RUNTIME;
   }
   for (int b = b0; b < b1; ++b) {
@@ -1233,9 +1441,9 @@ int lmpc_oracle_solve_range(const lmpc_config* cfg, const lmpc_vehicle* veh, int
       st = LMPC_SOLVE_INFEASIBLE;
       /* still report the rollout so the buffers are defined */
       p->max_iter = 0;
-      ipm_solve(p, w, &it, kk);
+      ipm_solve(p, w, NULL, &it, kk);
     } else {
-      st = ipm_solve(p, w, &it, kk);
+      st = ipm_solve(p, w, pq, &it, kk);
     }
     for (int i = 0; i < N; ++i)
       for (int k = 0; k < 6; ++k) X_optm[(size_t)(k * N + i) * B + b] = p->z[i][k];
@@ -1253,6 +1461,7 @@ int lmpc_oracle_solve_range(const lmpc_config* cfg, const lmpc_vehicle* veh, int
   }
   free(p);
   free(w);
+  free(pq);
   return LMPC_OK;
 }
 

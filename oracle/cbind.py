@@ -27,7 +27,8 @@ class CVehicle(C.Structure):
 class CConfig(C.Structure):
     _fields_ = [("N", C.c_int32), ("learning", C.c_int32), ("num_ss_pts", C.c_int32),
                 ("num_ss_pts_per_lap", C.c_int32), ("max_lap_stored", C.c_int32),
-                ("max_iter", C.c_int32), ("tol", C.c_double), ("margin", C.c_double),
+                ("max_iter", C.c_int32), ("polish", C.c_int32), ("reserved", C.c_int32),
+                ("tol", C.c_double), ("margin", C.c_double),
                 ("q_contour", C.c_double), ("q_heading", C.c_double), ("q_vel", C.c_double),
                 ("q_vy", C.c_double), ("q_vyaw", C.c_double), ("q_boundary", C.c_double),
                 ("R", C.c_double * 4), ("R_d", C.c_double * 4),
@@ -45,11 +46,11 @@ def c_vehicle(v: Vehicle) -> CVehicle:
     return cv
 
 
-def c_config(cfg: MPCConfig, max_iter: int = 0, tol: float = 0.0) -> CConfig:
+def c_config(cfg: MPCConfig, max_iter: int = 0, tol: float = 0.0, polish: int = 0) -> CConfig:
     cc = CConfig()
     cc.N, cc.learning = cfg.N, int(cfg.learning)
     cc.num_ss_pts, cc.num_ss_pts_per_lap, cc.max_lap_stored = cfg.num_ss_pts, cfg.num_ss_pts_per_lap, cfg.max_lap_stored
-    cc.max_iter, cc.tol = max_iter, tol
+    cc.max_iter, cc.tol, cc.polish = max_iter, tol, polish
     for n in ("margin", "q_contour", "q_heading", "q_vel", "q_vy", "q_vyaw", "q_boundary", "max_vel_ref_diff"):
         setattr(cc, n, float(getattr(cfg, n)))
     cc.R[:] = list(np.asarray(cfg.R, dtype=float).reshape(-1))
@@ -81,7 +82,7 @@ def _c(a):
 
 
 def solve_batch(cfg: MPCConfig, veh: Vehicle, inp: dict, ss_x=None, ss_j=None, b0=0, b1=None,
-                max_iter: int = 0, tol: float = 0.0) -> dict:
+                max_iter: int = 0, tol: float = 0.0, polish: int = 0) -> dict:
     """inp as produced by oracle.scenario.cold_start_inputs (batch axis last)."""
     N = cfg.N
     B = inp["x_ic"].shape[-1]
@@ -96,7 +97,7 @@ def solve_batch(cfg: MPCConfig, veh: Vehicle, inp: dict, ss_x=None, ss_j=None, b
     status = np.full(B, -1, dtype=np.int32)
     iters = np.zeros(B, dtype=np.int32)
     kkt = np.zeros((4, B))
-    cc, cv = c_config(cfg, max_iter, tol), c_vehicle(veh)
+    cc, cv = c_config(cfg, max_iter, tol, polish), c_vehicle(veh)
     rc = lib().lmpc_oracle_solve_range(C.byref(cc), C.byref(cv), C.c_int32(B), C.c_int32(b0), C.c_int32(b1),
                                        *[_p(a) for a in arrs], _p(ss_x), _p(ss_j), _p(X), _p(U), _p(dU),
                                        _p(lam), _p(status), _p(iters), _p(kkt))

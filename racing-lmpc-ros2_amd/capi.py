@@ -37,7 +37,8 @@ class CVehicle(C.Structure):
 class CConfig(C.Structure):
     _fields_ = [("N", C.c_int32), ("learning", C.c_int32), ("num_ss_pts", C.c_int32),
                 ("num_ss_pts_per_lap", C.c_int32), ("max_lap_stored", C.c_int32),
-                ("max_iter", C.c_int32), ("tol", C.c_double), ("margin", C.c_double),
+                ("max_iter", C.c_int32), ("polish", C.c_int32), ("reserved", C.c_int32),
+                ("tol", C.c_double), ("margin", C.c_double),
                 ("q_contour", C.c_double), ("q_heading", C.c_double), ("q_vel", C.c_double),
                 ("q_vy", C.c_double), ("q_vyaw", C.c_double), ("q_boundary", C.c_double),
                 ("R", C.c_double * 4), ("R_d", C.c_double * 4),
@@ -61,6 +62,9 @@ class CTrack(C.Structure):
 def _fill(struct, values: dict):
     for name, ctype in struct._fields_:
         if name == "reserved":
+            continue
+        if name == "polish":         # 0 (default): on, < 0: off -- presets need not carry the key
+            setattr(struct, name, int(values.get("polish", 0)))
             continue
         if name == "integrator":     # modeling.integrator_type, "rk4" (default) or "euler"
             iv = values.get("integrator", 0)
@@ -257,9 +261,10 @@ class Solver:
 
     # ---- launch order (longest job first; include/lmpc_hip.h) ----
     def set_launch_order(self, order):
-        """order: int32 device tensor [batch] (kept alive here) or None for the default mapping."""
+        """order: int32 device tensor [batch] (kept alive here; applies to solves of that batch size) or None for the default mapping."""
         self._launch_order = None if order is None else self._torch.as_tensor(order, dtype=self._torch.int32, device=self.device).contiguous()
-        self._check(self.lib.lmpc_set_launch_order(self._h, _ptr(self._launch_order)), "lmpc_set_launch_order")
+        n = 0 if self._launch_order is None else int(self._launch_order.numel())
+        self._check(self.lib.lmpc_set_launch_order(self._h, _ptr(self._launch_order), C.c_int32(n)), "lmpc_set_launch_order")
 
     def launch_order_from_iters(self, iters, order=None):
         """Fills (and returns) `order` from the iteration counts of the previous solve of the same batch, longest first."""

@@ -6,8 +6,6 @@
 // product fails loudly (negative return code + message) rather than falling back to a CPU path.
 #include <hip/hip_runtime.h>
 
-#include <cstdlib>
-
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -36,9 +34,6 @@ __global__ void lmpc_reg_pack_kernel(lmpc_regression_spec, int, int, const int*,
 template <int NF, int NOUT, bool WS_LAYOUT>
 __global__ void lmpc_regress_kernel(int, int, lmpc_regression_spec, int, const double*, const double*, const double*, double*,
                                     double*, double*);
-template <int KQ>
-__global__ void lmpc_solve_kernel_g4(lmpc_params, int, const double*, const double*, const double*, const double*, const double*,
-                                     const double*, const double*, double*, double*, double*, int*, int*, double*);
 __global__ void lmpc_launch_order_kernel(int, const int*, int*);
 struct lmpc_sqp_arrays;
 __global__ void lmpc_sqp_linesearch_kernel(lmpc_params, int, lmpc_sqp_arrays, int, double);
@@ -49,6 +44,8 @@ struct lmpc_handle {
   lmpc_config cfg;
   int device = 0;
   hipStream_t stream = nullptr;  // nullptr = the device's default (null) stream
+  const int* order = nullptr;  // lmpc_set_launch_order: device [order_n], applied to solves of that batch size only
+  int order_n = 0;
   double* ws = nullptr;  // [cap][N-1][LMPC_LIN_RECORD]
   size_t ws_cap = 0;
   float* ws_f32 = nullptr;  // the same for the single-precision solve
@@ -62,7 +59,6 @@ struct lmpc_handle {
   double ss_L = 0.0;
   int ss_nmax = 0;
   // regression store (device): lap samples, one-step residuals of the nominal model, end-of-lap flags
-  bool grouped = false;  // tracking fp64 N <= 23 through lmpc_solve_kernel_g4 (environment LMPC_GROUPED=1 at lmpc_create)
   bool reg_on = false;
   int reg_total = 0;
   int* reg_end = nullptr;
@@ -170,24 +166,12 @@ const void* pick_mixed_fn(int kq, int ks) {
   return nullptr;
 }
 
-// four problems per workgroup (csrc/lmpc_solve_kernel_g4.hip): tracking problem, fp64, N <= 23
-int launch_solve_g4(lmpc_handle* h, int kq, const solve_args& a) {
-  const void* fn = kq <= 2 ? reinterpret_cast<const void*>(&lmpc_solve_kernel_g4<2>) : reinterpret_cast<const void*>(&lmpc_solve_kernel_g4<4>);
-  const size_t lds = 4 * a.lds_bytes + 64;
-  HIP_TRY(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  lmpc_params P = h->P;
-  int B = a.B;
-  const double* ws = h->ws;
-  void* args[] = {(void*)&P,    (void*)&B,    (void*)&ws,  (void*)&a.x_ic, (void*)&a.u_ic,   (void*)&a.T_ref, (void*)&a.bl, (void*)&a.br,
-                  (void*)&a.vref, (void*)&a.X, (void*)&a.U, (void*)&a.dU,   (void*)&a.status, (void*)&a.iters, (void*)&a.kkt};
-  const int G = (a.B + 3) / 4;
-  HIP_TRY(h, hipLaunchKernel(fn, dim3(8 * ((G + 7) / 8)), dim3(256), args, lds, h->stream));
-  return LMPC_OK;
-}
-
 int launch_solve(lmpc_handle* h, const void* fn, const solve_args& a) {
   HIP_TRY(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)a.lds_bytes));
   lmpc_params P = h->P;
+  // the registered order applies to solves of exactly its own batch size; every other launch through this handle (the
+  // single-problem host path, the SQP's QPs on another batch, ...) keeps the default mapping
+  P.launch_order = (h->order && a.B == h->order_n) ? h->order : nullptr;
   int B = a.B;
   const double* ws = h->ws;
   void* args[] = {(void*)&P,        (void*)&B,      (void*)&ws,      (void*)&a.x_ic, (void*)&a.u_ic, (void*)&a.T_ref,
@@ -228,10 +212,6 @@ int lmpc_create(const lmpc_config* cfg, const lmpc_vehicle* veh, int device, lmp
   if (!cfg || !veh || !out) return LMPC_ERR_ARGUMENT;
   *out = nullptr;
   lmpc_handle* h = new (std::nothrow) lmpc_handle();
-  if (h) {
-    const char* e = getenv("LMPC_GROUPED");
-    h->grouped = e && e[0] == '1';
-  }
   if (!h) return LMPC_ERR_RUNTIME;
   *out = h;  // returned even on failure so that lmpc_last_error can be read; caller destroys it
   if (veh->model_id != LMPC_MODEL_SINGLE_TRACK_PLANAR)
@@ -459,8 +439,7 @@ int solve_batch_fp64_arrays(lmpc_handle* h, bool mixed, int32_t batch, const dou
   a.ss_x = h->P.learning ? ss_x : nullptr; a.ss_j = h->P.learning ? ss_j : nullptr;
   a.lam = h->P.learning ? convex_combi_optm : nullptr;
   a.X = X_optm; a.U = U_optm; a.dU = dU_optm; a.status = status; a.iters = iters; a.kkt = kkt;
-  const bool grouped = h->grouped && !mixed && !h->P.learning && kq_for(N) <= 4;
-  const int rc = grouped ? launch_solve_g4(h, kq_for(N), a) : launch_solve(h, fn, a);
+  const int rc = launch_solve(h, fn, a);
   if (rc != LMPC_OK) return rc;
   if (h->timing) HIP_TRY(h, hipEventRecord(h->ev[2], h->stream));
   return LMPC_OK;
@@ -969,9 +948,11 @@ int lmpc_set_regression_laps(lmpc_handle* h, int32_t n_laps, const int32_t* n_pt
   return LMPC_OK;
 }
 
-int lmpc_set_launch_order(lmpc_handle* h, const int32_t* order) {
+int lmpc_set_launch_order(lmpc_handle* h, const int32_t* order, int32_t batch) {
   if (!h) return LMPC_ERR_ARGUMENT;
-  h->P.launch_order = order;
+  if (order && batch <= 0) return fail(h, LMPC_ERR_ARGUMENT, "lmpc_set_launch_order: an order needs its length (batch > 0)");
+  h->order = order;
+  h->order_n = order ? batch : 0;
   return LMPC_OK;
 }
 

@@ -7,7 +7,8 @@
 // Everything the kernels need from lmpc_config / lmpc_vehicle, pre-digested on the host
 // (lmpc_create).  Passed by value as a kernel argument (lands in the kernarg segment / SGPRs).
 struct lmpc_params {
-  const int* launch_order;  // device [batch] or null: workgroup w solves problem launch_order[w] (lmpc_set_launch_order)
+  const int* launch_order;  // device [batch] or null: workgroup w solves problem launch_order[w] (set per launch by the host
+                            // layer from lmpc_set_launch_order, only when the batch size matches the registered length)
   int N;          // knot points
   int has_sigma;  // q_boundary > 0: one shared boundary slack (racing_mpc.cpp:529-539)
   int learning;   // LMPC terminal set + cost (racing_mpc.cpp:479-522)

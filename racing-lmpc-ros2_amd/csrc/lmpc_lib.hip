@@ -2,7 +2,6 @@
 // code is compiled without relocatable-device-code linking and -Rpass-analysis reports per kernel.
 #include "lmpc_prep_kernels.hip"
 #include "lmpc_solve_kernel.hip"
-#include "lmpc_solve_kernel_g4.hip"
 #include "lmpc_ss_kernel.hip"
 #include "lmpc_reg_kernel.hip"
 #include "lmpc_sqp_kernel.hip"

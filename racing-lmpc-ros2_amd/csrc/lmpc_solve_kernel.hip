@@ -135,21 +135,24 @@ struct Prof {};
 #define F_SCH 64
 #define MROW 10  // padded row stride of the 8x8 work matrices (conflict-free b128 row reads)
 
-// The workgroup is a single wavefront and the LDS executes one wave's DS instructions in issue order,
-// so cross-lane exchange through LDS needs no s_barrier and no wait for the write to retire: only the
-// compiler must not move memory operations across the exchange point.
-__device__ __forceinline__ void wave_sync() { __builtin_amdgcn_wave_barrier(); }
-// The same with memory-model fences at wavefront scope around it.  wave_barrier alone is invisible to the IR-level memory
-// passes (it is declared as not touching memory), so around a store that only SOME lanes execute -- `if (lane == 0)
-// T[..] = ..` -- the compiler may schedule the other lanes' later loads of those cells on the not-taken path ahead of the
-// taken path's stores: the readers then see the previous workgroup's LDS content.  (Seen on the terminal block of the
-// learning problem: results changed from process to process.)  The fences pin the order; at wavefront scope they cost no
-// cache action.
+// The workgroup is a single wavefront and the LDS executes one wave's DS instructions in issue order, so cross-lane
+// exchange through LDS needs no s_barrier and no wait for the write to retire: only the compiler must not move memory
+// operations across the exchange point.  __builtin_amdgcn_wave_barrier alone does not say that -- it is declared as not
+// touching memory, so around a store that only SOME lanes execute (`if (lane < 6) T[..] = ..`) the IR-level passes may
+// still schedule the other lanes' later loads of those cells, on the not-taken path, ahead of the taken path's stores:
+// the readers then see the previous content (seen once on the terminal block of the learning problem: results changed
+// from process to process).  Release / acquire fences at WAVEFRONT scope around the barrier pin the order; at that scope
+// they emit no cache action and no wait.
 __device__ __forceinline__ void wave_fence() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+#ifdef LMPC_PLAIN_SYNC  // (A/B timing only: the unfenced exchange point of rounds 1-2)
+__device__ __forceinline__ void wave_sync() { __builtin_amdgcn_wave_barrier(); }
+#else
+__device__ __forceinline__ void wave_sync() { wave_fence(); }
+#endif
 
 // A value that is the same in every lane, moved to scalar registers (v_readfirstlane): the solver's
 // wave-wide scalars (mu, step lengths, sigma, ...) then cost no vector registers while they are carried
@@ -1041,15 +1044,13 @@ __device__ void riccati_solve(const Lds<real>& L, int lane, Prof& pf) {
   PT_MARK(10 + NRHS - 1)
 }
 
-// The same solve with the running vector exchanged through LDS (what riccati_solve did until round 2): kept for the grouped
-// kernel, whose lanes (problem, rhs, component) do not fit one right-hand side per DPP row.
-// NP > 1 (lmpc_solve_kernel_g4): the wave carries the sweeps of NP problems at once -- lane (p, s, r), L.base is then a
-// per-lane value (problem p's records) and the 2-vector spread stays inside a group of 8 lanes for either NRHS.
-template <int NRHS, int NP = 1, typename real>
+// The same solve with the running vector exchanged through LDS (what riccati_solve did until round 2): the form the
+// one-wave-per-SIMD instantiations keep (see the call site).
+template <int NRHS, typename real>
 __device__ void riccati_solve_lds(const Lds<real>& L, int lane, Prof& pf) {
   const int N = L.N;
   const int r = lane & 7, s = (lane >> 3) & (NRHS - 1);
-  const bool own = lane < 8 * NRHS * NP;
+  const bool own = lane < 8 * NRHS;
   const int reg = KN_R0 + 10 * s;
   real* T = L.tail();
   real* const junk0 = T + TL_W + lane;  // 64 + 64 dead cells: W (80) and Y (80) are contiguous
@@ -1057,7 +1058,7 @@ __device__ void riccati_solve_lds(const Lds<real>& L, int lane, Prof& pf) {
   real* const pvec = T + TL_PV + 8 * s;
   real* const pdst = own ? pvec + r : junk0;
   auto spread2 = [&](real v, real& a, real& b) {  // values of lanes (s, 6) and (s, 7) to the whole group
-    if constexpr (NRHS == 2 || NP > 1) {
+    if constexpr (NRHS == 2) {
       a = group_bcast<0x00D8>(v);
       b = group_bcast<0x00F8>(v);
     } else {

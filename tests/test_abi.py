@@ -23,11 +23,11 @@ def test_header_symbols_are_exported(pkg):
 
 
 def test_struct_sizes_match_header(pkg):
-    # lmpc_vehicle: 2 int32 + 25 doubles; lmpc_config: 6 int32 + 39 doubles; lmpc_track: double + 2 int32 + 4 ptrs
+    # lmpc_vehicle: 2 int32 + 25 doubles; lmpc_config: 8 int32 + 39 doubles; lmpc_track: double + 2 int32 + 4 ptrs
     from importlib import import_module
     capi = import_module(pkg.__name__ + ".capi")
     assert C.sizeof(capi.CVehicle) == 8 + 25 * 8
-    assert C.sizeof(capi.CConfig) == 24 + 39 * 8
+    assert C.sizeof(capi.CConfig) == 32 + 39 * 8
     assert C.sizeof(capi.CTrack) == 16 + 4 * 8
 
 

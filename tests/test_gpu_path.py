@@ -869,27 +869,6 @@ def test_zero_components_of_the_hull_slack_weight_on_the_device(pkg, golden):
         pkg.Solver(preset, pkg.presets.barc_vehicle(), device=0)
 
 
-def test_grouped_kernel_matches_the_golden_vectors_and_the_default_kernel(pkg, golden, monkeypatch):
-    """lmpc_solve_kernel_g4 (opt-in, LMPC_GROUPED=1 at lmpc_create: four problems per workgroup, one wave runs the Riccati
-    vector sweeps of all four) is the same algorithm per problem: the golden vectors to the contract, the default kernel's
-    answers to the twin tolerance, and a batch that does not fill its last group (6 = 4 + 2: two surplus waves)."""
-    g = golden("qp_barc_tracking_n20")
-    veh, cfg, solver, *_ = make(pkg, "barc20", 1, 0)
-    base = to_np(solver.solve(g))
-    monkeypatch.setenv("LMPC_GROUPED", "1")
-    grouped = pkg.Solver(pkg.presets.barc_tracking_mpc(20), pkg.presets.barc_vehicle(), device=0)
-    monkeypatch.delenv("LMPC_GROUPED")
-    out = to_np(grouped.solve(g))
-    assert_contract(out, g, g["margin"], g["certified"], who="grouped kernel")
-    assert_same_iterations(out["iters"], base["iters"])
-    for k, sc, tol in (("X_optm", P.SCALE_X, TOL_TWIN), ("U_optm", P.SCALE_U, TOL_TWIN), ("dU_optm", P.SCALE_U, TOL_DU)):
-        assert scaled_err(out[k], base[k], sc) < tol, k
-    six = {k: (v[..., :6].copy() if isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[-1] == g["x_ic"].shape[-1] else v) for k, v in g.items()}
-    o6 = to_np(grouped.solve(six))
-    assert (o6["status"] == 0).all()
-    assert np.array_equal(o6["X_optm"], out["X_optm"][..., :6]) and np.array_equal(o6["iters"], out["iters"][:6])
-
-
 @pytest.mark.parametrize("N,n_laps,n_dense", [(40, 3, 6), (80, 5, 3)])
 def test_lmpc_at_long_horizons_against_the_dense_optimum(pkg, N, n_laps, n_dense):
     """barc_lmpc.param.yaml ships N = 40; N = 80 is the longest instantiation.  Not the twin but the DENSE optimum, with the
@@ -968,6 +947,10 @@ def test_launch_order_changes_the_schedule_not_the_answers(pkg):
     again = solver.solve(inp)
     solver.set_launch_order(torch.arange(999, -1, -1, dtype=torch.int32, device="cuda"))
     rev = solver.solve(inp)
+    # a solve of another batch size through the same handle ignores the registered order (it has 1000 entries)
+    few = {k: (np.ascontiguousarray(v[..., :7]) if isinstance(v, np.ndarray) and v.ndim and v.shape[-1] == 1000 else v) for k, v in inp.items()}
+    small = solver.solve(few)
     solver.set_launch_order(None)
     for k in ref:
         assert torch.equal(again[k], ref[k]) and torch.equal(rev[k], ref[k]), k
+        assert torch.equal(small[k], ref[k][..., :7]), k
