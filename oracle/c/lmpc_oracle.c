@@ -1135,6 +1135,18 @@ static int ipm_solve(prob_t* p, work_t* w, polish_t* pq, int* iters_out, double*
       status = LMPC_SOLVE_OPTIMAL;
       break;
     }
+    /* primal infeasibility: the row residual contracts by (1 - alpha) per iteration on a feasible problem; if it
+     * has not lost a tenth over five iterations while still large (step lengths stuck below ~2 %), give up.  (A
+     * tighter test -- "not halved" -- rejects feasible problems with a slow start: IAC at 60 m/s into a corner
+     * needs 20-30 iterations and contracts by 0.6-0.8 per five early on.) */
+    if (it % 5 == 0) {
+      if (it >= 10 && rdmax > 1e-6 && rdmax > 0.9 * rd_check) {
+        status = LMPC_SOLVE_INFEASIBLE;
+        break;
+      }
+      rd_check = rdmax;
+    }
+    if (it == p->max_iter) break;
     if (pq && !pol_tried && mu <= POLISH_MU && rdmax <= POLISH_RD) { /* the active set is usually settled by now */
       pol_tried = 1;
       if (polish(p, w, pq, m, &pol_rounds, &mu)) {
@@ -1149,18 +1161,6 @@ static int ipm_solve(prob_t* p, work_t* w, polish_t* pq, int* iters_out, double*
             if (p->act[i][sl][sd]) w->th[i][sl][sd] = p->lam[i][sl][sd] / p->t[i][sl][sd];
       for (int j = 0; j < S; ++j) w->thl[j] = p->ll[j] / p->tl[j];
     }
-    /* primal infeasibility: the row residual contracts by (1 - alpha) per iteration on a feasible problem; if it
-     * has not lost a tenth over five iterations while still large (step lengths stuck below ~2 %), give up.  (A
-     * tighter test -- "not halved" -- rejects feasible problems with a slow start: IAC at 60 m/s into a corner
-     * needs 20-30 iterations and contracts by 0.6-0.8 per five early on.) */
-    if (it % 5 == 0) {
-      if (it >= 10 && rdmax > 1e-6 && rdmax > 0.9 * rd_check) {
-        status = LMPC_SOLVE_INFEASIBLE;
-        break;
-      }
-      rd_check = rdmax;
-    }
-    if (it == p->max_iter) break;
     cost_gradient(p, w);
     newton_factor(p, w, mu <= JOSEPH_MU);
     double sigc = 0.0, alpha = 1.0;
@@ -1261,7 +1261,20 @@ static int ipm_solve(prob_t* p, work_t* w, polish_t* pq, int* iters_out, double*
         if (rdmax <= 1e-9 && mu <= STALL_MU && s / m >= mu) stalled = 1;
       }
     }
-    if (stalled) {
+    if (stalled) { /* the primal iterate is kept; slacks and multipliers have taken the corrector step (as in the kernel, which
+                    * updates them before it knows): they are what the polish classifies the rows by */
+      for (int i = 0; i < N; ++i)
+        for (int sl = 0; sl < NSLOT; ++sl)
+          for (int sd = 0; sd < 2; ++sd)
+            if (p->act[i][sl][sd]) {
+              p->t[i][sl][sd] += alpha * p->dtt[i][sl][sd];
+              p->lam[i][sl][sd] += alpha * p->dlam[i][sl][sd];
+            }
+      for (int j = 0; j < S; ++j) { /* (the kernel's simplex rows carry lambda with them: it moves too) */
+        p->tl[j] += alpha * p->dtl[j];
+        p->ll[j] += alpha * p->dll[j];
+        p->lmb[j] += alpha * p->dlmb[j];
+      }
       status = LMPC_SOLVE_OPTIMAL;
       break;
     }

@@ -166,9 +166,13 @@ const void* pick_mixed_fn(int kq, int ks) {
   return nullptr;
 }
 
-int launch_solve(lmpc_handle* h, const void* fn, const solve_args& a) {
+// pass: 0 a plain solve; 1 the fp32 iteration of a two-pass mixed solve (marks what it could not verify); 2 the fp64 kernel
+// behind it (solves the marked problems only)
+int launch_solve(lmpc_handle* h, const void* fn, const solve_args& a, int pass = 0) {
   HIP_TRY(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)a.lds_bytes));
   lmpc_params P = h->P;
+  P.flag_unverified = pass == 1;
+  P.cleanup = pass == 2;
   // the registered order applies to solves of exactly its own batch size; every other launch through this handle (the
   // single-problem host path, the SQP's QPs on another batch, ...) keeps the default mapping
   P.launch_order = (h->order && a.B == h->order_n) ? h->order : nullptr;
@@ -239,6 +243,7 @@ int lmpc_create(const lmpc_config* cfg, const lmpc_vehicle* veh, int device, lmp
   P.learning = cfg->learning ? 1 : 0;
   P.S = cfg->learning ? cfg->num_ss_pts : 0;
   P.max_iter = cfg->max_iter > 0 ? cfg->max_iter : 40;
+  P.polish = cfg->polish;
   P.tol = cfg->tol > 0.0 ? cfg->tol : 3e-14;
   const double qd[6] = {0.0, cfg->q_contour, cfg->q_heading, cfg->q_vel, cfg->q_vy, cfg->q_vyaw};
   const double qt[6] = {0.0, cfg->q_contour, cfg->q_heading, cfg->q_vel, 0.0, 0.0};
@@ -439,8 +444,19 @@ int solve_batch_fp64_arrays(lmpc_handle* h, bool mixed, int32_t batch, const dou
   a.ss_x = h->P.learning ? ss_x : nullptr; a.ss_j = h->P.learning ? ss_j : nullptr;
   a.lam = h->P.learning ? convex_combi_optm : nullptr;
   a.X = X_optm; a.U = U_optm; a.dU = dU_optm; a.status = status; a.iters = iters; a.kkt = kkt;
-  const int rc = launch_solve(h, fn, a);
+  // Mixed precision is two launches when the polish is on: the fp32 iteration verifies its own answers (polish accepted =
+  // KKT test passed) and marks the problems it could not verify -- a percent of a batch: active sets still ambiguous at
+  // mu = 2e-6, or more than four free simplex weights -- and the fp64 kernel behind it solves exactly those.
+  const bool two_pass = mixed && h->P.polish >= 0;
+  int rc = launch_solve(h, fn, a, two_pass ? 1 : 0);
   if (rc != LMPC_OK) return rc;
+  if (two_pass) {
+    const void* fn64 = pick_solve_fn(kq_for(N), ks_for(h->P.S));
+    if (!fn64) return fail(h, LMPC_ERR_UNSUPPORTED, "no fp64 kernel for this (N, num_ss_pts)");
+    a.lds_bytes = lmpc_lds_bytes(N, h->P.learning, h->P.S, 8);
+    rc = launch_solve(h, fn64, a, 2);
+    if (rc != LMPC_OK) return rc;
+  }
   if (h->timing) HIP_TRY(h, hipEventRecord(h->ev[2], h->stream));
   return LMPC_OK;
 }
@@ -503,6 +519,7 @@ int lmpc_solve_batch_f32(lmpc_handle* h, int32_t batch, const float* x_ic, const
   const size_t lds = lmpc_lds_bytes(N, 0, 0, 4);
   HIP_TRY(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   lmpc_params P = h->P;
+  P.launch_order = (h->order && batch == h->order_n) ? h->order : nullptr;
   int B = batch;
   const float *ws = h->ws_f32, *nul = nullptr;
   float* nulo = nullptr;

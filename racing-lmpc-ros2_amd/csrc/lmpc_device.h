@@ -14,7 +14,7 @@ struct lmpc_params {
   int learning;   // LMPC terminal set + cost (racing_mpc.cpp:479-522)
   int S;          // safe-set points
   int max_iter;
-  int pad0;
+  int polish;     // lmpc_config.polish: >= 0 the active-set polish runs (racing_mpc.cpp:90-95, OSQP polish = true)
   double tol;      // complementarity tolerance of the interior-point iteration
   double Qd[6];    // 2*q stage weights on x      (racing_mpc.cpp:459-463)
   double Qt[6];    // 2*10*q terminal weights     (racing_mpc.cpp:474-476)
@@ -29,8 +29,14 @@ struct lmpc_params {
   double marg;             // margin + chassis.b / 2 (racing_mpc.cpp:531)
   double chs2[6];          // 2 * convex_hull_slack
   double max_vel_ref_diff;
+  // two-pass mixed precision (set per launch by the host layer): the fp32 iteration marks a problem whose answer it could not
+  // verify (polish refused) with LMPC_SOLVE_UNVERIFIED instead of OPTIMAL; the fp64 kernel launched behind it with cleanup = 1
+  // solves exactly the marked problems and leaves the others alone
+  int flag_unverified;
+  int cleanup;
   lmpc_vehicle veh;
 };
+#define LMPC_SOLVE_UNVERIFIED 3  // (internal: never leaves lmpc_solve_batch_mixed)
 
 // LDS record sizes (in doubles) of the solve kernel; see DESIGN.md "data layout".
 #define LMPC_STAGE_STRIDE 78

@@ -342,6 +342,28 @@ template <> struct ipm_limits<float> {
   static constexpr float rd_ok = 1e-4f, rd_infeasible = 1e-2f, tiny = 1e-30f;
   static constexpr float rd_distress = 1e-4f;
 };
+// Active-set polish (what OSQP's polish = true is to the reference, racing_mpc.cpp:90-95; derivation and measurements in
+// oracle/c/lmpc_oracle.c, which runs the same rounds): rows with lam > t are HELD -- weight theta on them, none on the
+// others, one stabilised factorisation -- then `steps` multiplier steps on that factor (gradient y + theta * residual on
+// the held rows, full Newton step, y <- y + theta * (residual + the row's own increment)), a KKT test (held rows met to
+// `feas` with y >= -dual, the others satisfied to `feas`), and up to `rounds` repairs of the held set.  Double precision
+// tries it once as soon as mu <= mu_early with rows feasible to rd_early -- about two iterations before the interior
+// point's own tolerance, and the stabilised factorisations of those iterations are the ones it saves -- and again at
+// convergence if refused; single precision polishes at its convergence (mu ~ 2e-6), where it turns "within sqrt(mu) of the
+// optimum" into "the optimum to the accuracy of an fp32 solve".
+template <typename real> struct polish_limits;
+template <> struct polish_limits<double> {
+  static constexpr double theta = 1e8, feas = 1e-9, dual = 1e-7, mu_early = 1e-8, rd_early = 1e-6;
+  static constexpr int rounds = 3, steps = 2;
+};
+template <> struct polish_limits<float> {
+  // theta: 1e7 needs the stabilised factor and the fp64 2x2 pivot; with 1e5 chains of held input rows (u_i = u_{i-1} + t v_i,
+  // stiffness R_d / t^2 per link) converge like 0.7 per step.  Three steps: the third removes the rounding of the first two.
+  static constexpr float theta = 1e7f, feas = 1e-5f, dual = 1e-3f, mu_early = 0.0f, rd_early = 0.0f;
+  static constexpr int rounds = 4, steps = 3;
+};
+#define POLISH_THETA_L 1e8  // the simplex rows (always fp64)
+#define POLISH_STRONG 1e3   // a row with lam >= POLISH_STRONG t is one the interior point holds firmly
 template <typename real> struct vec2;
 template <> struct vec2<double> { typedef double2 type; };
 template <> struct vec2<float> { typedef float2 type; };
@@ -400,6 +422,19 @@ __device__ __forceinline__ real simplex_bl(real lm, real t, real l, real pprod, 
   const real th = l * it_;
   itf = frcp(th);
   const real cf = th * (-lm + t) + (smu - pm * pprod) * it_;
+  real ue = 0.0;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) ue += u[k] * ee[k];
+  return ssj - cf - ue;
+}
+
+// The same row in a polish round: barrier coefficient y + theta (-lambda_j) if the row lambda_j >= 0 is held (weight theta),
+// none if lambda_j is free (it is then one of the explicit unknowns: 1/theta is not used).
+template <typename real>
+__device__ __forceinline__ real simplex_bl_polish(real lm, real y, bool held, real ssj, const real (&u)[6], const real (&ee)[6],
+                                                    real& itf) {
+  itf = held ? real(1.0 / POLISH_THETA_L) : real(0);
+  const real cf = held ? y - real(POLISH_THETA_L) * lm : real(0);
   real ue = 0.0;
 #pragma unroll
   for (int k = 0; k < 6; ++k) ue += u[k] * ee[k];
@@ -689,6 +724,7 @@ struct SimplexRows {
   bool on[KS];
   int aidx[KS];  // slot of the point among the explicit ones of this iteration, -1: eliminated through 1/theta
   real lm[KS], t[KS], l[KS], p[KS], j[KS], dl[KS];
+  real sv[KS];  // lambda at the start of a polish (restored when it is refused)
   const real* ul;  // the (centred) points in LDS, component k of point j at ul[k * 64 KS + j]: read-only after the load, 36
                    // registers (KS = 3) the iteration's row state needs more -- consecutive lanes read consecutive cells
   __device__ __forceinline__ void load_u(int q, int lane, real (&u)[6]) const {
@@ -1218,6 +1254,7 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
   int b = (int)(blockIdx.x & 7) * ((B + 7) >> 3) + (int)(blockIdx.x >> 3);
   if (P.launch_order) b = (int)blockIdx.x < B ? P.launch_order[blockIdx.x] : B;
   if (b >= B) return;
+  if (P.cleanup && status_out[b] != LMPC_SOLVE_UNVERIFIED) return;  // second pass of a mixed solve: the marked problems only
   const int lane = threadIdx.x;
   const int N = P.N, NS = N - 1;
   typedef typename vec2<real>::type real2;
@@ -1454,6 +1491,54 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
   real mu = 0.0, rdmax = 0.0, rd_check = 0.0, last_step = 0.0, hsig = 0.0, ce = 0.0, mu_prev = inf;
   bool distress = false;
   const int max_iter = feasible ? P.max_iter : 0;
+  // ---- polish state (wave-uniform unless noted) ----
+  typedef polish_limits<real> pol;
+  const bool polish_on = P.polish >= 0;
+  bool polishing = false;    // the rounds below run instead of interior-point iterations
+  bool pol_init = false;     // the next round is the first of an attempt: classify the rows, keep the iterate
+  bool pol_final = false;    // the attempt at the interior point's own exit (a refusal then ends the solve with its iterate)
+  bool pol_early_done = false, polished = false, reentry = false;
+  int pol_round = 0, pol_rounds = 0;
+  int held = 0;              // (per lane) bit 2q / 2q + 1: upper / lower row of slot q held; bit 28 + q: simplex row q held
+  real sigma_keep = 0.0;
+  // The iterate as it stands goes to the result arrays (the abscissa without the single-precision shift, so that it
+  // reads back exactly) and comes back from them when a polish is refused: no registers are held for it across the
+  // sweeps, and every lane reads back what it wrote itself.
+  auto put_primal = [&](bool shifted) {
+    for (int e = lane; e < 6 * N; e += 64) {
+      const int k = e / N, i = e - k * N;
+      X_out[(size_t)(k * N + i) * B + b] = io(L.kn(i)[k]) + ((shifted && k == 0) ? s_shift : io(0));
+    }
+    for (int e = lane; e < 2 * NS; e += 64) {
+      const int k = e / NS, i = e - k * NS;
+      U_out[(size_t)(k * NS + i) * B + b] = io(L.kn(i + 1)[6 + k]);
+      dU_out[(size_t)(k * NS + i) * B + b] = io(L.kn(i)[8 + k]);
+    }
+  };
+  auto get_primal = [&]() {
+    for (int e = lane; e < 6 * N; e += 64) {
+      const int k = e / N, i = e - k * N;
+      if (i >= 1) L.kn(i)[k] = real(X_out[(size_t)(k * N + i) * B + b]);
+    }
+    for (int e = lane; e < 2 * NS; e += 64) {
+      const int k = e / NS, i = e - k * NS;
+      L.kn(i + 1)[6 + k] = real(U_out[(size_t)(k * NS + i) * B + b]);
+      L.kn(i)[8 + k] = real(dU_out[(size_t)(k * NS + i) * B + b]);
+    }
+  };
+
+  // a refused polish: iterate, slack variable and simplex weights as the interior point left them (its t, lam were never touched)
+  auto refuse = [&]() {
+    wave_sync();
+    get_primal();
+    sigma = sigma_keep;
+    if constexpr (KS > 0) {
+#pragma unroll
+      for (int q = 0; q < KS; ++q) sx.lm[q] = sx.sv[q];
+    }
+    wave_sync();
+    polishing = false;
+  };
 
   // it == -1 is the start-point Newton step (all row weights zero, full step); it >= 0 the
   // interior-point iterations.
@@ -1461,8 +1546,41 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
     const bool ipm = it >= 0;
     // ======== rows: complementarity, residual, barrier weights ========
     if (ipm) {
+     bool again, leave = false;
+     do {  // (a second time when the interior point hands over to the polish in this iteration, or takes over again)
+      again = false;
       real musum = 0.0, rdl = 0.0, eysum = 0.0;
-      {
+      if (polishing) {
+        if (pol_init) {  // ---- a polish attempt starts: which rows are held; keep the iterate ----
+          pol_init = false;
+          pol_round = 0;
+          held = 0;
+#pragma unroll
+          for (int q = 0; q < KQ; ++q) held |= (s_lu[q] > s_tu[q] ? 1 << (2 * q) : 0) | (s_ll[q] > s_tl[q] ? 2 << (2 * q) : 0);
+          if constexpr (KS > 0) {
+#pragma unroll
+            for (int q = 0; q < KS; ++q) {
+              held |= (sx.on[q] && sx.l[q] > sx.t[q]) ? 1 << (28 + q) : 0;
+              sx.sv[q] = sx.lm[q];
+            }
+          }
+          sigma_keep = sigma;
+          put_primal(false);
+        }
+        // weights of the round: theta on the held rows, nothing on the others; multipliers start from the interior point's on
+        // the rows it held itself and from zero on rows a repair has added
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) {
+          const int f = flags(q);
+          const bool hu = (held >> (2 * q)) & 1, hd = (held >> (2 * q + 1)) & 1;
+          const real thu = hu ? real(pol::theta) : real(0), thd = hd ? real(pol::theta) : real(0);
+          lds[o_w(q)] = thu + thd;
+          lds[o_csig(q)] = (f & F_SIG) ? (thd - thu) : real(0);
+          eysum += (f & F_SIG) ? (thu + thd) : real(0);
+          s_pu[q] = (hu && s_lu[q] > s_tu[q]) ? s_lu[q] : real(0);
+          s_pl[q] = (hd && s_ll[q] > s_tl[q]) ? s_ll[q] : real(0);
+        }
+      } else {
         real val[KQ];
         real2 hl[KQ];
 #pragma unroll
@@ -1483,15 +1601,24 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
           eysum += (f & F_SIG) ? (thu + thd) : real(0);
         }
       }
+      bool pol_giveup = false;
       if constexpr (KS > 0) {
         PT_MARK(2)
         // ---- which points stay explicit this iteration: the (at most MA_MAX) smallest theta below tau ----
+        // (polish round: the free simplex weights have theta = 0 and must ALL be explicit -- more than MA_MAX of them and
+        // the round cannot be set up)
         treal thq[KS];
+        int nfree = 0;
 #pragma unroll
         for (int q = 0; q < KS; ++q) {
-          thq[q] = sx.on[q] ? sx.l[q] * frcp(sx.t[q]) : tinf;
+          const bool hq = (held >> (28 + q)) & 1;
+          thq[q] = !sx.on[q] ? tinf : polishing ? (hq ? treal(POLISH_THETA_L) : treal(0)) : sx.l[q] * frcp(sx.t[q]);
           sx.aidx[q] = -1;
+          nfree += (polishing && sx.on[q] && !hq) ? 1 : 0;
+          if (polishing) sx.p[q] = (hq && sx.l[q] > sx.t[q]) ? sx.l[q] : treal(0);
         }
+        if (polishing) pol_giveup = __popcll(__ballot(nfree > 0)) + __popcll(__ballot(nfree > 1)) + __popcll(__ballot(nfree > 2)) > MA_MAX;
+       if (!pol_giveup) {
         if (lane < 6 * MA_MAX) TT[TL_UA + lane] = 0.0;            // unused slots: u = 0, theta = 1, rhs = 0
         if (lane < MA_MAX) {
           TT[TL_THA + lane] = 1.0;
@@ -1595,43 +1722,74 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
           TT[TL_EPS + lane] = e;
         }
         wave_fence();
+       }
       }
-      {
-        real red[2] = {musum, eysum};
-        wave_sum_n<2>(red);
-        musum = red[0];
-        hsig = qsig + red[1];
-      }
-      rdmax = wave_max(rdl);
-      hsig = uni(hsig);
-      mu = uni(musum * inv_m);
-      // (see the step-length rule; far from feasibility mu may rise legitimately: IAC at 60 m/s into a corner)
-      if (it >= 1 && mu >= mu_prev && rdmax <= lim::rd_distress) distress = true;
-      mu_prev = mu;
-      if (!(mu == mu) || !(rdmax == rdmax)) {
-        status = LMPC_SOLVE_INFEASIBLE;
-        break;
-      }
-      if (mu <= tol && rdmax <= lim::rd_ok) {
-        status = LMPC_SOLVE_OPTIMAL;
-        break;
-      }
-      // primal infeasibility: on a feasible problem the row residual contracts by (1 - alpha) per iteration; not
-      // losing a tenth over five iterations while still large (step lengths stuck below ~2 %) ends the solve (this
-      // also bounds the straggler that would otherwise hold its CU slot for max_iter iterations).  "Not halved" is
-      // too tight: feasible problems with a slow start (IAC at 60 m/s into a corner) contract by 0.6-0.8 per five.
-      if (it % 5 == 0) {
-        if (it >= 10 && rdmax > lim::rd_infeasible && rdmax > real(0.9) * rd_check) {
-          status = LMPC_SOLVE_INFEASIBLE;
-          break;
+      if (polishing) {
+        if (pol_giveup) {  // the round cannot be set up: the attempt is refused (what it has changed goes back)
+          refuse();
+          if (pol_final) {
+            status = LMPC_SOLVE_OPTIMAL;
+            leave = true;
+          } else {
+            reentry = again = true;
+          }
+        } else {
+          hsig = uni(qsig + wave_sum(eysum));
+          ++pol_rounds;
         }
-        rd_check = rdmax;
+      } else {
+        {
+          real red[2] = {musum, eysum};
+          wave_sum_n<2>(red);
+          musum = red[0];
+          hsig = qsig + red[1];
+        }
+        rdmax = wave_max(rdl);
+        hsig = uni(hsig);
+        mu = uni(musum * inv_m);
+        // (see the step-length rule; far from feasibility mu may rise legitimately: IAC at 60 m/s into a corner)
+        // (reentry: the same iterate a second time, after a refused polish -- none of the bookkeeping repeats)
+        if (!reentry && it >= 1 && mu >= mu_prev && rdmax <= lim::rd_distress) distress = true;
+        mu_prev = mu;
+        if (!(mu == mu) || !(rdmax == rdmax)) {
+          status = LMPC_SOLVE_INFEASIBLE;
+          leave = true;
+        } else if (mu <= tol && rdmax <= lim::rd_ok) {
+          if (polish_on) {  // converged: polish what the interior point has reached
+            polishing = pol_init = pol_final = again = true;
+          } else {
+            status = LMPC_SOLVE_OPTIMAL;
+            leave = true;
+          }
+        } else {
+          // primal infeasibility: on a feasible problem the row residual contracts by (1 - alpha) per iteration; not
+          // losing a tenth over five iterations while still large (step lengths stuck below ~2 %) ends the solve (this
+          // also bounds the straggler that would otherwise hold its CU slot for max_iter iterations).  "Not halved" is
+          // too tight: feasible problems with a slow start (IAC at 60 m/s into a corner) contract by 0.6-0.8 per five.
+          if (!reentry && it % 5 == 0) {
+            if (it >= 10 && rdmax > lim::rd_infeasible && rdmax > real(0.9) * rd_check) {
+              status = LMPC_SOLVE_INFEASIBLE;
+              leave = true;
+            }
+            rd_check = rdmax;
+          }
+          if (it == max_iter) leave = true;
+          // the early attempt: the active set is usually settled two iterations before the interior point's own tolerance
+          if (!leave && polish_on && !pol_early_done && mu <= real(pol::mu_early) && rdmax <= real(pol::rd_early)) {
+            pol_early_done = true;
+            polishing = pol_init = again = true;
+            pol_final = false;
+          }
+        }
+        reentry = false;
       }
-      if (it == max_iter) break;
+     } while (again);
+      if (leave) break;
       wave_sync();
       PT_MARK(2)
-      if (sizeof(real) == 8 && mu <= real(JOSEPH_MU))  // (single precision stops at mu ~ 2e-6)
-        riccati_factor<(KS > 0), (sizeof(real) == 8)>(L, lane, TT + TL_PT);
+      // the stabilised factor: double precision late in the iteration, every precision in a polish round
+      if (polishing || (sizeof(real) == 8 && mu <= real(JOSEPH_MU)))
+        riccati_factor<(KS > 0), true>(L, lane, TT + TL_PT);
       else
         riccati_factor<(KS > 0), false>(L, lane, TT + TL_PT);
       PT_MARK(3)
@@ -1640,14 +1798,17 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
     real sigc = 0.0, alpha = 1.0, dsigma = 0.0;
     bool numerics_failed = false, stalled = false;
     treal eeps[6] = {0, 0, 0, 0, 0, 0};  // E eps of this iterate (safe-set block), in scalar registers
-    if constexpr (KS > 0) {
-#pragma unroll
-      for (int k = 0; k < 6; ++k) eeps[k] = uni(TT[TL_E + k] * TT[TL_EPS + k]);
-    }
     real d_val[KQ];
-    const int npass = ipm ? 2 : 1;
+    bool pol_nan = false;
+    // interior point: predictor and corrector from the same point; polish round: pol::steps multiplier steps, each from the
+    // point the one before has reached
+    const int npass = ipm ? (polishing ? pol::steps : 2) : 1;
     for (int pass = 0; pass < npass; ++pass) {
-      const real smu = (pass == 1) ? sigc * mu : 0.0, pm = (pass == 1) ? 1.0 : 0.0;
+      const real smu = (pass == 1 && !polishing) ? sigc * mu : 0.0, pm = (pass == 1 && !polishing) ? 1.0 : 0.0;
+      if constexpr (KS > 0) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) eeps[k] = uni(TT[TL_E + k] * TT[TL_EPS + k]);
+      }
       // ======== gradient: cost gradient + row coefficients, written by the component owner ========
       real sgsum = 0.0;  // sum of boundary-row coefficients entering the sigma gradient
       if constexpr (KS > 0) {
@@ -1659,7 +1820,9 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
           for (int q = 0; q < KS; ++q) {
             treal itf, uq[6];
             sx.load_u(q, lane, uq);
-            const treal rj = sx.on[q] ? -simplex_bl(sx.lm[q], sx.t[q], sx.l[q], sx.p[q], sx.j[q], uq, treal(smu), treal(pm), eeps, itf) : treal(0);
+            const treal blq = polishing ? simplex_bl_polish(sx.lm[q], sx.p[q], ((held >> (28 + q)) & 1) != 0, sx.j[q], uq, eeps, itf)
+                                        : simplex_bl(sx.lm[q], sx.t[q], sx.l[q], sx.p[q], sx.j[q], uq, treal(smu), treal(pm), eeps, itf);
+            const treal rj = sx.on[q] ? -blq : treal(0);
             if (sx.aidx[q] >= 0) TT[TL_RA + sx.aidx[q]] = rj;
             const treal w = (sx.on[q] && sx.aidx[q] < 0) ? rj * itf : treal(0);
             bs[6] += w;
@@ -1697,6 +1860,20 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
           cb[q] = lds[CTB + ((gr >> 8) & 0xff)];
           ql[q] = lds[o_val[q] + (KN_QLIN - 3)];
         }
+        if (polishing) {  // held rows: y + theta * residual (s_pu / s_pl carry y in a polish round)
+#pragma unroll
+          for (int q = 0; q < KQ; ++q) {
+            const int f = flags(q);
+            const real sg = (f & F_SIG) ? sigma : 0.0;
+            const bool hu = (held >> (2 * q)) & 1, hd = (held >> (2 * q + 1)) & 1;
+            const real cu = hu ? rfma(real(pol::theta), val[q] - sg - hl[q].x, s_pu[q]) : real(0);
+            const real cd = hd ? rfma(real(pol::theta), -val[q] - sg + hl[q].y, s_pl[q]) : real(0);
+            const real g = ca[q] * val[q] + cb[q] * par[q] + ((f & F_QLIN) ? ql[q] : real(0));
+            lds[o_w(q)] = g + cu - cd;
+            if (pass == 0) lds[(f & F_EY) ? JB + KN_EY : o_w(q) + 10] = 0.0;
+            sgsum += (f & F_SIG) ? (cu + cd) : real(0);
+          }
+        } else {
 #pragma unroll
         for (int q = 0; q < KQ; ++q) {
           const int f = flags(q);
@@ -1710,6 +1887,7 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
           lds[o_w(q)] = g + cu - cd;
           if (pass == 0) lds[(f & F_EY) ? JB + KN_EY : o_w(q) + 10] = 0.0;
           sgsum += (f & F_SIG) ? (cu + cd) : real(0);
+        }
         }
       }
       wave_sync();
@@ -1788,7 +1966,8 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
         for (int q = 0; q < KS; ++q) {
           treal itf, uq[6];
           sx.load_u(q, lane, uq);
-          treal r = -simplex_bl(sx.lm[q], sx.t[q], sx.l[q], sx.p[q], sx.j[q], uq, treal(smu), treal(pm), eeps, itf);
+          treal r = polishing ? -simplex_bl_polish(sx.lm[q], sx.p[q], ((held >> (28 + q)) & 1) != 0, sx.j[q], uq, eeps, itf)
+                              : -simplex_bl(sx.lm[q], sx.t[q], sx.l[q], sx.p[q], sx.j[q], uq, treal(smu), treal(pm), eeps, itf);
 #pragma unroll
           for (int k = 0; k < 6; ++k) r += uq[k] * e[k];
           r = sx.on[q] ? r : 0.0;
@@ -1816,6 +1995,58 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
           const treal dA = TT[TL_XA + (sx.aidx[q] >= 0 ? sx.aidx[q] : 0)];
           sx.dl[q] = sx.on[q] ? (sx.aidx[q] >= 0 ? dA : dB) : treal(0);
         }
+      }
+      if (polishing) {
+        // ======== polish round: the full step, taken at once; multipliers from the residual BEFORE the step plus the row's
+        // own increment (the stored value is rounded after the update, the increment is not: in single precision the
+        // re-read residual of a row that has landed on its bound is exactly zero and says nothing) ========
+        bool finite_step = dsigma == dsigma;
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) {
+          const int f = flags(q);
+          const real dval = dz0[q] + dsigma * dz1[q];
+          finite_step = finite_step && (fabs(dval) < inf);
+          const real sg = (f & F_SIG) ? sigma : 0.0, dsg = (f & F_SIG) ? dsigma : 0.0;
+          const bool hu = (held >> (2 * q)) & 1, hd = (held >> (2 * q + 1)) & 1;
+          s_pu[q] = hu ? rfma(real(pol::theta), (val[q] - sg - hl[q].x) + (dval - dsg), s_pu[q]) : real(0);
+          s_pl[q] = hd ? rfma(real(pol::theta), (-val[q] - sg + hl[q].y) + (-dval - dsg), s_pl[q]) : real(0);
+          const bool mv = (f & F_MOVE) != 0;
+          lds[mv ? o_val[q] : JB + q] += mv ? dval : real(0);
+        }
+        if (has_sigma) sigma = uni(sigma + dsigma);
+        if constexpr (KS > 0) {
+#pragma unroll
+          for (int q = 0; q < KS; ++q) {
+            const bool hq = (held >> (28 + q)) & 1;
+            sx.p[q] = hq ? sx.p[q] + treal(POLISH_THETA_L) * (-sx.lm[q] - sx.dl[q]) : treal(0);
+            sx.lm[q] += sx.dl[q];
+            finite_step = finite_step && (fabs(sx.dl[q]) < tinf);
+          }
+        }
+        pol_nan = pol_nan || (__ballot(!finite_step) != 0);
+        wave_sync();
+        if constexpr (KS > 0) {  // the hull residual and the simplex residual at the new point (the next step's gradient)
+          treal ul[7] = {0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+          for (int q = 0; q < KS; ++q) {
+            treal uq[6];
+            sx.load_u(q, lane, uq);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) ul[k] += uq[k] * sx.lm[q];
+            ul[6] += sx.lm[q];
+          }
+          wave_sum_split<7>(ul, lane);
+          sx.r1 = 1.0 - ul[6];
+          if (lane < 6) {
+            treal e = 0.0;
+#pragma unroll
+            for (int k = 0; k < 6; ++k)
+              if (k == lane) e = (treal(L.kn(N - 1)[k]) - sx.ss0[k]) - ul[k];
+            TT[TL_EPS + lane] = e;
+          }
+          wave_fence();
+        }
+        continue;
       }
       // ======== row steps; largest feasible step as 1 / max(1, max -dt/t, max -dlam/lam) ========
       auto row_step = [&](bool on, treal t, treal lam, treal pprod, treal rd, treal cdy, treal& dt_, treal& dl_,
@@ -1944,12 +2175,118 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
       }
     }
 
+    if (polishing) {
+      // ======== polish round: KKT test of the point reached, repair of the held set ========
+      bool changed = false;
+      {
+        real val[KQ];
+        real2 hl[KQ];
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) {
+          val[q] = lds[o_val[q]];
+          hl[q] = bounds(q);
+        }
+        bool bad = false, neg = false, weakneg = false, viol = false;
+        real ymin = 0.0, comp = 0.0;
+        real ru[KQ], rl[KQ];
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) {
+          const int f = flags(q);
+          const real sg = (f & F_SIG) ? sigma : 0.0;
+          ru[q] = val[q] - sg - hl[q].x;
+          rl[q] = -val[q] - sg + hl[q].y;
+          const bool hu = (held >> (2 * q)) & 1, hd = (held >> (2 * q + 1)) & 1;
+          const bool nu_ = hu && s_pu[q] < -real(pol::dual), nd_ = hd && s_pl[q] < -real(pol::dual);
+          bad = bad || (hu && !(fabs(ru[q]) <= real(pol::feas))) || (hd && !(fabs(rl[q]) <= real(pol::feas)));
+          neg = neg || nu_ || nd_;
+          weakneg = weakneg || (nu_ && s_lu[q] < real(POLISH_STRONG) * s_tu[q]) || (nd_ && s_ll[q] < real(POLISH_STRONG) * s_tl[q]);
+          viol = viol || (!hu && (f & F_UP) && !(ru[q] <= real(pol::feas))) || (!hd && (f & F_LO) && !(rl[q] <= real(pol::feas)));
+          ymin = fmin(ymin, fmin(hu ? s_pu[q] : real(0), hd ? s_pl[q] : real(0)));
+          comp += (hu ? fabs(s_pu[q] * ru[q]) : real(0)) + (hd ? fabs(s_pl[q] * rl[q]) : real(0));
+        }
+        if constexpr (KS > 0) {
+#pragma unroll
+          for (int q = 0; q < KS; ++q) {
+            const bool hq = (held >> (28 + q)) & 1, fr = sx.on[q] && !hq;
+            const bool nq = hq && sx.p[q] < -treal(pol::dual);
+            bad = bad || (hq && !(fabs(sx.lm[q]) <= treal(pol::feas)));
+            neg = neg || nq;
+            weakneg = weakneg || (nq && sx.l[q] < treal(POLISH_STRONG) * sx.t[q]);
+            viol = viol || (fr && !(-sx.lm[q] <= treal(pol::feas)));
+            ymin = fmin(ymin, hq ? real(sx.p[q]) : real(0));
+            comp += hq ? real(fabs(sx.p[q] * sx.lm[q])) : real(0);
+          }
+        }
+        const bool anybad = pol_nan || __ballot(bad) != 0, anyneg = __ballot(neg) != 0, anyweak = __ballot(weakneg) != 0;
+        const bool anyviol = __ballot(viol) != 0;
+        if (!anybad && !anyneg && !anyviol) {  // accepted: the optimum for the held set, and the held set passes the KKT test
+          mu = uni(wave_sum(comp) * inv_m);
+          real worst = 0.0;  // largest violation left on any row
+#pragma unroll
+          for (int q = 0; q < KQ; ++q)
+            worst = fmax(worst, fmax((flags(q) & F_UP) ? ru[q] : real(0), (flags(q) & F_LO) ? rl[q] : real(0)));
+          rdmax = wave_max(worst);
+          polished = true;
+          status = LMPC_SOLVE_OPTIMAL;
+          break;
+        }
+        // repair: release rows with a negative multiplier -- those the interior point did not hold firmly if there are
+        // such, otherwise the most negative ones (a wrong row drags its neighbours' multipliers below zero) -- and only
+        // when no multiplier is negative, hold the rows the new point violates
+        const real ycut = real(0.5) * wave_min(ymin);
+        const int before = held;
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) {
+          const int f = flags(q);
+          const bool hu = (held >> (2 * q)) & 1, hd = (held >> (2 * q + 1)) & 1;
+          const bool du = hu && s_pu[q] < -real(pol::dual) && (anyweak ? s_lu[q] < real(POLISH_STRONG) * s_tu[q] : s_pu[q] <= ycut);
+          const bool dd = hd && s_pl[q] < -real(pol::dual) && (anyweak ? s_ll[q] < real(POLISH_STRONG) * s_tl[q] : s_pl[q] <= ycut);
+          const bool au = !anyneg && !hu && (f & F_UP) && !(ru[q] <= real(pol::feas));
+          const bool ad = !anyneg && !hd && (f & F_LO) && !(rl[q] <= real(pol::feas));
+          held = (held & ~((du ? 1 : 0) << (2 * q)) & ~((dd ? 2 : 0) << (2 * q))) | ((au ? 1 : 0) << (2 * q)) | ((ad ? 2 : 0) << (2 * q));
+        }
+        if constexpr (KS > 0) {
+#pragma unroll
+          for (int q = 0; q < KS; ++q) {
+            const bool hq = (held >> (28 + q)) & 1, fr = sx.on[q] && !hq;
+            const bool dq = hq && sx.p[q] < -treal(pol::dual) && (anyweak ? sx.l[q] < treal(POLISH_STRONG) * sx.t[q] : real(sx.p[q]) <= ycut);
+            const bool aq = !anyneg && fr && !(-sx.lm[q] <= treal(pol::feas));
+            held = (held & ~((dq ? 1 : 0) << (28 + q))) | ((aq ? 1 : 0) << (28 + q));
+          }
+        }
+        changed = __ballot(held != before) != 0;
+      }
+      ++pol_round;
+      refuse();  // (every round starts from the interior point's iterate)
+      if (changed && pol_round < pol::rounds) {
+        polishing = true;
+        --it;
+        continue;
+      }
+      if (pol_final) {
+        status = LMPC_SOLVE_OPTIMAL;
+        break;
+      }
+      reentry = true;
+      --it;
+      continue;
+    }
     if (numerics_failed) {
       status = (mu <= real(10) * tol && rdmax <= lim::rd_ok) ? LMPC_SOLVE_OPTIMAL : LMPC_SOLVE_MAX_ITER;
+      if (status == LMPC_SOLVE_OPTIMAL && polish_on) {  // (what the interior point reached is polished like a converged iterate)
+        polishing = pol_init = pol_final = true;
+        --it;
+        continue;
+      }
       break;
     }
     if (stalled) {
       status = LMPC_SOLVE_OPTIMAL;
+      if (polish_on) {
+        polishing = pol_init = pol_final = true;
+        --it;
+        continue;
+      }
       break;
     }
     // ======== primal update by the component owners ========
@@ -1998,19 +2335,14 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
   }
   PT_MARK(7)
   if (it < 0) it = 0;
+  it += pol_rounds;  // (a polish round costs about what an iteration does and is counted as one)
   if (!feasible) status = LMPC_SOLVE_INFEASIBLE;
+  // two-pass mixed precision: an answer the fp32 iteration could not verify is marked for the fp64 kernel behind it
+  if (P.flag_unverified && status == LMPC_SOLVE_OPTIMAL && polish_on && !polished) status = LMPC_SOLVE_UNVERIFIED;
 
   // ---------------- write back: X [6][N][B], U, dU [2][N-1][B] ----------------
   wave_sync();
-  for (int e = lane; e < 6 * N; e += 64) {
-    const int k = e / N, i = e - k * N;
-    X_out[(size_t)(k * N + i) * B + b] = io(L.kn(i)[k]) + (k == 0 ? s_shift : io(0));
-  }
-  for (int e = lane; e < 2 * NS; e += 64) {
-    const int k = e / NS, i = e - k * NS;
-    U_out[(size_t)(k * NS + i) * B + b] = io(L.kn(i + 1)[6 + k]);
-    dU_out[(size_t)(k * NS + i) * B + b] = io(L.kn(i)[8 + k]);
-  }
+  put_primal(true);
   if constexpr (KS > 0) {
     if (lam_out) {
 #pragma unroll
