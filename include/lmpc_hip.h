@@ -50,6 +50,8 @@ typedef enum lmpc_status {
 #define LMPC_SOLVE_OPTIMAL 0
 #define LMPC_SOLVE_MAX_ITER 1
 #define LMPC_SOLVE_INFEASIBLE 2 /* x_ic outside [x_min, x_max] at knot 0, row residual stalls, NaN */
+#define LMPC_SOLVE_UNVERIFIED 3 /* lmpc_solve_batch_mixed with lmpc_config.polish = 1 only: the fp32 iteration converged but its
+                                   polish was refused (the default two-pass solve re-solves these in fp64 and never reports 3) */
 
 /* vehicle_model_factory.cpp:31-49 -- same selector names; only the first is built */
 #define LMPC_MODEL_SINGLE_TRACK_PLANAR 0
@@ -96,7 +98,9 @@ typedef struct lmpc_config {
   int32_t max_lap_stored;
   int32_t max_iter;           /* interior-point iteration cap (<=0: default 40)             */
   int32_t polish;             /* active-set polish of the interior-point answer, the role of OSQP's polish = true
-                                 (racing_mpc.cpp:90-95): 0 (default) on, < 0 off               */
+                                 (racing_mpc.cpp:90-95): 0 (default) on, < 0 off; 1: on, and lmpc_solve_batch_mixed
+                                 leaves out its fp64 pass -- problems whose fp32 answer it could not verify keep
+                                 status LMPC_SOLVE_UNVERIFIED (diagnostics)                    */
   int32_t reserved;           /* (keeps `tol` 8-byte aligned; set to 0)                      */
   double tol;                 /* complementarity tolerance (<=0: default 3e-14)             */
   double margin;

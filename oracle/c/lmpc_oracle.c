@@ -861,7 +861,8 @@ static void primal_update(prob_t* p, double alpha) {
  *                the residual taken before the step and the row's own increment added (not re-read after the update:
  *                in single precision the stored value is rounded, its increment is not) -- which converge like
  *                (curvature / THETA)^k, i.e. at once;
- *   verify     : held rows met to POLISH_FEAS with multiplier >= -POLISH_DUAL, every other row satisfied to POLISH_FEAS;
+ *   verify     : held rows met to POLISH_FEAS with multiplier >= -POLISH_DUAL, every other row satisfied to POLISH_FEAS,
+ *                the last step below POLISH_STEP_TOL (scaled units);
  *   repair     : if a held row has a negative multiplier, release rows -- only those the interior point did not hold
  *                firmly (lam < POLISH_STRONG t) if there are such, otherwise the most negative ones (a wrong row drags
  *                its neighbours' multipliers below zero: releasing everything negative wrecks the set) -- and only when
@@ -881,6 +882,8 @@ static void primal_update(prob_t* p, double alpha) {
 #define POLISH_FEAS 1e-9
 #define POLISH_DUAL 1e-7
 #define POLISH_STRONG 1e3
+#define POLISH_STEP_TOL 1e-5 /* the last multiplier step, in the reference's scaled units (racing_mpc.cpp:36-37): converged
+                              * steps are 1e-7 .. 1e-10, the ones this is there to catch 1e-3 .. 1e-1 */
 typedef struct {
   double z[NMAX][8], v[NMAX][2], sigma, lmb[SMAX];
   rows_t y;
@@ -924,6 +927,7 @@ __attribute__((optimize("no-tree-vectorize"))) static int polish(prob_t* p, work
     }
     cost_gradient(p, w);
     newton_factor(p, w, 1);
+    double last_step = 0.0;
     for (int k = 0; k < POLISH_STEPS; ++k) {
       cost_gradient(p, w);
       for (int i = 0; i < N; ++i)
@@ -948,9 +952,18 @@ __attribute__((optimize("no-tree-vectorize"))) static int polish(prob_t* p, work
         }
       for (int j = 0; j < S; ++j)
         if (q->heldl[j]) q->yl[j] += POLISH_THETA * (q->resl[j] - p->dlmb[j]);
+      last_step = 0.0;
+      for (int i = 0; i < N; ++i) {
+        static const double isx[8] = {1.0 / 2000, 1.0 / 10, 1.0 / 0.1, 1.0 / 80, 1.0 / 2, 1.0 / 2, 1.0 / 10, 1.0 / 0.3};
+        if (i >= 1)
+          for (int r = 0; r < 8; ++r) last_step = fmax(last_step, fabs(p->dz[i][r]) * isx[r]);
+        if (i < N - 1)
+          for (int r = 0; r < 2; ++r) last_step = fmax(last_step, fabs(p->dv[i][r]) * isx[6 + r]);
+      }
     }
     /* ---- verify ---- */
-    int bad = 0, anyneg = 0, anyweak = 0, anyviol = 0;
+    int bad = !(last_step <= POLISH_STEP_TOL), anyneg = 0, anyweak = 0, anyviol = 0; /* (a last step that still moved the
+                                                                                       * iterate: the steps have not converged) */
     double ymin = 0.0, comp = 0.0;
     for (int i = 0; i < N; ++i)
       for (int sl = 0; sl < NSLOT; ++sl)

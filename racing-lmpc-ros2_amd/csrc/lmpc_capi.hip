@@ -35,6 +35,10 @@ template <int NF, int NOUT, bool WS_LAYOUT>
 __global__ void lmpc_regress_kernel(int, int, lmpc_regression_spec, int, const double*, const double*, const double*, double*,
                                     double*, double*);
 __global__ void lmpc_launch_order_kernel(int, const int*, int*);
+__global__ void lmpc_collect_unverified_kernel(int, const int*, int*);
+template <typename real, int KQ, int KS, typename io>
+__global__ void lmpc_cleanup_kernel(lmpc_params, int, const int*, const int*, const io*, const io*, const io*, const io*, const io*,
+                                    const io*, const io*, const io*, const io*, io*, io*, io*, io*, int*, int*, io*);
 struct lmpc_sqp_arrays;
 __global__ void lmpc_sqp_linesearch_kernel(lmpc_params, int, lmpc_sqp_arrays, int, double);
 __global__ void lmpc_sqp_accumulate_kernel(int, const int*, int*);
@@ -47,6 +51,7 @@ struct lmpc_handle {
   const int* order = nullptr;  // lmpc_set_launch_order: device [order_n], applied to solves of that batch size only
   int order_n = 0;
   double* ws = nullptr;  // [cap][N-1][LMPC_LIN_RECORD]
+  int* unverified = nullptr;  // [cap + 1]: the problems a mixed first pass could not verify, and their number
   size_t ws_cap = 0;
   float* ws_f32 = nullptr;  // the same for the single-precision solve
   size_t ws_f32_cap = 0;
@@ -166,13 +171,44 @@ const void* pick_mixed_fn(int kq, int ks) {
   return nullptr;
 }
 
-// pass: 0 a plain solve; 1 the fp32 iteration of a two-pass mixed solve (marks what it could not verify); 2 the fp64 kernel
-// behind it (solves the marked problems only)
+// the fp64 second pass of a mixed solve, for the (KQ, KS) the mixed kernels exist for
+const void* pick_cleanup_fn(int kq, int ks) {
+  if (ks == 2) return kq <= 4 ? reinterpret_cast<const void*>(&lmpc_cleanup_kernel<double, 4, 2, double>) : nullptr;
+  if (ks == 3) return kq <= 4 ? reinterpret_cast<const void*>(&lmpc_cleanup_kernel<double, 4, 3, double>) : nullptr;
+  switch (kq) {
+    case 2:
+    case 4: return reinterpret_cast<const void*>(&lmpc_cleanup_kernel<double, 4, 0, double>);
+    case 7: return reinterpret_cast<const void*>(&lmpc_cleanup_kernel<double, 7, 0, double>);
+    case 11: return reinterpret_cast<const void*>(&lmpc_cleanup_kernel<double, 11, 0, double>);
+    case 14: return reinterpret_cast<const void*>(&lmpc_cleanup_kernel<double, 14, 0, double>);
+  }
+  return nullptr;
+}
+
+int launch_cleanup(lmpc_handle* h, const void* fn, const solve_args& a) {
+  hipLaunchKernelGGL(lmpc_collect_unverified_kernel, dim3(1), dim3(1024), 0, h->stream, a.B, a.status, h->unverified);
+  HIP_TRY(h, hipGetLastError());
+  HIP_TRY(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)a.lds_bytes));
+  lmpc_params P = h->P;
+  P.launch_order = nullptr;
+  P.flag_unverified = 0;
+  int B = a.B;
+  const double* ws = h->ws;
+  const int* list = h->unverified;
+  const int* count = h->unverified + a.B;
+  void* args[] = {(void*)&P,      (void*)&B,    (void*)&list,  (void*)&count,  (void*)&ws,     (void*)&a.x_ic, (void*)&a.u_ic,
+                  (void*)&a.T_ref, (void*)&a.bl, (void*)&a.br,  (void*)&a.vref, (void*)&a.ss_x, (void*)&a.ss_j, (void*)&a.lam,
+                  (void*)&a.X,    (void*)&a.U,  (void*)&a.dU,  (void*)&a.status, (void*)&a.iters, (void*)&a.kkt};
+  const int grid = a.B < 1024 ? a.B : 1024;  // (a percent of a batch is marked: 1024 workgroups take them in one or two turns)
+  HIP_TRY(h, hipLaunchKernel(fn, dim3(grid), dim3(64), args, a.lds_bytes, h->stream));
+  return LMPC_OK;
+}
+
+// pass: 0 a plain solve; 1 the fp32 iteration of a two-pass mixed solve (marks what it could not verify)
 int launch_solve(lmpc_handle* h, const void* fn, const solve_args& a, int pass = 0) {
   HIP_TRY(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)a.lds_bytes));
   lmpc_params P = h->P;
   P.flag_unverified = pass == 1;
-  P.cleanup = pass == 2;
   // the registered order applies to solves of exactly its own batch size; every other launch through this handle (the
   // single-problem host path, the SQP's QPs on another batch, ...) keeps the default mapping
   P.launch_order = (h->order && a.B == h->order_n) ? h->order : nullptr;
@@ -303,6 +339,7 @@ void lmpc_destroy(lmpc_handle* h) {
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
   if (h->ws) (void)hipFree(h->ws);
+  if (h->unverified) (void)hipFree(h->unverified);
   if (h->ws_f32) (void)hipFree(h->ws_f32);
   if (h->ss_npts) (void)hipFree(h->ss_npts);
   if (h->ss_off) (void)hipFree(h->ss_off);
@@ -350,6 +387,9 @@ int lmpc_reserve(lmpc_handle* h, int32_t max_batch) {
   h->ws_cap = 0;
   const size_t bytes = (size_t)max_batch * (h->P.N - 1) * LMPC_LIN_RECORD * sizeof(double);
   HIP_TRY(h, hipMalloc(&h->ws, bytes));
+  if (h->unverified) HIP_TRY(h, hipFree(h->unverified));
+  h->unverified = nullptr;
+  HIP_TRY(h, hipMalloc(&h->unverified, ((size_t)max_batch + 1) * sizeof(int)));
   h->ws_cap = (size_t)max_batch;
   return LMPC_OK;
 }
@@ -447,14 +487,14 @@ int solve_batch_fp64_arrays(lmpc_handle* h, bool mixed, int32_t batch, const dou
   // Mixed precision is two launches when the polish is on: the fp32 iteration verifies its own answers (polish accepted =
   // KKT test passed) and marks the problems it could not verify -- a percent of a batch: active sets still ambiguous at
   // mu = 2e-6, or more than four free simplex weights -- and the fp64 kernel behind it solves exactly those.
-  const bool two_pass = mixed && h->P.polish >= 0;
-  int rc = launch_solve(h, fn, a, two_pass ? 1 : 0);
+  const bool two_pass = mixed && h->P.polish == 0;  // (polish = 1: the marks stay visible, no second pass -- diagnostics)
+  int rc = launch_solve(h, fn, a, (mixed && h->P.polish >= 0) ? 1 : 0);
   if (rc != LMPC_OK) return rc;
   if (two_pass) {
-    const void* fn64 = pick_solve_fn(kq_for(N), ks_for(h->P.S));
-    if (!fn64) return fail(h, LMPC_ERR_UNSUPPORTED, "no fp64 kernel for this (N, num_ss_pts)");
+    const void* fn64 = pick_cleanup_fn(kq_for(N), ks_for(h->P.S));
+    if (!fn64) return fail(h, LMPC_ERR_UNSUPPORTED, "no fp64 second pass for this (N, num_ss_pts)");
     a.lds_bytes = lmpc_lds_bytes(N, h->P.learning, h->P.S, 8);
-    rc = launch_solve(h, fn64, a, 2);
+    rc = launch_cleanup(h, fn64, a);
     if (rc != LMPC_OK) return rc;
   }
   if (h->timing) HIP_TRY(h, hipEventRecord(h->ev[2], h->stream));

@@ -30,13 +30,11 @@ struct lmpc_params {
   double chs2[6];          // 2 * convex_hull_slack
   double max_vel_ref_diff;
   // two-pass mixed precision (set per launch by the host layer): the fp32 iteration marks a problem whose answer it could not
-  // verify (polish refused) with LMPC_SOLVE_UNVERIFIED instead of OPTIMAL; the fp64 kernel launched behind it with cleanup = 1
-  // solves exactly the marked problems and leaves the others alone
+  // verify (polish refused) with LMPC_SOLVE_UNVERIFIED instead of OPTIMAL; lmpc_cleanup_kernel behind it solves those in fp64
   int flag_unverified;
-  int cleanup;
+  int pad1;
   lmpc_vehicle veh;
 };
-#define LMPC_SOLVE_UNVERIFIED 3  // (internal: never leaves lmpc_solve_batch_mixed)
 
 // LDS record sizes (in doubles) of the solve kernel; see DESIGN.md "data layout".
 #define LMPC_STAGE_STRIDE 78

@@ -284,3 +284,15 @@ __global__ __launch_bounds__(1024) void lmpc_launch_order_kernel(int B, const in
     __syncthreads();
   }
 }
+
+// The problems a mixed-precision first pass has marked LMPC_SOLVE_UNVERIFIED: list [0 .. n) and n at list [B].  One workgroup;
+// the order within the list is whatever the atomics produce (each problem is solved on its own: the results do not depend on it).
+__global__ __launch_bounds__(1024) void lmpc_collect_unverified_kernel(int B, const int* __restrict__ status, int* __restrict__ list) {
+  __shared__ int n;
+  if (threadIdx.x == 0) n = 0;
+  __syncthreads();
+  for (int b = threadIdx.x; b < B; b += 1024)
+    if (status[b] == LMPC_SOLVE_UNVERIFIED) list[atomicAdd(&n, 1)] = b;
+  __syncthreads();
+  if (threadIdx.x == 0) list[B] = n;
+}

@@ -42,6 +42,9 @@
 #define OCCF 3
 #endif
 #define NSLOT 11
+#ifndef LMPC_POLISH_BUILD  // (0: the polish compiled out -- A/B timing of what its presence costs the interior point's loop)
+#define LMPC_POLISH_BUILD 1
+#endif
 // resident waves per SIMD the register allocation is sized for: the fp64 tracking kernels up to N = 23 and every fp32
 // kernel up to N = 40 run two (three for fp32, N <= 23); the fp64 LMPC and long-horizon kernels need the full file
 constexpr int lmpc_waves_per_simd(int real_bytes, int kq, int ks) {
@@ -346,22 +349,31 @@ template <> struct ipm_limits<float> {
 // oracle/c/lmpc_oracle.c, which runs the same rounds): rows with lam > t are HELD -- weight theta on them, none on the
 // others, one stabilised factorisation -- then `steps` multiplier steps on that factor (gradient y + theta * residual on
 // the held rows, full Newton step, y <- y + theta * (residual + the row's own increment)), a KKT test (held rows met to
-// `feas` with y >= -dual, the others satisfied to `feas`), and up to `rounds` repairs of the held set.  Double precision
+// `feas` with y >= -dual, the others satisfied to `feas`, the last step below step_tol in the reference's scaled units),
+// and up to `rounds` repairs of the held set.  Double precision
 // tries it once as soon as mu <= mu_early with rows feasible to rd_early -- about two iterations before the interior
 // point's own tolerance, and the stabilised factorisations of those iterations are the ones it saves -- and again at
 // convergence if refused; single precision polishes at its convergence (mu ~ 2e-6), where it turns "within sqrt(mu) of the
 // optimum" into "the optimum to the accuracy of an fp32 solve".
 template <typename real> struct polish_limits;
 template <> struct polish_limits<double> {
-  static constexpr double theta = 1e8, feas = 1e-9, dual = 1e-7, mu_early = 1e-8, rd_early = 1e-6;
+  static constexpr bool early = true;
+  static constexpr double theta = 1e8, feas = 1e-9, dual = 1e-7, mu_early = 1e-8, rd_early = 1e-6, step_ok = 0.0, step_tol = 1e-5;
   static constexpr int rounds = 3, steps = 2;
 };
 template <> struct polish_limits<float> {
   // theta: 1e7 needs the stabilised factor and the fp64 2x2 pivot; with 1e5 chains of held input rows (u_i = u_{i-1} + t v_i,
-  // stiffness R_d / t^2 per link) converge like 0.7 per step.  Three steps: the third removes the rounding of the first two.
-  static constexpr float theta = 1e7f, feas = 1e-5f, dual = 1e-3f, mu_early = 0.0f, rd_early = 0.0f;
+  // stiffness R_d / t^2 per link) converge like 0.7 per step.  Up to three steps: the third removes what the rounding of the
+  // first two has left, and is only taken when the second still moved the iterate by more than step_ok (scaled units).
+  static constexpr bool early = false;  // (an early attempt at mu ~ 1e-4 was measured on the serial twin: the iterations it saves are fewer than the rounds it adds)
+  static constexpr float theta = 1e7f, feas = 1e-5f, dual = 1e-3f, mu_early = 0.0f, rd_early = 0.0f, step_ok = 3e-6f, step_tol = 1e-4f;
   static constexpr int rounds = 4, steps = 3;
 };
+// 1 / scale of the quantity a slot constrains: the reference's scale vectors (racing_mpc.cpp:36-37, hard-coded there for every
+// vehicle) -- used only to measure a polish step
+__device__ __forceinline__ float slot_inv_scale(int sl) {
+  return sl == 0 ? 5e-4f : (sl == 1 || sl == 10) ? 0.1f : sl == 2 ? 10.0f : sl == 3 ? 0.0125f : (sl == 4 || sl == 5) ? 0.5f : (sl == 6 || sl == 8) ? 0.1f : (1.0f / 0.3f);
+}
 #define POLISH_THETA_L 1e8  // the simplex rows (always fp64)
 #define POLISH_STRONG 1e3   // a row with lam >= POLISH_STRONG t is one the interior point holds firmly
 template <typename real> struct vec2;
@@ -1234,27 +1246,16 @@ __device__ void feedback_rollout(const Lds<real>& L, int lane) {
 // `real` is the arithmetic and LDS type, `io` the type of the arrays in HBM: <double, double> is the reference's
 // precision, <float, float> the single-precision path, <float, double> the mixed path (fp64 linearisation, regression,
 // safe-set centring and results around an fp32 interior-point iteration).
+// One problem, solved by the calling wavefront in the LDS block it is given (the body of both kernels below).
 template <typename real, int KQ, int KS, typename io>
-__global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void lmpc_solve_kernel(
-    lmpc_params P, int B, const io* __restrict__ ws_lin, const io* __restrict__ x_ic,
-    const io* __restrict__ u_ic, const io* __restrict__ T_ref, const io* __restrict__ bl,
+__device__ __forceinline__ void lmpc_solve_problem(
+    const lmpc_params& P, const int B, const int b, unsigned char* lds_raw, const io* __restrict__ ws_lin,
+    const io* __restrict__ x_ic, const io* __restrict__ u_ic, const io* __restrict__ T_ref, const io* __restrict__ bl,
     const io* __restrict__ br, const io* __restrict__ vref, const io* __restrict__ ss_x,
     const io* __restrict__ ss_j, io* __restrict__ lam_out, io* __restrict__ X_out,
     io* __restrict__ U_out, io* __restrict__ dU_out, int* __restrict__ status_out,
     int* __restrict__ iters_out, io* __restrict__ kkt_out) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];  // one symbol for every instantiation
   real* const lds = reinterpret_cast<real*>(lds_raw);
-  // XCD-aware problem assignment: consecutive workgroups go round-robin to the 8 XCDs (each with its own L2), while
-  // consecutive problems share 64-byte lines in the [field][knot][batch] arrays.  Workgroup w takes problem
-  // (w mod 8) * ceil(B / 8) + w / 8, so each XCD owns a contiguous eighth of the batch and the 8-byte strided
-  // accesses of neighbouring problems merge in that XCD's L2 instead of reaching HBM as partial lines.
-  // With a launch order (longest job first from the previous solve's iteration counts, lmpc_set_launch_order) workgroup
-  // w takes problem launch_order[w]: the hardware starts workgroups in index order, so the long problems go first and the
-  // short ones fill the tail of the second residency round.
-  int b = (int)(blockIdx.x & 7) * ((B + 7) >> 3) + (int)(blockIdx.x >> 3);
-  if (P.launch_order) b = (int)blockIdx.x < B ? P.launch_order[blockIdx.x] : B;
-  if (b >= B) return;
-  if (P.cleanup && status_out[b] != LMPC_SOLVE_UNVERIFIED) return;  // second pass of a mixed solve: the marked problems only
   const int lane = threadIdx.x;
   const int N = P.N, NS = N - 1;
   typedef typename vec2<real>::type real2;
@@ -1374,7 +1375,7 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
     const bool eys = valid && sl == SL_EY;
     const int fl = (au ? F_UP : 0) | (al ? F_LO : 0) | ((eys && has_sigma) ? F_SIG : 0) | ((valid && sl == 3) ? F_QLIN : 0) |
              ((valid && sl < SL_EY && (i >= 1 || sl >= SL_V)) ? F_MOVE : 0) | (eys ? F_EY : 0) | ((eys && i >= 1) ? F_SCH : 0);
-    s_gf[q] = ca | (cb << 8) | ((pd + 1) << 16) | (fl << 20);
+    s_gf[q] = ca | (cb << 8) | ((pd + 1) << 16) | (fl << 20) | (sl << 27);  // (bits 27..30: the slot kind, for the polish's scaled step)
     m_rows += (au ? 1.0 : 0.0) + (al ? 1.0 : 0.0);
     s_tu[q] = s_tl[q] = 1.0;
     s_lu[q] = s_ll[q] = 0.0;
@@ -1491,19 +1492,13 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
   real mu = 0.0, rdmax = 0.0, rd_check = 0.0, last_step = 0.0, hsig = 0.0, ce = 0.0, mu_prev = inf;
   bool distress = false;
   const int max_iter = feasible ? P.max_iter : 0;
-  // ---- polish state (wave-uniform unless noted) ----
   typedef polish_limits<real> pol;
-  const bool polish_on = P.polish >= 0;
-  bool polishing = false;    // the rounds below run instead of interior-point iterations
-  bool pol_init = false;     // the next round is the first of an attempt: classify the rows, keep the iterate
-  bool pol_final = false;    // the attempt at the interior point's own exit (a refusal then ends the solve with its iterate)
-  bool pol_early_done = false, polished = false, reentry = false;
-  int pol_round = 0, pol_rounds = 0;
-  int held = 0;              // (per lane) bit 2q / 2q + 1: upper / lower row of slot q held; bit 28 + q: simplex row q held
-  real sigma_keep = 0.0;
+  const bool polish_on = LMPC_POLISH_BUILD && P.polish >= 0;
+  bool polished = false, pol_early_done = false, reentry = false;
+  int pol_rounds = 0;
   // The iterate as it stands goes to the result arrays (the abscissa without the single-precision shift, so that it
-  // reads back exactly) and comes back from them when a polish is refused: no registers are held for it across the
-  // sweeps, and every lane reads back what it wrote itself.
+  // reads back exactly) and comes back from them when a polish round is over: nothing is held in registers for it, and
+  // every lane reads back what it wrote itself.
   auto put_primal = [&](bool shifted) {
     for (int e = lane; e < 6 * N; e += 64) {
       const int k = e / N, i = e - k * N;
@@ -1527,60 +1522,472 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
     }
   };
 
-  // a refused polish: iterate, slack variable and simplex weights as the interior point left them (its t, lam were never touched)
-  auto refuse = [&]() {
-    wave_sync();
-    get_primal();
-    sigma = sigma_keep;
+  // ======== the active-set polish (polish_limits above; the twin's polish() runs the same rounds) ========
+  // Called from the rows phase of the interior point, i.e. at a point where the predictor products s_pu / s_pl (and
+  // sx.p) are dead: a round keeps its multiplier estimates y there.  Slacks and multipliers of the interior point are
+  // not touched; the iterate is put aside in the result arrays and comes back unless the attempt is accepted.  Own call
+  // sites of the factorisation and the sweeps: nothing of this is live across the interior point's hot loops.
+  auto polish_attempt = [&]() -> bool {
+    int held = 0;  // (per lane) bit 2q / 2q + 1: upper / lower row of slot q held; bit 28 + q: simplex row q held
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) held |= (s_lu[q] > s_tu[q] ? 1 << (2 * q) : 0) | (s_ll[q] > s_tl[q] ? 2 << (2 * q) : 0);
     if constexpr (KS > 0) {
 #pragma unroll
-      for (int q = 0; q < KS; ++q) sx.lm[q] = sx.sv[q];
+      for (int q = 0; q < KS; ++q) {
+        held |= (sx.on[q] && sx.l[q] > sx.t[q]) ? 1 << (28 + q) : 0;
+        sx.sv[q] = sx.lm[q];
+      }
     }
-    wave_sync();
-    polishing = false;
-  };
-
-  // it == -1 is the start-point Newton step (all row weights zero, full step); it >= 0 the
-  // interior-point iterations.
-  for (it = -1; it <= max_iter; ++it) {
-    const bool ipm = it >= 0;
-    // ======== rows: complementarity, residual, barrier weights ========
-    if (ipm) {
-     bool again, leave = false;
-     do {  // (a second time when the interior point hands over to the polish in this iteration, or takes over again)
-      again = false;
-      real musum = 0.0, rdl = 0.0, eysum = 0.0;
-      if (polishing) {
-        if (pol_init) {  // ---- a polish attempt starts: which rows are held; keep the iterate ----
-          pol_init = false;
-          pol_round = 0;
-          held = 0;
+    const real sigma_keep = sigma;
+    put_primal(false);
+    bool accepted = false;
+    for (int round = 0; round < pol::rounds; ++round) {
+      if (round > 0) {  // every round starts from the interior point's iterate
+        wave_sync();
+        get_primal();
+        sigma = sigma_keep;
+        if constexpr (KS > 0) {
 #pragma unroll
-          for (int q = 0; q < KQ; ++q) held |= (s_lu[q] > s_tu[q] ? 1 << (2 * q) : 0) | (s_ll[q] > s_tl[q] ? 2 << (2 * q) : 0);
-          if constexpr (KS > 0) {
+          for (int q = 0; q < KS; ++q) sx.lm[q] = sx.sv[q];
+        }
+        wave_sync();
+      }
+      // ---- weights: theta on the held rows, nothing on the others; multipliers start from the interior point's on the
+      // rows it held itself and from zero on rows a repair has added ----
+      real eysum = 0.0;
 #pragma unroll
-            for (int q = 0; q < KS; ++q) {
-              held |= (sx.on[q] && sx.l[q] > sx.t[q]) ? 1 << (28 + q) : 0;
-              sx.sv[q] = sx.lm[q];
+      for (int q = 0; q < KQ; ++q) {
+        const int f = flags(q);
+        const bool hu = (held >> (2 * q)) & 1, hd = (held >> (2 * q + 1)) & 1;
+        const real thu = hu ? real(pol::theta) : real(0), thd = hd ? real(pol::theta) : real(0);
+        lds[o_w(q)] = thu + thd;
+        lds[o_csig(q)] = (f & F_SIG) ? (thd - thu) : real(0);
+        eysum += (f & F_SIG) ? (thu + thd) : real(0);
+        s_pu[q] = (hu && s_lu[q] > s_tu[q]) ? s_lu[q] : real(0);
+        s_pl[q] = (hd && s_ll[q] > s_tl[q]) ? s_ll[q] : real(0);
+      }
+      if constexpr (KS > 0) {
+        // the free simplex weights have theta = 0 and must ALL be explicit unknowns of the terminal block: more than MA_MAX
+        // of them and the round cannot be set up
+        treal thq[KS];
+        int nfree = 0;
+#pragma unroll
+        for (int q = 0; q < KS; ++q) {
+          const bool hq = (held >> (28 + q)) & 1;
+          thq[q] = !sx.on[q] ? tinf : (hq ? treal(POLISH_THETA_L) : treal(0));
+          sx.aidx[q] = -1;
+          nfree += (sx.on[q] && !hq) ? 1 : 0;
+          sx.p[q] = (hq && sx.l[q] > sx.t[q]) ? sx.l[q] : treal(0);
+        }
+        if (__popcll(__ballot(nfree > 0)) + __popcll(__ballot(nfree > 1)) + __popcll(__ballot(nfree > 2)) > MA_MAX) break;
+        if (lane < 6 * MA_MAX) TT[TL_UA + lane] = 0.0;
+        if (lane < MA_MAX) {
+          TT[TL_THA + lane] = 1.0;
+          TT[TL_RA + lane] = 0.0;
+        }
+        wave_fence();
+        int m = 0;
+        for (int a = 0; a < MA_MAX; ++a) {
+          treal cand = tinf;
+          int cq = 0;
+#pragma unroll
+          for (int q = 0; q < KS; ++q) {
+            const bool better = sx.aidx[q] < 0 && thq[q] < sx.tau && thq[q] < cand;
+            cand = better ? thq[q] : cand;
+            cq = better ? q : cq;
+          }
+          const treal best = wave_min(cand);
+          if (!(best < tinf)) break;
+          const int owner = __ffsll((long long)__ballot(cand == best)) - 1;
+          if (lane == owner) {
+#pragma unroll
+            for (int q = 0; q < KS; ++q)
+              if (q == cq) {
+                sx.aidx[q] = a;
+                treal uq[6];
+                sx.load_u(q, lane, uq);
+#pragma unroll
+                for (int k = 0; k < 6; ++k) TT[TL_UA + a * 6 + k] = uq[k];
+                TT[TL_THA + a] = thq[q];
+              }
+          }
+          wave_fence();
+          m = a + 1;
+        }
+        sx.m = m;
+        wave_fence();
+        treal tt[21], av[14];
+#pragma unroll
+        for (int k = 0; k < 21; ++k) tt[k] = 0.0;
+#pragma unroll
+        for (int k = 0; k < 14; ++k) av[k] = 0.0;
+#pragma unroll
+        for (int q = 0; q < KS; ++q) {
+          const treal itf = (sx.on[q] && sx.aidx[q] < 0) ? frcp(thq[q]) : treal(0);
+          int n = 0;
+          treal uq[6];
+          sx.load_u(q, lane, uq);
+#pragma unroll
+          for (int r = 0; r < 6; ++r) {
+#pragma unroll
+            for (int c = r; c < 6; ++c) tt[n++] += uq[r] * uq[c] * itf;
+            av[r] += uq[r] * itf;
+            av[7 + r] += uq[r] * sx.lm[q];
+          }
+          av[6] += itf;
+          av[13] += sx.lm[q];
+        }
+        {
+          treal red[32], red3[3] = {av[11], av[12], av[13]};
+#pragma unroll
+          for (int k = 0; k < 21; ++k) red[k] = tt[k];
+#pragma unroll
+          for (int k = 0; k < 11; ++k) red[21 + k] = av[k];
+          wave_sum_split<32>(red, lane);
+          wave_sum_split<3>(red3, lane);
+#pragma unroll
+          for (int k = 0; k < 21; ++k) tt[k] = red[k];
+#pragma unroll
+          for (int k = 0; k < 11; ++k) av[k] = red[21 + k];
+          av[11] = red3[0];
+          av[12] = red3[1];
+          av[13] = red3[2];
+        }
+        sx.r1 = 1.0 - av[13];
+        {
+          treal F[36], aB[6];
+          int n = 0;
+#pragma unroll
+          for (int r = 0; r < 6; ++r) {
+#pragma unroll
+            for (int c = r; c < 6; ++c) {
+              F[r * 6 + c] = tt[n];
+              F[c * 6 + r] = tt[n];
+              ++n;
+            }
+            aB[r] = av[r];
+          }
+#pragma unroll
+          for (int k = 0; k < 6; ++k) F[k * 6 + k] += 1.0 / fmax(TT[TL_E + k], treal(1e-30));
+          term_factor_u(TT, lane, F, aB, av[6], m);
+        }
+        if (lane < 6) {
+          treal e = 0.0;
+#pragma unroll
+          for (int k = 0; k < 6; ++k)
+            if (k == lane) e = (treal(L.kn(N - 1)[k]) - sx.ss0[k]) - av[7 + k];
+          TT[TL_EPS + lane] = e;
+        }
+        wave_fence();
+      }
+      hsig = uni(qsig + wave_sum(eysum));
+      ++pol_rounds;
+      wave_sync();
+      riccati_factor<(KS > 0), true>(L, lane, TT + TL_PT);
+      bool nan_step = false;
+      // ---- pol::steps multiplier steps on that factor, each from the point the one before has reached ----
+      for (int k = 0; k < pol::steps; ++k) {
+        treal eeps[6] = {0, 0, 0, 0, 0, 0};
+        if constexpr (KS > 0) {
+#pragma unroll
+          for (int c = 0; c < 6; ++c) eeps[c] = uni(TT[TL_E + c] * TT[TL_EPS + c]);
+          treal bs[7] = {0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+          for (int q = 0; q < KS; ++q) {
+            treal itf, uq[6];
+            sx.load_u(q, lane, uq);
+            const treal rj = sx.on[q] ? -simplex_bl_polish(sx.lm[q], sx.p[q], ((held >> (28 + q)) & 1) != 0, sx.j[q], uq, eeps, itf) : treal(0);
+            if (sx.aidx[q] >= 0) TT[TL_RA + sx.aidx[q]] = rj;
+            const treal w = (sx.on[q] && sx.aidx[q] < 0) ? rj * itf : treal(0);
+            bs[6] += w;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) bs[c] += uq[c] * w;
+          }
+          wave_sum_split<7>(bs, lane);
+          wave_fence();
+          treal beta[6], h[6], nu;
+#pragma unroll
+          for (int c = 0; c < 6; ++c) beta[c] = bs[c];
+          term_solve_u(TT, lane, sx.m, beta, bs[6], sx.r1, h, nu);
+          if (lane < 6) {
+            treal hs = h[0];
+#pragma unroll
+            for (int c = 1; c < 6; ++c) hs = (lane == c) ? h[c] : hs;
+            TT[TL_TG + lane] = TT[TL_E + lane] * TT[TL_EPS + lane] - hs;
+          }
+          wave_fence();
+        }
+        real sgsum = 0.0;
+        {  // gradient: cost gradient + (y + theta * residual) on the held rows
+          real val[KQ], par[KQ], ca[KQ], cb[KQ], ql[KQ];
+          real2 hl[KQ];
+#pragma unroll
+          for (int q = 0; q < KQ; ++q) {
+            const int gr = s_gf[q];
+            val[q] = lds[o_val[q]];
+            hl[q] = bounds(q);
+            par[q] = lds[o_val[q] + ((gr >> 16) & 3) - 1];
+            ca[q] = lds[CTB + (gr & 0xff)];
+            cb[q] = lds[CTB + ((gr >> 8) & 0xff)];
+            ql[q] = lds[o_val[q] + (KN_QLIN - 3)];
+          }
+#pragma unroll
+          for (int q = 0; q < KQ; ++q) {
+            const int f = flags(q);
+            const real sg = (f & F_SIG) ? sigma : 0.0;
+            const bool hu = (held >> (2 * q)) & 1, hd = (held >> (2 * q + 1)) & 1;
+            const real cu = hu ? rfma(real(pol::theta), val[q] - sg - hl[q].x, s_pu[q]) : real(0);
+            const real cd = hd ? rfma(real(pol::theta), -val[q] - sg + hl[q].y, s_pl[q]) : real(0);
+            const real g = ca[q] * val[q] + cb[q] * par[q] + ((f & F_QLIN) ? ql[q] : real(0));
+            lds[o_w(q)] = g + cu - cd;
+            if (k == 0) lds[(f & F_EY) ? JB + KN_EY : o_w(q) + 10] = 0.0;
+            sgsum += (f & F_SIG) ? (cu + cd) : real(0);
+          }
+        }
+        wave_sync();
+        for (int i = lane; i < N; i += 64) {
+          real* kn = L.kn(i);
+          kn[KN_R0 + 1] += kn[KN_EY];
+          if (k == 0) kn[KN_R1 + 1] = (i >= 1) ? kn[KN_CSIG] : 0.0;
+        }
+        if constexpr (KS > 0) {
+          wave_sync();
+          if (lane < 6) L.kn(N - 1)[KN_R0 + lane] += real(TT[TL_TG + lane]);
+        }
+        wave_sync();
+        if constexpr (lmpc_waves_per_simd(sizeof(real), KQ, KS) < 2) {
+          if (k == 0 && has_sigma)
+            riccati_solve_lds<2>(L, lane, pf);
+          else
+            riccati_solve_lds<1>(L, lane, pf);
+        } else {
+          if (k == 0 && has_sigma)
+            riccati_solve<2>(L, lane, pf);
+          else
+            riccati_solve<1>(L, lane, pf);
+        }
+        real dz0[KQ], dz1[KQ], val[KQ];
+        real2 hl[KQ];
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) {
+          dz0[q] = lds[o_val[q] + 10];
+          dz1[q] = lds[o_val[q] + 20];
+          val[q] = lds[o_val[q]];
+          hl[q] = bounds(q);
+        }
+        real dsigma = 0.0;
+        if (has_sigma) {
+          real red[3] = {0.0, 0.0, sgsum};
+          {
+            real cs[KQ];
+#pragma unroll
+            for (int q = 0; q < KQ; ++q) cs[q] = lds[o_csig(q)];
+#pragma unroll
+            for (int q = 0; q < KQ; ++q) {
+              const bool sch = (flags(q) & F_SCH) != 0;
+              red[0] += sch ? cs[q] * dz0[q] : real(0);
+              red[1] += sch ? cs[q] * dz1[q] : real(0);
             }
           }
-          sigma_keep = sigma;
-          put_primal(false);
+          wave_sum_n<3>(red);
+          if (k == 0) ce = red[1];
+          const real qsg = qsig * sigma - red[2];
+          dsigma = uni(-(qsg + red[0]) / (hsig + ce));
         }
-        // weights of the round: theta on the held rows, nothing on the others; multipliers start from the interior point's on
-        // the rows it held itself and from zero on rows a repair has added
+        if constexpr (KS > 0) {
+          const real* knT = L.kn(N - 1);
+          treal e[6], gs[7] = {0, 0, 0, 0, 0, 0, 0}, rj[KS], itfq[KS];
+#pragma unroll
+          for (int c = 0; c < 6; ++c) e[c] = TT[TL_E + c] * treal(knT[KN_R0 + c] + dsigma * knT[KN_R1 + c]);
+#pragma unroll
+          for (int q = 0; q < KS; ++q) {
+            treal itf, uq[6];
+            sx.load_u(q, lane, uq);
+            treal r = -simplex_bl_polish(sx.lm[q], sx.p[q], ((held >> (28 + q)) & 1) != 0, sx.j[q], uq, eeps, itf);
+#pragma unroll
+            for (int c = 0; c < 6; ++c) r += uq[c] * e[c];
+            r = sx.on[q] ? r : 0.0;
+            rj[q] = r;
+            itfq[q] = itf;
+            if (sx.aidx[q] >= 0) TT[TL_RA + sx.aidx[q]] = r;
+            const treal w = (sx.on[q] && sx.aidx[q] < 0) ? r * itf : treal(0);
+            gs[6] += w;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) gs[c] += uq[c] * w;
+          }
+          wave_sum_split<7>(gs, lane);
+          wave_fence();
+          treal beta[6], h[6], nu;
+#pragma unroll
+          for (int c = 0; c < 6; ++c) beta[c] = gs[c];
+          term_solve_u(TT, lane, sx.m, beta, gs[6], sx.r1, h, nu);
+#pragma unroll
+          for (int q = 0; q < KS; ++q) {
+            treal uh = 0.0, uq[6];
+            sx.load_u(q, lane, uq);
+#pragma unroll
+            for (int c = 0; c < 6; ++c) uh += uq[c] * h[c];
+            const treal dB = (rj[q] - nu - uh) * itfq[q];
+            const treal dA = TT[TL_XA + (sx.aidx[q] >= 0 ? sx.aidx[q] : 0)];
+            sx.dl[q] = sx.on[q] ? (sx.aidx[q] >= 0 ? dA : dB) : treal(0);
+          }
+        }
+        // the full step, taken at once; multipliers from the residual BEFORE the step plus the row's own increment (the
+        // stored value is rounded after the update, the increment is not: in single precision the re-read residual of a
+        // row that has landed on its bound is exactly zero and says nothing)
+        bool finite_step = dsigma == dsigma;
+        real stepmax = 0.0;
 #pragma unroll
         for (int q = 0; q < KQ; ++q) {
           const int f = flags(q);
+          const real dval = dz0[q] + dsigma * dz1[q];
+          finite_step = finite_step && (fabs(dval) < inf);
+          stepmax = fmax(stepmax, (f & F_MOVE) ? fabs(dval) * real(slot_inv_scale((s_gf[q] >> 27) & 15)) : real(0));
+          const real sg = (f & F_SIG) ? sigma : 0.0, dsg = (f & F_SIG) ? dsigma : 0.0;
           const bool hu = (held >> (2 * q)) & 1, hd = (held >> (2 * q + 1)) & 1;
-          const real thu = hu ? real(pol::theta) : real(0), thd = hd ? real(pol::theta) : real(0);
-          lds[o_w(q)] = thu + thd;
-          lds[o_csig(q)] = (f & F_SIG) ? (thd - thu) : real(0);
-          eysum += (f & F_SIG) ? (thu + thd) : real(0);
-          s_pu[q] = (hu && s_lu[q] > s_tu[q]) ? s_lu[q] : real(0);
-          s_pl[q] = (hd && s_ll[q] > s_tl[q]) ? s_ll[q] : real(0);
+          s_pu[q] = hu ? rfma(real(pol::theta), (val[q] - sg - hl[q].x) + (dval - dsg), s_pu[q]) : real(0);
+          s_pl[q] = hd ? rfma(real(pol::theta), (-val[q] - sg + hl[q].y) + (-dval - dsg), s_pl[q]) : real(0);
+          const bool mv = (f & F_MOVE) != 0;
+          lds[mv ? o_val[q] : JB + q] += mv ? dval : real(0);
         }
-      } else {
+        if (has_sigma) sigma = uni(sigma + dsigma);
+        if constexpr (KS > 0) {
+#pragma unroll
+          for (int q = 0; q < KS; ++q) {
+            const bool hq = (held >> (28 + q)) & 1;
+            sx.p[q] = hq ? sx.p[q] + treal(POLISH_THETA_L) * (-sx.lm[q] - sx.dl[q]) : treal(0);
+            sx.lm[q] += sx.dl[q];
+            finite_step = finite_step && (fabs(sx.dl[q]) < tinf);
+          }
+        }
+        nan_step = nan_step || (__ballot(!finite_step) != 0);
+        last_step = wave_max(stepmax);  // (scaled: what kkt[0] reports after an accepted polish)
+        wave_sync();
+        if constexpr (KS > 0) {  // the hull residual and the simplex residual at the new point (the next step's gradient)
+          treal ul[7] = {0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+          for (int q = 0; q < KS; ++q) {
+            treal uq[6];
+            sx.load_u(q, lane, uq);
+#pragma unroll
+            for (int c = 0; c < 6; ++c) ul[c] += uq[c] * sx.lm[q];
+            ul[6] += sx.lm[q];
+          }
+          wave_sum_split<7>(ul, lane);
+          sx.r1 = 1.0 - ul[6];
+          if (lane < 6) {
+            treal e = 0.0;
+#pragma unroll
+            for (int c = 0; c < 6; ++c)
+              if (c == lane) e = (treal(L.kn(N - 1)[c]) - sx.ss0[c]) - ul[c];
+            TT[TL_EPS + lane] = e;
+          }
+          wave_fence();
+        }
+        if (k >= 1 && last_step <= real(pol::step_ok)) break;  // (converged: the remaining steps would move nothing)
+      }
+      // ---- KKT test of the point reached; repair of the held set ----
+      real val[KQ];
+      real2 hl[KQ];
+#pragma unroll
+      for (int q = 0; q < KQ; ++q) {
+        val[q] = lds[o_val[q]];
+        hl[q] = bounds(q);
+      }
+      bool bad = false, neg = false, weakneg = false, viol = false;
+      real ymin = 0.0, comp = 0.0, worst = 0.0;
+#pragma unroll
+      for (int q = 0; q < KQ; ++q) {
+        const int f = flags(q);
+        const real sg = (f & F_SIG) ? sigma : 0.0;
+        const real ru = val[q] - sg - hl[q].x, rl = -val[q] - sg + hl[q].y;
+        const bool hu = (held >> (2 * q)) & 1, hd = (held >> (2 * q + 1)) & 1;
+        const bool nu_ = hu && s_pu[q] < -real(pol::dual), nd_ = hd && s_pl[q] < -real(pol::dual);
+        bad = bad || (hu && !(fabs(ru) <= real(pol::feas))) || (hd && !(fabs(rl) <= real(pol::feas)));
+        neg = neg || nu_ || nd_;
+        weakneg = weakneg || (nu_ && s_lu[q] < real(POLISH_STRONG) * s_tu[q]) || (nd_ && s_ll[q] < real(POLISH_STRONG) * s_tl[q]);
+        viol = viol || (!hu && (f & F_UP) && !(ru <= real(pol::feas))) || (!hd && (f & F_LO) && !(rl <= real(pol::feas)));
+        ymin = fmin(ymin, fmin(hu ? s_pu[q] : real(0), hd ? s_pl[q] : real(0)));
+        comp += (hu ? fabs(s_pu[q] * ru) : real(0)) + (hd ? fabs(s_pl[q] * rl) : real(0));
+        worst = fmax(worst, fmax((f & F_UP) ? ru : real(0), (f & F_LO) ? rl : real(0)));
+      }
+      if constexpr (KS > 0) {
+#pragma unroll
+        for (int q = 0; q < KS; ++q) {
+          const bool hq = (held >> (28 + q)) & 1, fr = sx.on[q] && !hq;
+          const bool nq = hq && sx.p[q] < -treal(pol::dual);
+          bad = bad || (hq && !(fabs(sx.lm[q]) <= treal(pol::feas)));
+          neg = neg || nq;
+          weakneg = weakneg || (nq && sx.l[q] < treal(POLISH_STRONG) * sx.t[q]);
+          viol = viol || (fr && !(-sx.lm[q] <= treal(pol::feas)));
+          ymin = fmin(ymin, hq ? real(sx.p[q]) : real(0));
+          comp += hq ? real(fabs(sx.p[q] * sx.lm[q])) : real(0);
+        }
+      }
+      // (a last multiplier step that still moved the iterate: the steps have not converged -- held rows that are stiff meet
+      // their bounds long before the point is stationary, so the row tests alone would pass)
+      const bool anybad = nan_step || !(last_step <= real(pol::step_tol)) || __ballot(bad) != 0;
+      const bool anyneg = __ballot(neg) != 0, anyweak = __ballot(weakneg) != 0;
+      const bool anyviol = __ballot(viol) != 0;
+      if (!anybad && !anyneg && !anyviol) {  // the optimum for the held set, and the held set passes the KKT test
+        mu = uni(wave_sum(comp) * inv_m);
+        rdmax = wave_max(worst);
+        accepted = true;
+        break;
+      }
+      // repair: release rows with a negative multiplier -- those the interior point did not hold firmly if there are such,
+      // otherwise the most negative ones (a wrong row drags its neighbours' multipliers below zero) -- and only when no
+      // multiplier is negative, hold the rows the new point violates
+      const real ycut = real(0.5) * wave_min(ymin);
+      const int before = held;
+#pragma unroll
+      for (int q = 0; q < KQ; ++q) {
+        const int f = flags(q);
+        const real sg = (f & F_SIG) ? sigma : 0.0;
+        const real ru = val[q] - sg - hl[q].x, rl = -val[q] - sg + hl[q].y;
+        const bool hu = (held >> (2 * q)) & 1, hd = (held >> (2 * q + 1)) & 1;
+        const bool du = hu && s_pu[q] < -real(pol::dual) && (anyweak ? s_lu[q] < real(POLISH_STRONG) * s_tu[q] : s_pu[q] <= ycut);
+        const bool dd = hd && s_pl[q] < -real(pol::dual) && (anyweak ? s_ll[q] < real(POLISH_STRONG) * s_tl[q] : s_pl[q] <= ycut);
+        const bool au = !anyneg && !hu && (f & F_UP) && !(ru <= real(pol::feas));
+        const bool ad = !anyneg && !hd && (f & F_LO) && !(rl <= real(pol::feas));
+        held = (held & ~((du ? 1 : 0) << (2 * q)) & ~((dd ? 2 : 0) << (2 * q))) | ((au ? 1 : 0) << (2 * q)) | ((ad ? 2 : 0) << (2 * q));
+      }
+      if constexpr (KS > 0) {
+#pragma unroll
+        for (int q = 0; q < KS; ++q) {
+          const bool hq = (held >> (28 + q)) & 1, fr = sx.on[q] && !hq;
+          const bool dq = hq && sx.p[q] < -treal(pol::dual) && (anyweak ? sx.l[q] < treal(POLISH_STRONG) * sx.t[q] : real(sx.p[q]) <= ycut);
+          const bool aq = !anyneg && fr && !(-sx.lm[q] <= treal(pol::feas));
+          held = (held & ~((dq ? 1 : 0) << (28 + q))) | ((aq ? 1 : 0) << (28 + q));
+        }
+      }
+      if (__ballot(held != before) == 0) break;  // (the multiplier steps did not converge on a consistent set: nothing to repair)
+    }
+    if (!accepted) {  // refused: iterate, slack variable and simplex weights as the interior point left them
+      wave_sync();
+      get_primal();
+      sigma = sigma_keep;
+      if constexpr (KS > 0) {
+#pragma unroll
+        for (int q = 0; q < KS; ++q) sx.lm[q] = sx.sv[q];
+      }
+      wave_sync();
+    }
+    return accepted;
+  };
+
+  // it == -1 is the start-point Newton step (all row weights zero, full step); it >= 0 the
+  // interior-point iterations.  The iterations are the INNER loop; a polish attempt sits between two runs of it (outer
+  // loop: at most twice round), so that nothing of the polish weighs on the register allocation of the hot loop.
+  it = -1;
+  for (;;) {
+  int hand_over = 0;  // why the interior point stopped: 0 for good (status says why), 1 the early polish attempt, 2 the one at its exit
+  for (; it <= max_iter; ++it) {
+    const bool ipm = it >= 0;
+    // ======== rows: complementarity, residual, barrier weights ========
+    if (ipm) {
+      real musum = 0.0, rdl = 0.0, eysum = 0.0;
+      {
         real val[KQ];
         real2 hl[KQ];
 #pragma unroll
@@ -1601,24 +2008,15 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
           eysum += (f & F_SIG) ? (thu + thd) : real(0);
         }
       }
-      bool pol_giveup = false;
       if constexpr (KS > 0) {
         PT_MARK(2)
         // ---- which points stay explicit this iteration: the (at most MA_MAX) smallest theta below tau ----
-        // (polish round: the free simplex weights have theta = 0 and must ALL be explicit -- more than MA_MAX of them and
-        // the round cannot be set up)
         treal thq[KS];
-        int nfree = 0;
 #pragma unroll
         for (int q = 0; q < KS; ++q) {
-          const bool hq = (held >> (28 + q)) & 1;
-          thq[q] = !sx.on[q] ? tinf : polishing ? (hq ? treal(POLISH_THETA_L) : treal(0)) : sx.l[q] * frcp(sx.t[q]);
+          thq[q] = sx.on[q] ? sx.l[q] * frcp(sx.t[q]) : tinf;
           sx.aidx[q] = -1;
-          nfree += (polishing && sx.on[q] && !hq) ? 1 : 0;
-          if (polishing) sx.p[q] = (hq && sx.l[q] > sx.t[q]) ? sx.l[q] : treal(0);
         }
-        if (polishing) pol_giveup = __popcll(__ballot(nfree > 0)) + __popcll(__ballot(nfree > 1)) + __popcll(__ballot(nfree > 2)) > MA_MAX;
-       if (!pol_giveup) {
         if (lane < 6 * MA_MAX) TT[TL_UA + lane] = 0.0;            // unused slots: u = 0, theta = 1, rhs = 0
         if (lane < MA_MAX) {
           TT[TL_THA + lane] = 1.0;
@@ -1722,74 +2120,56 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
           TT[TL_EPS + lane] = e;
         }
         wave_fence();
-       }
       }
-      if (polishing) {
-        if (pol_giveup) {  // the round cannot be set up: the attempt is refused (what it has changed goes back)
-          refuse();
-          if (pol_final) {
-            status = LMPC_SOLVE_OPTIMAL;
-            leave = true;
-          } else {
-            reentry = again = true;
-          }
-        } else {
-          hsig = uni(qsig + wave_sum(eysum));
-          ++pol_rounds;
-        }
-      } else {
-        {
-          real red[2] = {musum, eysum};
-          wave_sum_n<2>(red);
-          musum = red[0];
-          hsig = qsig + red[1];
-        }
-        rdmax = wave_max(rdl);
-        hsig = uni(hsig);
-        mu = uni(musum * inv_m);
-        // (see the step-length rule; far from feasibility mu may rise legitimately: IAC at 60 m/s into a corner)
-        // (reentry: the same iterate a second time, after a refused polish -- none of the bookkeeping repeats)
-        if (!reentry && it >= 1 && mu >= mu_prev && rdmax <= lim::rd_distress) distress = true;
-        mu_prev = mu;
-        if (!(mu == mu) || !(rdmax == rdmax)) {
+      {
+        real red[2] = {musum, eysum};
+        wave_sum_n<2>(red);
+        musum = red[0];
+        hsig = qsig + red[1];
+      }
+      rdmax = wave_max(rdl);
+      hsig = uni(hsig);
+      mu = uni(musum * inv_m);
+      // (see the step-length rule; far from feasibility mu may rise legitimately: IAC at 60 m/s into a corner)
+      // (reentry: the same iterate a second time -- after a refused polish, or on the way to the final one: none of the
+      // bookkeeping repeats)
+      if (!reentry && it >= 1 && mu >= mu_prev && rdmax <= lim::rd_distress) distress = true;
+      mu_prev = mu;
+      const bool again_here = reentry;
+      reentry = false;
+      if (!(mu == mu) || !(rdmax == rdmax)) {
+        status = LMPC_SOLVE_INFEASIBLE;
+        break;
+      }
+      if (mu <= tol && rdmax <= lim::rd_ok) {
+        status = LMPC_SOLVE_OPTIMAL;
+        hand_over = polish_on ? 2 : 0;
+        break;
+      }
+      // primal infeasibility: on a feasible problem the row residual contracts by (1 - alpha) per iteration; not
+      // losing a tenth over five iterations while still large (step lengths stuck below ~2 %) ends the solve (this
+      // also bounds the straggler that would otherwise hold its CU slot for max_iter iterations).  "Not halved" is
+      // too tight: feasible problems with a slow start (IAC at 60 m/s into a corner) contract by 0.6-0.8 per five.
+      if (!again_here && it % 5 == 0) {
+        if (it >= 10 && rdmax > lim::rd_infeasible && rdmax > real(0.9) * rd_check) {
           status = LMPC_SOLVE_INFEASIBLE;
-          leave = true;
-        } else if (mu <= tol && rdmax <= lim::rd_ok) {
-          if (polish_on) {  // converged: polish what the interior point has reached
-            polishing = pol_init = pol_final = again = true;
-          } else {
-            status = LMPC_SOLVE_OPTIMAL;
-            leave = true;
-          }
-        } else {
-          // primal infeasibility: on a feasible problem the row residual contracts by (1 - alpha) per iteration; not
-          // losing a tenth over five iterations while still large (step lengths stuck below ~2 %) ends the solve (this
-          // also bounds the straggler that would otherwise hold its CU slot for max_iter iterations).  "Not halved" is
-          // too tight: feasible problems with a slow start (IAC at 60 m/s into a corner) contract by 0.6-0.8 per five.
-          if (!reentry && it % 5 == 0) {
-            if (it >= 10 && rdmax > lim::rd_infeasible && rdmax > real(0.9) * rd_check) {
-              status = LMPC_SOLVE_INFEASIBLE;
-              leave = true;
-            }
-            rd_check = rdmax;
-          }
-          if (it == max_iter) leave = true;
-          // the early attempt: the active set is usually settled two iterations before the interior point's own tolerance
-          if (!leave && polish_on && !pol_early_done && mu <= real(pol::mu_early) && rdmax <= real(pol::rd_early)) {
-            pol_early_done = true;
-            polishing = pol_init = again = true;
-            pol_final = false;
-          }
+          break;
         }
-        reentry = false;
+        rd_check = rdmax;
       }
-     } while (again);
-      if (leave) break;
+      if (it == max_iter) break;
+      // the early attempt: the active set is usually settled two iterations before the interior point's own tolerance
+      if constexpr (pol::early) {
+        if (polish_on && !pol_early_done && mu <= real(pol::mu_early) && rdmax <= real(pol::rd_early)) {
+          pol_early_done = true;
+          hand_over = 1;
+          break;
+        }
+      }
       wave_sync();
       PT_MARK(2)
-      // the stabilised factor: double precision late in the iteration, every precision in a polish round
-      if (polishing || (sizeof(real) == 8 && mu <= real(JOSEPH_MU)))
-        riccati_factor<(KS > 0), true>(L, lane, TT + TL_PT);
+      if (sizeof(real) == 8 && mu <= real(JOSEPH_MU))  // (single precision stops at mu ~ 2e-6)
+        riccati_factor<(KS > 0), (sizeof(real) == 8)>(L, lane, TT + TL_PT);
       else
         riccati_factor<(KS > 0), false>(L, lane, TT + TL_PT);
       PT_MARK(3)
@@ -1798,17 +2178,14 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
     real sigc = 0.0, alpha = 1.0, dsigma = 0.0;
     bool numerics_failed = false, stalled = false;
     treal eeps[6] = {0, 0, 0, 0, 0, 0};  // E eps of this iterate (safe-set block), in scalar registers
-    real d_val[KQ];
-    bool pol_nan = false;
-    // interior point: predictor and corrector from the same point; polish round: pol::steps multiplier steps, each from the
-    // point the one before has reached
-    const int npass = ipm ? (polishing ? pol::steps : 2) : 1;
-    for (int pass = 0; pass < npass; ++pass) {
-      const real smu = (pass == 1 && !polishing) ? sigc * mu : 0.0, pm = (pass == 1 && !polishing) ? 1.0 : 0.0;
-      if constexpr (KS > 0) {
+    if constexpr (KS > 0) {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) eeps[k] = uni(TT[TL_E + k] * TT[TL_EPS + k]);
-      }
+      for (int k = 0; k < 6; ++k) eeps[k] = uni(TT[TL_E + k] * TT[TL_EPS + k]);
+    }
+    real d_val[KQ];
+    const int npass = ipm ? 2 : 1;
+    for (int pass = 0; pass < npass; ++pass) {
+      const real smu = (pass == 1) ? sigc * mu : 0.0, pm = (pass == 1) ? 1.0 : 0.0;
       // ======== gradient: cost gradient + row coefficients, written by the component owner ========
       real sgsum = 0.0;  // sum of boundary-row coefficients entering the sigma gradient
       if constexpr (KS > 0) {
@@ -1820,9 +2197,7 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
           for (int q = 0; q < KS; ++q) {
             treal itf, uq[6];
             sx.load_u(q, lane, uq);
-            const treal blq = polishing ? simplex_bl_polish(sx.lm[q], sx.p[q], ((held >> (28 + q)) & 1) != 0, sx.j[q], uq, eeps, itf)
-                                        : simplex_bl(sx.lm[q], sx.t[q], sx.l[q], sx.p[q], sx.j[q], uq, treal(smu), treal(pm), eeps, itf);
-            const treal rj = sx.on[q] ? -blq : treal(0);
+            const treal rj = sx.on[q] ? -simplex_bl(sx.lm[q], sx.t[q], sx.l[q], sx.p[q], sx.j[q], uq, treal(smu), treal(pm), eeps, itf) : treal(0);
             if (sx.aidx[q] >= 0) TT[TL_RA + sx.aidx[q]] = rj;
             const treal w = (sx.on[q] && sx.aidx[q] < 0) ? rj * itf : treal(0);
             bs[6] += w;
@@ -1860,20 +2235,6 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
           cb[q] = lds[CTB + ((gr >> 8) & 0xff)];
           ql[q] = lds[o_val[q] + (KN_QLIN - 3)];
         }
-        if (polishing) {  // held rows: y + theta * residual (s_pu / s_pl carry y in a polish round)
-#pragma unroll
-          for (int q = 0; q < KQ; ++q) {
-            const int f = flags(q);
-            const real sg = (f & F_SIG) ? sigma : 0.0;
-            const bool hu = (held >> (2 * q)) & 1, hd = (held >> (2 * q + 1)) & 1;
-            const real cu = hu ? rfma(real(pol::theta), val[q] - sg - hl[q].x, s_pu[q]) : real(0);
-            const real cd = hd ? rfma(real(pol::theta), -val[q] - sg + hl[q].y, s_pl[q]) : real(0);
-            const real g = ca[q] * val[q] + cb[q] * par[q] + ((f & F_QLIN) ? ql[q] : real(0));
-            lds[o_w(q)] = g + cu - cd;
-            if (pass == 0) lds[(f & F_EY) ? JB + KN_EY : o_w(q) + 10] = 0.0;
-            sgsum += (f & F_SIG) ? (cu + cd) : real(0);
-          }
-        } else {
 #pragma unroll
         for (int q = 0; q < KQ; ++q) {
           const int f = flags(q);
@@ -1887,7 +2248,6 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
           lds[o_w(q)] = g + cu - cd;
           if (pass == 0) lds[(f & F_EY) ? JB + KN_EY : o_w(q) + 10] = 0.0;
           sgsum += (f & F_SIG) ? (cu + cd) : real(0);
-        }
         }
       }
       wave_sync();
@@ -1966,8 +2326,7 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
         for (int q = 0; q < KS; ++q) {
           treal itf, uq[6];
           sx.load_u(q, lane, uq);
-          treal r = polishing ? -simplex_bl_polish(sx.lm[q], sx.p[q], ((held >> (28 + q)) & 1) != 0, sx.j[q], uq, eeps, itf)
-                              : -simplex_bl(sx.lm[q], sx.t[q], sx.l[q], sx.p[q], sx.j[q], uq, treal(smu), treal(pm), eeps, itf);
+          treal r = -simplex_bl(sx.lm[q], sx.t[q], sx.l[q], sx.p[q], sx.j[q], uq, treal(smu), treal(pm), eeps, itf);
 #pragma unroll
           for (int k = 0; k < 6; ++k) r += uq[k] * e[k];
           r = sx.on[q] ? r : 0.0;
@@ -1995,58 +2354,6 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
           const treal dA = TT[TL_XA + (sx.aidx[q] >= 0 ? sx.aidx[q] : 0)];
           sx.dl[q] = sx.on[q] ? (sx.aidx[q] >= 0 ? dA : dB) : treal(0);
         }
-      }
-      if (polishing) {
-        // ======== polish round: the full step, taken at once; multipliers from the residual BEFORE the step plus the row's
-        // own increment (the stored value is rounded after the update, the increment is not: in single precision the
-        // re-read residual of a row that has landed on its bound is exactly zero and says nothing) ========
-        bool finite_step = dsigma == dsigma;
-#pragma unroll
-        for (int q = 0; q < KQ; ++q) {
-          const int f = flags(q);
-          const real dval = dz0[q] + dsigma * dz1[q];
-          finite_step = finite_step && (fabs(dval) < inf);
-          const real sg = (f & F_SIG) ? sigma : 0.0, dsg = (f & F_SIG) ? dsigma : 0.0;
-          const bool hu = (held >> (2 * q)) & 1, hd = (held >> (2 * q + 1)) & 1;
-          s_pu[q] = hu ? rfma(real(pol::theta), (val[q] - sg - hl[q].x) + (dval - dsg), s_pu[q]) : real(0);
-          s_pl[q] = hd ? rfma(real(pol::theta), (-val[q] - sg + hl[q].y) + (-dval - dsg), s_pl[q]) : real(0);
-          const bool mv = (f & F_MOVE) != 0;
-          lds[mv ? o_val[q] : JB + q] += mv ? dval : real(0);
-        }
-        if (has_sigma) sigma = uni(sigma + dsigma);
-        if constexpr (KS > 0) {
-#pragma unroll
-          for (int q = 0; q < KS; ++q) {
-            const bool hq = (held >> (28 + q)) & 1;
-            sx.p[q] = hq ? sx.p[q] + treal(POLISH_THETA_L) * (-sx.lm[q] - sx.dl[q]) : treal(0);
-            sx.lm[q] += sx.dl[q];
-            finite_step = finite_step && (fabs(sx.dl[q]) < tinf);
-          }
-        }
-        pol_nan = pol_nan || (__ballot(!finite_step) != 0);
-        wave_sync();
-        if constexpr (KS > 0) {  // the hull residual and the simplex residual at the new point (the next step's gradient)
-          treal ul[7] = {0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-          for (int q = 0; q < KS; ++q) {
-            treal uq[6];
-            sx.load_u(q, lane, uq);
-#pragma unroll
-            for (int k = 0; k < 6; ++k) ul[k] += uq[k] * sx.lm[q];
-            ul[6] += sx.lm[q];
-          }
-          wave_sum_split<7>(ul, lane);
-          sx.r1 = 1.0 - ul[6];
-          if (lane < 6) {
-            treal e = 0.0;
-#pragma unroll
-            for (int k = 0; k < 6; ++k)
-              if (k == lane) e = (treal(L.kn(N - 1)[k]) - sx.ss0[k]) - ul[k];
-            TT[TL_EPS + lane] = e;
-          }
-          wave_fence();
-        }
-        continue;
       }
       // ======== row steps; largest feasible step as 1 / max(1, max -dt/t, max -dlam/lam) ========
       auto row_step = [&](bool on, treal t, treal lam, treal pprod, treal rd, treal cdy, treal& dt_, treal& dl_,
@@ -2175,118 +2482,15 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
       }
     }
 
-    if (polishing) {
-      // ======== polish round: KKT test of the point reached, repair of the held set ========
-      bool changed = false;
-      {
-        real val[KQ];
-        real2 hl[KQ];
-#pragma unroll
-        for (int q = 0; q < KQ; ++q) {
-          val[q] = lds[o_val[q]];
-          hl[q] = bounds(q);
-        }
-        bool bad = false, neg = false, weakneg = false, viol = false;
-        real ymin = 0.0, comp = 0.0;
-        real ru[KQ], rl[KQ];
-#pragma unroll
-        for (int q = 0; q < KQ; ++q) {
-          const int f = flags(q);
-          const real sg = (f & F_SIG) ? sigma : 0.0;
-          ru[q] = val[q] - sg - hl[q].x;
-          rl[q] = -val[q] - sg + hl[q].y;
-          const bool hu = (held >> (2 * q)) & 1, hd = (held >> (2 * q + 1)) & 1;
-          const bool nu_ = hu && s_pu[q] < -real(pol::dual), nd_ = hd && s_pl[q] < -real(pol::dual);
-          bad = bad || (hu && !(fabs(ru[q]) <= real(pol::feas))) || (hd && !(fabs(rl[q]) <= real(pol::feas)));
-          neg = neg || nu_ || nd_;
-          weakneg = weakneg || (nu_ && s_lu[q] < real(POLISH_STRONG) * s_tu[q]) || (nd_ && s_ll[q] < real(POLISH_STRONG) * s_tl[q]);
-          viol = viol || (!hu && (f & F_UP) && !(ru[q] <= real(pol::feas))) || (!hd && (f & F_LO) && !(rl[q] <= real(pol::feas)));
-          ymin = fmin(ymin, fmin(hu ? s_pu[q] : real(0), hd ? s_pl[q] : real(0)));
-          comp += (hu ? fabs(s_pu[q] * ru[q]) : real(0)) + (hd ? fabs(s_pl[q] * rl[q]) : real(0));
-        }
-        if constexpr (KS > 0) {
-#pragma unroll
-          for (int q = 0; q < KS; ++q) {
-            const bool hq = (held >> (28 + q)) & 1, fr = sx.on[q] && !hq;
-            const bool nq = hq && sx.p[q] < -treal(pol::dual);
-            bad = bad || (hq && !(fabs(sx.lm[q]) <= treal(pol::feas)));
-            neg = neg || nq;
-            weakneg = weakneg || (nq && sx.l[q] < treal(POLISH_STRONG) * sx.t[q]);
-            viol = viol || (fr && !(-sx.lm[q] <= treal(pol::feas)));
-            ymin = fmin(ymin, hq ? real(sx.p[q]) : real(0));
-            comp += hq ? real(fabs(sx.p[q] * sx.lm[q])) : real(0);
-          }
-        }
-        const bool anybad = pol_nan || __ballot(bad) != 0, anyneg = __ballot(neg) != 0, anyweak = __ballot(weakneg) != 0;
-        const bool anyviol = __ballot(viol) != 0;
-        if (!anybad && !anyneg && !anyviol) {  // accepted: the optimum for the held set, and the held set passes the KKT test
-          mu = uni(wave_sum(comp) * inv_m);
-          real worst = 0.0;  // largest violation left on any row
-#pragma unroll
-          for (int q = 0; q < KQ; ++q)
-            worst = fmax(worst, fmax((flags(q) & F_UP) ? ru[q] : real(0), (flags(q) & F_LO) ? rl[q] : real(0)));
-          rdmax = wave_max(worst);
-          polished = true;
-          status = LMPC_SOLVE_OPTIMAL;
-          break;
-        }
-        // repair: release rows with a negative multiplier -- those the interior point did not hold firmly if there are
-        // such, otherwise the most negative ones (a wrong row drags its neighbours' multipliers below zero) -- and only
-        // when no multiplier is negative, hold the rows the new point violates
-        const real ycut = real(0.5) * wave_min(ymin);
-        const int before = held;
-#pragma unroll
-        for (int q = 0; q < KQ; ++q) {
-          const int f = flags(q);
-          const bool hu = (held >> (2 * q)) & 1, hd = (held >> (2 * q + 1)) & 1;
-          const bool du = hu && s_pu[q] < -real(pol::dual) && (anyweak ? s_lu[q] < real(POLISH_STRONG) * s_tu[q] : s_pu[q] <= ycut);
-          const bool dd = hd && s_pl[q] < -real(pol::dual) && (anyweak ? s_ll[q] < real(POLISH_STRONG) * s_tl[q] : s_pl[q] <= ycut);
-          const bool au = !anyneg && !hu && (f & F_UP) && !(ru[q] <= real(pol::feas));
-          const bool ad = !anyneg && !hd && (f & F_LO) && !(rl[q] <= real(pol::feas));
-          held = (held & ~((du ? 1 : 0) << (2 * q)) & ~((dd ? 2 : 0) << (2 * q))) | ((au ? 1 : 0) << (2 * q)) | ((ad ? 2 : 0) << (2 * q));
-        }
-        if constexpr (KS > 0) {
-#pragma unroll
-          for (int q = 0; q < KS; ++q) {
-            const bool hq = (held >> (28 + q)) & 1, fr = sx.on[q] && !hq;
-            const bool dq = hq && sx.p[q] < -treal(pol::dual) && (anyweak ? sx.l[q] < treal(POLISH_STRONG) * sx.t[q] : real(sx.p[q]) <= ycut);
-            const bool aq = !anyneg && fr && !(-sx.lm[q] <= treal(pol::feas));
-            held = (held & ~((dq ? 1 : 0) << (28 + q))) | ((aq ? 1 : 0) << (28 + q));
-          }
-        }
-        changed = __ballot(held != before) != 0;
-      }
-      ++pol_round;
-      refuse();  // (every round starts from the interior point's iterate)
-      if (changed && pol_round < pol::rounds) {
-        polishing = true;
-        --it;
-        continue;
-      }
-      if (pol_final) {
-        status = LMPC_SOLVE_OPTIMAL;
-        break;
-      }
-      reentry = true;
-      --it;
-      continue;
-    }
     if (numerics_failed) {
       status = (mu <= real(10) * tol && rdmax <= lim::rd_ok) ? LMPC_SOLVE_OPTIMAL : LMPC_SOLVE_MAX_ITER;
-      if (status == LMPC_SOLVE_OPTIMAL && polish_on) {  // (what the interior point reached is polished like a converged iterate)
-        polishing = pol_init = pol_final = true;
-        --it;
-        continue;
-      }
+      // (what the interior point has reached is polished like a converged iterate)
+      hand_over = (status == LMPC_SOLVE_OPTIMAL && polish_on) ? 2 : 0;
       break;
     }
     if (stalled) {
       status = LMPC_SOLVE_OPTIMAL;
-      if (polish_on) {
-        polishing = pol_init = pol_final = true;
-        --it;
-        continue;
-      }
+      hand_over = polish_on ? 2 : 0;
       break;
     }
     // ======== primal update by the component owners ========
@@ -2333,6 +2537,20 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
       }
     }
   }
+  if (hand_over == 0) break;
+  wave_sync();
+  if (polish_attempt()) {
+    polished = true;
+    status = LMPC_SOLVE_OPTIMAL;
+    break;
+  }
+  if (hand_over == 2 || !pol::early) {  // refused at the exit: the interior point's own answer stands
+    status = LMPC_SOLVE_OPTIMAL;
+    break;
+  }
+  reentry = true;  // refused early: the interior point goes on from the same iterate (same `it`; the rows phase puts its
+                   // barrier weights back into the records)
+  }
   PT_MARK(7)
   if (it < 0) it = 0;
   it += pol_rounds;  // (a polish round costs about what an iteration does and is counted as one)
@@ -2375,6 +2593,50 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
   }
 }
 
+template <typename real, int KQ, int KS, typename io>
+__global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void lmpc_solve_kernel(
+    lmpc_params P, int B, const io* __restrict__ ws_lin, const io* __restrict__ x_ic,
+    const io* __restrict__ u_ic, const io* __restrict__ T_ref, const io* __restrict__ bl,
+    const io* __restrict__ br, const io* __restrict__ vref, const io* __restrict__ ss_x,
+    const io* __restrict__ ss_j, io* __restrict__ lam_out, io* __restrict__ X_out,
+    io* __restrict__ U_out, io* __restrict__ dU_out, int* __restrict__ status_out,
+    int* __restrict__ iters_out, io* __restrict__ kkt_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];  // one symbol for every instantiation
+  // XCD-aware problem assignment: consecutive workgroups go round-robin to the 8 XCDs (each with its own L2), while
+  // consecutive problems share 64-byte lines in the [field][knot][batch] arrays.  Workgroup w takes problem
+  // (w mod 8) * ceil(B / 8) + w / 8, so each XCD owns a contiguous eighth of the batch and the 8-byte strided
+  // accesses of neighbouring problems merge in that XCD's L2 instead of reaching HBM as partial lines.
+  // With a launch order (longest job first from the previous solve's iteration counts, lmpc_set_launch_order) workgroup
+  // w takes problem launch_order[w]: the hardware starts workgroups in index order, so the long problems go first and the
+  // short ones fill the tail of the second residency round.
+  int b = (int)(blockIdx.x & 7) * ((B + 7) >> 3) + (int)(blockIdx.x >> 3);
+  if (P.launch_order) b = (int)blockIdx.x < B ? P.launch_order[blockIdx.x] : B;
+  if (b >= B) return;
+  lmpc_solve_problem<real, KQ, KS, io>(P, B, b, lds_raw, ws_lin, x_ic, u_ic, T_ref, bl, br, vref, ss_x, ss_j, lam_out, X_out, U_out,
+                                       dU_out, status_out, iters_out, kkt_out);
+}
+
+// Second pass of a mixed-precision solve (lmpc_solve_batch_mixed): the problems the fp32 iteration marked
+// LMPC_SOLVE_UNVERIFIED, solved in fp64.  `list` [count] holds them (lmpc_collect_unverified_kernel); a small fixed grid
+// of workgroups takes list entries in turn -- launching one workgroup per problem of the batch to have 99 % of them
+// return at once costs more than the solves (38 KB of LDS and 500 registers to allocate per workgroup: 1.3 ms per 8192).
+template <typename real, int KQ, int KS, typename io>
+__global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void lmpc_cleanup_kernel(
+    lmpc_params P, int B, const int* __restrict__ list, const int* __restrict__ count, const io* __restrict__ ws_lin,
+    const io* __restrict__ x_ic, const io* __restrict__ u_ic, const io* __restrict__ T_ref, const io* __restrict__ bl,
+    const io* __restrict__ br, const io* __restrict__ vref, const io* __restrict__ ss_x,
+    const io* __restrict__ ss_j, io* __restrict__ lam_out, io* __restrict__ X_out,
+    io* __restrict__ U_out, io* __restrict__ dU_out, int* __restrict__ status_out,
+    int* __restrict__ iters_out, io* __restrict__ kkt_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const int n = *count;
+  for (int w = blockIdx.x; w < n; w += gridDim.x) {
+    lmpc_solve_problem<real, KQ, KS, io>(P, B, list[w], lds_raw, ws_lin, x_ic, u_ic, T_ref, bl, br, vref, ss_x, ss_j, lam_out, X_out,
+                                         U_out, dU_out, status_out, iters_out, kkt_out);
+    wave_fence();
+  }
+}
+
 #define LMPC_INSTANTIATE(REAL, KQ, KS, IO)                                                                              \
   template __global__ void lmpc_solve_kernel<REAL, KQ, KS, IO>(lmpc_params, int, const IO*, const IO*, const IO*,        \
                                                                 const IO*, const IO*, const IO*, const IO*, const IO*,    \
@@ -2409,6 +2671,17 @@ LMPC_INSTANTIATE(float, 11, 0, double)  // iac_car_tracking_mpc.param.yaml ships
 LMPC_INSTANTIATE(float, 14, 0, double)
 LMPC_INSTANTIATE(float, 4, 2, double)  // the learning problem, N <= 23 (BASELINE configs[4])
 LMPC_INSTANTIATE(float, 4, 3, double)
+// the fp64 second pass behind each of the mixed kernels above
+#define LMPC_INSTANTIATE_CLEANUP(KQ, KS)                                                                                  \
+  template __global__ void lmpc_cleanup_kernel<double, KQ, KS, double>(lmpc_params, int, const int*, const int*,          \
+      const double*, const double*, const double*, const double*, const double*, const double*, const double*,           \
+      const double*, const double*, double*, double*, double*, double*, int*, int*, double*);
+LMPC_INSTANTIATE_CLEANUP(4, 0)
+LMPC_INSTANTIATE_CLEANUP(7, 0)
+LMPC_INSTANTIATE_CLEANUP(11, 0)
+LMPC_INSTANTIATE_CLEANUP(14, 0)
+LMPC_INSTANTIATE_CLEANUP(4, 2)
+LMPC_INSTANTIATE_CLEANUP(4, 3)
 // (the learning problem at N = 40 in mixed precision was built and measured: 1.16 M solves/s against 0.70 M in fp64, but
 //  median 1.2e-3 / 99th percentile 1.5e-2 from the fp64 answers -- outside the 1e-3 the mixed entry states; not shipped)
 #endif

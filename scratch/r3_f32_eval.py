@@ -67,5 +67,10 @@ pickle.dump({{k: o[k] for k in ('X_optm', 'U_optm', 'dU_optm', 'status', 'iters'
     if acc.any(): print(f"   accepted {acc.sum()}: max err {e[both & acc].max():.2e}, 99.9% {np.quantile(e[both & acc], .999):.2e};  not accepted {np.sum(both & ~acc)}: max err {e[both & ~acc].max() if (both & ~acc).any() else 0:.2e}")
     if acc.any(): print("   worst accepted:", [(int(b), f"{e[b]:.1e}") for b in np.argsort(-np.where(both & acc, e, 0))[:5]])
     if os.environ.get("DUMP_ACC"): np.save(os.environ["DUMP_ACC"], acc)
+    if acc.any():
+        ls = o["kkt"][0]
+        for lo, hi in ((0, 1e-7), (1e-7, 1e-6), (1e-6, 1e-5), (1e-5, 1e-4), (1e-4, 1e-3), (1e-3, 1e9)):
+            sel = both & acc & (ls >= lo) & (ls < hi)
+            if sel.any(): print(f"     last step in [{lo:g},{hi:g}): {sel.sum():5d} problems, max err {e[sel].max():.2e}")
     worst = np.argsort(-np.where(both, e, 0))[:6]
     print("   worst:", [(int(b), f"{e[b]:.1e}", int(o['iters'][b])) for b in worst])

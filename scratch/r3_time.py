@@ -7,6 +7,8 @@ ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT))
 import importlib
 pkg = importlib.import_module("racing-lmpc-ros2_amd")
+if os.environ.get("LMPC_LIB"):
+    pkg.capi.library_path = lambda: Path(os.environ["LMPC_LIB"])
 SX = np.array([2000, 10, 0.1, 80, 2, 2.0]); SU = np.array([10, 0.3])
 dev = torch.device("cuda:0")
 
@@ -27,7 +29,7 @@ def case(kind, N, B, precisions=("f64",), seeds=0):
     tr = pkg.workloads.synthetic_track("putnam" if kind == "iac" else "barc")
     res = {}
     ref = None
-    for pol in (0, -1):
+    for pol in ((0, -1, 1) if "mixed" in precisions else (0, -1)):
         if kind == "lmpc":
             cfg = dict(pkg.presets.barc_lmpc(N, 5)); laps = pkg.workloads.synthetic_laps(tr, 5)
             x, u = pkg.workloads.sample_states_near_laps(laps, B, tr["L"], seed=seeds)
@@ -51,7 +53,7 @@ def case(kind, N, B, precisions=("f64",), seeds=0):
             q = torch.stack([s_last + (kk - torch.fmod(kk, L)) * torch.sign(s0 - s_last), inp["X_ref"][1, -1]]).contiguous()
             ss_x, ss_j, _ = sv.ss_query(q)
             kw = dict(ss_x=ss_x, ss_j=ss_j)
-        for prec in precisions:
+        for prec in (precisions if pol != 1 else ("mixed",)):
             out = sv.alloc_outputs(B)
             if kind == "lmpc":
                 out["convex_combi_optm"] = torch.zeros((int(cfg["num_ss_pts"]), B), dtype=torch.float64, device=dev)
@@ -62,7 +64,7 @@ def case(kind, N, B, precisions=("f64",), seeds=0):
             else:
                 o, ms = timed(sv, lambda: sv.solve(inp, out, mixed=(prec == "mixed"), **kw))
             st = np.bincount(o["status"].cpu().numpy(), minlength=4); it = o["iters"].cpu().numpy()
-            line = f"{kind:5s} N={N:2d} B={B:6d} {prec:5s} polish={'on ' if pol == 0 else 'off'}: QP kernel {ms:8.3f} ms  {B / ms / 1e3:7.3f} M/s  status {st.tolist()}  iters mean {it.mean():.2f} max {it.max()}"
+            line = f"{kind:5s} N={N:2d} B={B:6d} {prec:5s} polish={'on ' if pol == 0 else 'off' if pol < 0 else 'on, one pass'}: QP kernel {ms:8.3f} ms  {B / ms / 1e3:7.3f} M/s  status {st.tolist()}  iters mean {it.mean():.2f} max {it.max()}"
             if prec == "f64" and pol == 0:
                 ref = {k: o[k].clone() for k in ("X_optm", "U_optm", "status")}
             elif ref is not None:

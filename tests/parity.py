@@ -1,10 +1,9 @@
-"""Shared parity bookkeeping: per-problem scaled error against the dense optimum, and the contract check that holds
-strictly complementary problems to 1e-6 and only oracle-labelled degenerate ones to the relaxed bound
-(tests/tolerances.py)."""
+"""Shared parity bookkeeping: per-problem scaled error against the dense optimum, and the contract check that holds every
+problem to 1e-6 (tests/tolerances.py)."""
 import numpy as np
 
 from oracle import params as P, qp as Q
-from tolerances import TOL_DEGENERATE, TOL_DU, TOL_XU
+from tolerances import TOL_DU, TOL_XU
 
 
 def per_problem_err(out, ref):
@@ -16,22 +15,15 @@ def per_problem_err(out, ref):
 
 
 def assert_contract(out, ref, margin, certified=None, who="kernel"):
-    """Every problem solved; strictly complementary ones (oracle's margin >= DEGENERATE_MARGIN, certified dense optimum)
-    within TOL_XU / TOL_DU of the dense optimum, the others within TOL_DEGENERATE.  Returns the degenerate fraction."""
+    """Every problem solved and within TOL_XU / TOL_DU of the dense optimum -- strictly complementary or degenerate alike
+    (tests/tolerances.py).  Returns the degenerate fraction (oracle's margin below DEGENERATE_MARGIN) for the record."""
     status = np.asarray(out["status"])
     assert (status == 0).all(), (who, np.where(status != 0)[0], status[status != 0])
     exu, ed = per_problem_err(out, ref)
-    strict = np.asarray(margin) >= Q.DEGENERATE_MARGIN
-    if certified is not None:
-        strict &= np.asarray(certified, dtype=bool)
-    assert strict.mean() > 0.5, strict.mean()
-    worst = int(np.argmax(np.where(strict, exu, 0.0)))
-    assert exu[strict].max() < TOL_XU, (who, "strict", worst, exu[worst], float(np.asarray(margin)[worst]))
-    assert ed[strict].max() < TOL_DU, (who, "strict dU", ed[strict].max())
-    if (~strict).any():
-        assert exu[~strict].max() < TOL_DEGENERATE, (who, "degenerate", exu[~strict].max())
-        assert ed[~strict].max() < 40 * TOL_DEGENERATE, (who, "degenerate dU", ed[~strict].max())
-    return float((~strict).mean())
+    worst = int(np.argmax(exu))
+    assert exu.max() < TOL_XU, (who, worst, exu[worst], float(np.asarray(margin)[worst]))
+    assert ed.max() < TOL_DU, (who, "dU", ed.max())
+    return float((np.asarray(margin) < Q.DEGENERATE_MARGIN).mean())
 
 
 def dense_reference(cfg, veh, inp, problems, ss_x=None, ss_j=None):
@@ -57,9 +49,11 @@ def dense_reference(cfg, veh, inp, problems, ss_x=None, ss_j=None):
 
 
 def assert_same_iterations(a, b):
-    """Kernel and serial twin run the same iteration: the counts are equal on >= 90 % of the problems and within one on
-    >= 97 %.  The few that differ by more are problems that crawl towards the tolerance at the floor of fp64 (mu a few
-    1e-14, changing by a factor 0.6 .. 0.9 per iteration): which iteration first dips under it depends on the last bits,
-    i.e. on FMA contraction and summation order."""
+    """Kernel and serial twin run the same iteration (the count is interior-point iterations + polish rounds): equal on
+    >= 90 % of the problems and within one on >= 95 %.  The few that differ by more are borderline decisions that depend on
+    the last bits, i.e. on FMA contraction and summation order: a polish attempt that one of the two accepts and the other
+    refuses (a held row met to 0.9e-9 or 1.1e-9) costs the refusing one the three to five interior-point iterations down to
+    its own tolerance; a problem crawling at the floor of fp64 (mu a few 1e-14) dips under the tolerance an iteration
+    apart.  Both end at the same optimum (the value tests hold them to 1e-6 of each other)."""
     d = np.abs(np.asarray(a).astype(int) - np.asarray(b).astype(int))
-    assert (d == 0).mean() >= 0.9 and (d <= 1).mean() >= 0.97 and d.max() <= 6, (float((d == 0).mean()), float((d <= 1).mean()), int(d.max()))
+    assert (d == 0).mean() >= 0.9 and (d <= 1).mean() >= 0.95 and d.max() <= 8, (float((d == 0).mean()), float((d <= 1).mean()), int(d.max()))

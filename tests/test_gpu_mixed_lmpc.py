@@ -74,19 +74,44 @@ def test_mixed_learning_solve_against_dense_optima_with_160_points(pkg):
     """5 stored laps, 160 safe-set points: against the DENSE optimum."""
     e = _dense_errors(pkg, 32)
     print("mixed LMPC, S = 160, vs dense: median %.1e, 90 %% %.1e, max %.1e" % (np.median(e), np.percentile(e, 90), e.max()))
-    assert np.median(e) < 1e-4 and np.percentile(e, 90) < TOL_MIXED and e.max() < 3e-2, np.sort(e)[-5:]
+    assert np.median(e) < 1e-5 and e.max() < TOL_MIXED, np.sort(e)[-5:]
 
 
-@pytest.mark.xfail(strict=True, reason="measured on 4096 problems against the fp64 kernel: median 1.4e-5, 99th percentile "
-                                       "3.3e-3, worst 1.0e-2 -- the tail is the fp32 stage rows (soft boundary, saturated "
-                                       "inputs), as on the tracking problem; every problem within 1e-3 is not met")
 def test_mixed_learning_solve_every_problem_within_1e3(pkg):
+    """Every problem of a full-size batch within the stated 1e-3 of the fp64 kernel's answer.  (Round 2 committed this as a
+    strict xfail: median 1.4e-5, 99th percentile 3.3e-3, worst 1.0e-2 -- an fp32 interior point stops at mu ~ 2e-6, O(sqrt(mu))
+    from the optimum where the active set is still ambiguous.  The fp32 polish verifies its answers; what it cannot verify,
+    about a percent of a batch, is solved by the fp64 second pass.)"""
     sv, tr, laps, inp, ss_x, ss_j = _s160(pkg, 4096)
     o64, o32 = _solve(sv, inp, ss_x, ss_j, False), _solve(sv, inp, ss_x, ss_j, True)
     both = (o64["status"] == 0) & (o32["status"] == 0)
+    assert both.mean() > 0.999
     e, _ = per_problem_err({k: o32[k][..., both] for k in ("X_optm", "U_optm", "dU_optm")},
                            {k: o64[k][..., both] for k in ("X_optm", "U_optm", "dU_optm")})
-    assert e.max() < TOL_MIXED, (np.median(e), np.percentile(e, 99), e.max())
+    print("mixed vs fp64, 4096 learning problems: median %.1e, 99 %% %.1e, max %.1e" % (np.median(e), np.percentile(e, 99), e.max()))
+    assert e.max() < TOL_MIXED and np.percentile(e, 99) < 1e-4, (np.median(e), np.percentile(e, 99), e.max())
+
+
+def test_mixed_one_pass_marks_what_it_cannot_verify(pkg):
+    """lmpc_config.polish = 1: no fp64 second pass -- the problems whose fp32 polish was refused keep LMPC_SOLVE_UNVERIFIED (3);
+    they are a small fraction, the accepted ones are within the stated tolerance, and the default two-pass solve reports
+    none."""
+    sv, tr, laps, inp, ss_x, ss_j = _s160(pkg, 2048)
+    o64, two = _solve(sv, inp, ss_x, ss_j, False), _solve(sv, inp, ss_x, ss_j, True)
+    cfg1 = dict(pkg.presets.barc_lmpc(20, 5)); cfg1["polish"] = 1
+    sv1 = pkg.Solver(cfg1, pkg.presets.barc_vehicle(), device=0)
+    sv1.set_safe_set(laps, tr["L"])
+    one = _solve(sv1, inp, ss_x, ss_j, True)
+    assert not (two["status"] == 3).any()
+    marked = one["status"] == 3
+    assert 0 < marked.mean() < 0.03, marked.mean()
+    acc = (one["status"] == 0) & (o64["status"] == 0)
+    e, _ = per_problem_err({k: one[k][..., acc] for k in ("X_optm", "U_optm", "dU_optm")},
+                           {k: o64[k][..., acc] for k in ("X_optm", "U_optm", "dU_optm")})
+    assert e.max() < TOL_MIXED, e.max()
+    # the second pass writes the fp64 answers over the marked problems: bit-identical to the fp64 entry
+    for k in ("X_optm", "U_optm", "dU_optm"):
+        assert np.array_equal(two[k][..., marked], o64[k][..., marked]), k
 
 
 @pytest.mark.parametrize("mixed", [False, True])

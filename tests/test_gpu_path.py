@@ -5,7 +5,7 @@ import pytest
 from conftest import scaled_err
 from oracle import cbind, dynamics as D, params as P, qp as Q, scenario as S
 from parity import assert_contract, assert_same_iterations, dense_reference, per_problem_err
-from tolerances import TOL_DEGENERATE, TOL_DU, TOL_LINEARIZE_REL, TOL_MEDIAN, TOL_TWIN, TOL_XU
+from tolerances import TOL_DU, TOL_F32, TOL_LINEARIZE_REL, TOL_MEDIAN, TOL_TWIN, TOL_XU
 
 pytestmark = pytest.mark.gpu
 
@@ -138,7 +138,7 @@ def test_full_batch_properties(pkg):
     same = (twin["status"] == 0) & ok[:128]
     assert_same_iterations(o["iters"][:128][same], twin["iters"][same])
     et = np.abs((X[:, :, :128] - twin["X_optm"]) / P.SCALE_X[:, None, None]).max(axis=(0, 1))[same]
-    assert np.percentile(et, 95) < TOL_TWIN and et.max() < TOL_DEGENERATE
+    assert et.max() < TOL_TWIN, et.max()
 
 
 def test_infeasible_initial_state_and_determinism(pkg):
@@ -427,7 +427,7 @@ def test_randomised_configurations_against_the_dense_optimum(pkg, seed):
         strict.append(bool(info.get("polished")) and Q.strict_complementarity(qp, yex, info["lam"]) >= Q.DEGENERATE_MARGIN)
     assert n_dense_ok >= B // 2, n_dense_ok
     per, strict = np.array(per), np.array(strict)
-    assert strict.sum() >= 4 and per[strict].max() < TOL_XU and per.max() < TOL_DEGENERATE, (per[strict].max(), per.max())
+    assert strict.sum() >= 4 and per.max() < TOL_XU, (per[strict].max(), per.max())   # (degenerate or not: all of them)
 
 
 @pytest.mark.parametrize("seed", [0, 1, 2])
@@ -474,9 +474,7 @@ def test_lmpc_randomised_configurations_against_the_dense_optimum(pkg, seed):
     assert n_ok >= 8, n_ok
     per, strict = np.array(per), np.array(strict)
     print("lmpc randomised: strict", strict.mean(), "worst strict", per[strict].max() if strict.any() else None, "worst", per.max())
-    # (the learning problem's simplex rows carry a proximal floor in the Newton matrix, csrc TH_L_MIN: measured worst
-    #  strict problem 1.1e-6 over these configurations, so twice the tracking bound)
-    assert (not strict.any() or per[strict].max() < 2 * TOL_XU) and per.max() < TOL_DEGENERATE, sorted(per)[-4:]
+    assert per.max() < TOL_XU, sorted(per)[-4:]
 
 
 def test_full_dynamics_sqp_reaches_kkt_points_of_the_nlp(pkg):
@@ -594,7 +592,7 @@ def test_longer_horizons_match_the_twin(pkg, N):
     ok = (out["status"] == 0) & (twin["status"] == 0)
     assert_same_iterations(out["iters"][ok], twin["iters"][ok])
     e = np.abs((out["X_optm"] - twin["X_optm"]) / P.SCALE_X[:, None, None]).max(axis=(0, 1))[ok]
-    assert np.percentile(e, 95) < TOL_TWIN and e.max() < TOL_DEGENERATE
+    assert e.max() < TOL_TWIN, e.max()
     # dynamics rows hold exactly along the whole horizon
     A, Bm, g = (t.cpu().numpy() for t in solver.linearize(inp))
     X, U = out["X_optm"], out["U_optm"]
@@ -619,7 +617,7 @@ def test_horizons_at_the_row_layout_boundaries_match_the_twin(pkg, N):
     ok = (out["status"] == 0) & (twin["status"] == 0)
     assert_same_iterations(out["iters"][ok], twin["iters"][ok])
     e = np.abs((out["X_optm"] - twin["X_optm"]) / P.SCALE_X[:, None, None]).max(axis=(0, 1))[ok]
-    assert np.percentile(e, 90) < TOL_TWIN and e.max() < TOL_DEGENERATE
+    assert e.max() < TOL_TWIN, e.max()
     assert np.array_equal(out["X_optm"][:, 0, :], inp["x_ic"])          # x_0 = x_ic (racing_mpc.cpp:200-201)
 
 
@@ -647,13 +645,13 @@ def test_lmpc_at_other_horizons_matches_the_twin(pkg, N, n_laps):
     assert (o["status"] == twin["status"]).all() and (o["status"] == 0).all(), (o["status"], twin["status"])
     ok = o["status"] == 0
     # (the wave sums of the terminal block run in a different order than the twin's serial loops: at the accuracy floor
-    #  the stopping rules can fire an iteration or two apart on an odd problem)
-    assert np.abs(o["iters"][ok] - twin["iters"][ok]).max() <= 2 and (o["iters"][ok] == twin["iters"][ok]).mean() >= 0.8
+    #  the stopping rules -- and the acceptance of a polish attempt -- can fall differently on an odd problem)
+    d = np.abs(o["iters"][ok] - twin["iters"][ok])
+    assert d.max() <= 8 and (d <= 1).mean() >= 0.9 and (d == 0).mean() >= 0.8, d
     e = np.abs((o["X_optm"] - twin["X_optm"]) / P.SCALE_X[:, None, None]).max(axis=(0, 1))[ok]
-    # The learning cost has no tracking terms, so the optimum is flat in more directions than the tracking problem's:
-    # kernel and twin agree to 1e-8 in the median and sit up to a few 1e-6 apart on the flattest problems; both are
-    # within 2e-9 of the DENSE optimum where that was computed (test_lmpc_at_long_horizons_against_the_dense_optimum).
-    assert np.median(e) < 1e-6 and np.percentile(e, 90) < 5 * TOL_TWIN and e.max() < TOL_DEGENERATE, (np.median(e), np.percentile(e, 90), e.max())
+    # (the learning cost has no tracking terms, so the optimum is flat in more directions than the tracking problem's: until
+    #  the polish kernel and twin sat up to a few 1e-6 apart on the flattest problems)
+    assert np.median(e) < 1e-8 and e.max() < TOL_TWIN, (np.median(e), np.percentile(e, 90), e.max())
     lam = o["convex_combi_optm"][:, ok]
     assert np.abs(lam.sum(0) - 1.0).max() < 1e-8 and lam.min() > -1e-10
 
@@ -675,7 +673,7 @@ def test_single_precision_solve_on_the_iac_problem(pkg, golden):
     ok = (o64["status"] == 0) & (o32["status"] == 0)
     assert ok.mean() > 0.995 and ((o32["status"] == 0) | (o64["status"] != 0)).mean() > 0.998
     e = np.abs((o32["X_optm"].astype(np.float64) - o64["X_optm"]) / P.SCALE_X[:, None, None]).max(axis=(0, 1))[ok]
-    assert np.median(e) < 1e-4 and np.percentile(e, 99) < 2e-3 and e.max() < 5e-2
+    assert np.median(e) < 1e-5 and np.percentile(e, 99) < 1e-4 and e.max() < TOL_F32, (np.median(e), np.percentile(e, 99), e.max())
     # the abscissa keeps its resolution on a 2.8 km lap (carried relative to x_ic inside the kernel)
     assert np.abs(o32["X_optm"][0, 0] - inp["x_ic"][0].cpu().numpy().astype(np.float32)).max() == 0.0
     # rows of the QP hold to single precision
@@ -701,7 +699,7 @@ def test_mixed_precision_solve_on_the_iac_problem(pkg, golden):
     ok = (o64["status"] == 0) & (om["status"] == 0)
     assert ok.mean() > 0.995 and ((om["status"] == 0) | (o64["status"] != 0)).mean() > 0.998
     e = np.abs((om["X_optm"] - o64["X_optm"]) / P.SCALE_X[:, None, None]).max(axis=(0, 1))[ok]
-    assert np.median(e) < 1e-4 and np.percentile(e, 99) < 2e-3 and e.max() < 5e-2
+    assert np.median(e) < 1e-5 and np.percentile(e, 99) < 1e-4 and e.max() < TOL_F32, (np.median(e), np.percentile(e, 99), e.max())
     assert np.array_equal(om["X_optm"][0, 0], inp["x_ic"][0].cpu().numpy())  # x_0 = x_ic exactly, abscissa included
 
     # the horizon iac_car_tracking_mpc.param.yaml ships (N = 80: the KQ = 14 row layout in single precision)
@@ -712,7 +710,7 @@ def test_mixed_precision_solve_on_the_iac_problem(pkg, golden):
     ok = (o64["status"] == 0) & (om["status"] == 0)
     assert ok.mean() > 0.99
     e = np.abs((om["X_optm"] - o64["X_optm"]) / P.SCALE_X[:, None, None]).max(axis=(0, 1))[ok]
-    assert np.median(e) < 1e-4 and np.percentile(e, 99) < 5e-3 and e.max() < 5e-2
+    assert np.median(e) < 1e-5 and np.percentile(e, 99) < 1e-4 and e.max() < TOL_F32, (np.median(e), np.percentile(e, 99), e.max())
 
     # the learning problem is served up to N = 23 (tests/test_gpu_mixed_lmpc.py); its long horizons have no mixed kernel
     lm = pkg.Solver(pkg.presets.barc_lmpc(40, 3), pkg.presets.barc_vehicle(), device=0)
@@ -890,12 +888,11 @@ def test_lmpc_at_long_horizons_against_the_dense_optimum(pkg, N, n_laps, n_dense
     assert (o["status"] == 0).all(), o["status"]
     sample = list(range(0, B, B // n_dense))[:n_dense]
     ref, margin, certified, _, _ = dense_reference(cfg, veh, inp, sample, ss_x.cpu().numpy(), ss_j.cpu().numpy())
-    # (the learning cost has no tracking terms: most of these optima have a strict-complementarity margin below 1e-4 or an
-    #  active-set polish that was not accepted, so they are held to the degenerate bound; the strict ones to 1e-6)
+    # (the learning cost has no tracking terms: most of these optima have a strict-complementarity margin below 1e-4 or a
+    #  dense active-set polish that was not accepted -- held to 1e-6 all the same)
     exu, ed = per_problem_err({k: o[k][..., sample] for k in ("X_optm", "U_optm", "dU_optm")}, ref)
     strict = (margin >= Q.DEGENERATE_MARGIN) & certified
-    assert (exu[strict] < TOL_XU).all() and (exu[~strict] < TOL_DEGENERATE).all(), (exu, margin, certified)
-    assert (ed[strict] < TOL_DU).all() and (ed[~strict] < 40 * TOL_DEGENERATE).all(), (ed, margin)
+    assert (exu < TOL_XU).all() and (ed < TOL_DU).all(), (exu, ed, margin, certified)
     print("N = %d: %d dense optima, %d strict, worst strict %.1e, worst degenerate %.1e" % (
         N, n_dense, strict.sum(), exu[strict].max() if strict.any() else 0.0, exu[~strict].max() if (~strict).any() else 0.0))
 

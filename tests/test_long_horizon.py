@@ -55,8 +55,8 @@ def test_twin_solves_every_problem_the_dense_solver_solves(pkg, golden, N):
 @pytest.mark.gpu
 @pytest.mark.parametrize("N", HORIZONS)
 def test_kernel_meets_the_contract_on_unclipped_long_horizons(pkg, golden, N):
-    """Status 0 on every problem, 1e-6 against the DENSE optimum wherever the dense multipliers are strictly
-    complementary, the relaxed bound only where the oracle says degenerate."""
+    """Status 0 on every problem and 1e-6 against the DENSE optimum on every problem (a quarter to a third of these are
+    degenerate by the oracle's margin: the polish makes no difference between them and the strict ones)."""
     g = golden(f"qp_barc_tracking_long_n{N}")
     solver = pkg.Solver(pkg.presets.barc_tracking_mpc(N), pkg.presets.barc_vehicle(), device=0)
     out = {k: v.cpu().numpy() for k, v in solver.solve(g).items() if hasattr(v, "cpu")}
@@ -111,7 +111,7 @@ def _iac_lmpc_check(out, g, who):
     e, ed = per_problem_err(out, g)
     st = np.asarray(out["status"])
     assert (st == 0).all(), (who, st)
-    assert e.max() < TOL_XU and ed.max() < 40 * TOL_XU, (who, e, ed)      # degenerate or not: all of them
+    assert e.max() < TOL_XU and ed.max() < TOL_XU, (who, e, ed)      # degenerate or not: all of them
     lam = np.asarray(out["convex_combi_optm"])
     assert np.abs(lam.sum(0) - 1.0).max() < 1e-9 and lam.min() > -1e-12
     assert np.asarray(out["iters"]).max() <= 20
