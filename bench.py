@@ -67,7 +67,7 @@ def live_traffic_bytes(workload_argv, kernel):
             for counter in ("FETCH_SIZE", "WRITE_SIZE"):
                 out = os.path.join(d, counter)
                 cmd = [exe, "--pmc", counter, "-d", out, "-o", "run", "--", sys.executable, str(ROOT / "bench.py"), "--steps", "5",
-                       "--warmup", "1", "--no-cpu-baseline", "--no-batch1", "--streams", "1", "--no-pmc"] + workload_argv
+                       "--warmup", "1", "--no-cpu-baseline", "--no-batch1", "--no-others", "--streams", "1", "--no-pmc"] + workload_argv
                 proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
                 try:
                     proc.wait(timeout=90)
@@ -194,8 +194,9 @@ def cpu_baseline(pkg, N, batch):
                                          ptr(status), ptr(iters), ptr(kkt))
         assert rc == 0, rc
 
+    solve_range(0, per_thread)          # cold: page faults of the work area, instruction cache
     t0 = time.perf_counter()
-    solve_range(0, per_thread)
+    solve_range(0, per_thread)          # the figure quoted: a warm call
     per = (time.perf_counter() - t0) / per_thread
     def run(reps):
         def work(c):
@@ -211,9 +212,38 @@ def cpu_baseline(pkg, N, batch):
     dt = run(reps)
     assert (status == 0).mean() > 0.99
     return {"value": reps * B / dt, "unit": "solves/s", "cores": cores, "kind": "port",
-            "single_thread_solve_ms": per * 1e3,   # one thread, one problem at a time (the first 32 problems, untimed cores idle)
+            "single_thread_solve_ms": per * 1e3,   # one thread, one problem at a time (the first 32 problems, second call, other cores idle)
             "sample": f"{reps} x {B} problems of the bench workload ({per_thread} per thread per call), static split "
                       f"over {cores} host threads = usable cores (affinity mask capped by the cgroup CPU quota; os.cpu_count() = {os.cpu_count()}) (one C call per slice, shared preallocated arrays), oracle/c/lmpc_oracle.c -O3 ({dt:.1f} s wall)"}
+
+
+def other_configs(steps, warmup):
+    """The other BASELINE configs, each as a short leg of this same script in a child process (own handles, streams and
+    buffers; --no-pmc, no CPU leg): configs[2] as quoted, and the per-GPU shares of the two 8-GPU configs.  Every entry
+    carries what the headline carries: ms_per_step (pipelined), ms_per_step_one_stream, kernels_ms, roofline."""
+    import subprocess
+    legs = [("configs[2]", ["--workload", "lmpc", "--batch", "4096", "--horizon", "20"]),
+            ("configs[3], share of one GPU (8192 of 65536)", ["--workload", "iac", "--horizon", "40", "--batch", "8192", "--precision", "f32"]),
+            ("configs[4], share of one GPU (32768 of 262144)", ["--workload", "lmpc", "--batch", "32768", "--horizon", "20", "--precision", "mixed", "--regression"])]
+    keep = ("metric", "value", "unit", "ms_per_step", "ms_per_step_one_stream", "value_one_stream", "dtype", "config", "kernels_ms",
+            "solved_fraction", "mean_ipm_iters", "p50_solve_ms", "p99_solve_ms", "ss_query_kernel")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = []
+    for name, argv in legs:
+        cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", "1", "--steps", str(max(5, min(steps, 20))), "--warmup", str(max(1, min(warmup, 3))),
+               "--no-cpu-baseline", "--no-pmc", "--no-batch1", "--no-others"] + argv
+        try:
+            r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+            line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+            j = json.loads(line)
+            e = {"baseline_config": name, **{k: j.get(k) for k in keep if k in j}}
+            e["config"] = {k: v for k, v in (j.get("config") or {}).items() if k != "ranks_seen"}
+            rf = j.get("roofline") or {}
+            e["roofline"] = {k: rf.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_solve")}
+            out.append(e)
+        except Exception as ex:  # a failed leg is reported, not hidden
+            out.append({"baseline_config": name, "error": "%s: %s" % (type(ex).__name__, str(ex)[:300])})
+    return out
 
 
 def main():
@@ -246,6 +276,12 @@ def main():
                     "traffic (N = 1 only, ~30 s); roofline.traffic then comes from the committed passes in profiles/")
     ap.add_argument("--no-batch1", action="store_true", help="skip the single-car latency probe (profiling runs: keeps every "
                                                              "launch of the QP kernel at the bench batch size)")
+    ap.add_argument("--output-layout", choices=["soa", "aos"], default="soa", help="result arrays [component][knot][batch] (default, what the "
+                    "batch-parallel consumers read) or [batch][knot][component] (lmpc_set_output_layout: full-line stores; never the headline)")
+    ap.add_argument("--no-latency", action="store_true", help="skip the per-call latency loop (counter passes: every launch of the QP "
+                    "kernel is then one of the timed steps; kernels_ms comes from 20 calls)")
+    ap.add_argument("--no-others", action="store_true", help="default run only: skip the short legs on the other BASELINE configs "
+                    "(configs[2], the per-GPU shares of configs[3] and configs[4]) that are reported under `others`")
     args = ap.parse_args()
 
     # --gpus is authoritative.  Under a launcher (WORLD_SIZE set) it must agree with the world the launcher made; started
@@ -344,6 +380,14 @@ def main():
         u_hi = [min(P["u_max"][0], 0.015), min(P["u_max"][1], 0.314159)]
         x, u = pkg.workloads.sample_initial_states("barc", B, tr["L"], u_lo, u_hi, seed=rank)
     solver.reserve(B)
+    if args.output_layout == "aos":
+        assert world == 1 and not f32, "--output-layout aos: single GPU, fp64 arrays (the gather packs the default layout)"
+        _mk = make_solver
+        def make_solver():  # noqa: E306
+            sv = _mk()
+            sv.set_output_layout("aos")
+            return sv
+        solver.set_output_layout("aos")
     inp = solver.prepare(tr, x.T.copy(), 0.025)   # node cold start on the device (racing_mpc_node.cpp:210-292)
     inp["u_ic"] = torch.as_tensor(u.T.copy(), dtype=torch.float64, device=dev)
     S = max(1, args.streams)
@@ -457,7 +501,7 @@ def main():
     if rank == 0:
         solver.enable_timing(True)
         # p99 over >= 1000 timed calls (bounded to ~3 s of GPU time for the big batches)
-        n_lat = int(max(100, min(1000, 3.0 / max(elapsed / args.steps, 1e-4))))
+        n_lat = 20 if args.no_latency else int(max(100, min(1000, 3.0 / max(elapsed / args.steps, 1e-4))))
         for k in range(n_lat):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -529,14 +573,17 @@ def main():
                                    + (" -- mixed precision: fp32 Riccati / interior point between fp64 arrays (BASELINE configs[4])" if mixed else "")
                                    + (" -- error-dynamics regression on: %d recorded sample pairs, every stage regressed before its QP" % len(reg_laps)
                                       if (lmpc and reg_laps) else ""),
-                       "batch_per_gpu": B, "horizon": N, "streams": S,
+                       "batch_per_gpu": B, "horizon": N, "streams": S, "output_layout": args.output_layout,
                        "launch_order": ("longest first by the previous solve's iteration counts of the SAME batch (perfect foresight here)"
                                         if orders else "default"), "result_gather": "rccl all_gather (async)" if gather else "none",
                        "ranks_seen": ranks_seen},
             "p50_solve_ms": float(np.percentile(lat, 50)), "p99_solve_ms": float(np.percentile(lat, 99)),
             "latency_samples": len(lat), "value_one_stream": one_stream_value,
+            # one batch at a time: the figure that reconciles with kernels_ms and the rocprofv3 summaries (the headline
+            # ms_per_step overlaps consecutive batches on `streams` HIP streams, so it can sit below one kernel's duration)
+            "ms_per_step_one_stream": (B / one_stream_value * 1e3) if one_stream_value else elapsed / args.steps * 1e3,
             "batch1_solve_ms": {"p50": float(np.percentile(lat1, 50)), "p99": float(np.percentile(lat1, 99)), "control_period_ms": 25.0} if lat1 else None,
-            "solved_fraction": float((st == 0).mean()), "mean_ipm_iters": float(iters.mean()),
+            "solved_fraction": float((st == 0).mean()), "mean_ipm_iters": float(iters.mean()),  # (interior-point iterations + polish rounds)
             "kernels_ms": {"linearize": float(np.mean(lin_ms)), "qp_solve": sol_avg,
                            **({"ss_query": float(np.mean(ss_ms))} if ss_ms else {})},
             "launch": ({**solver.launch_info(), "lds_bytes_per_problem": solver.launch_info()["lds_bytes_per_problem"] // 2,
@@ -560,6 +607,9 @@ def main():
                                       "note": "one wave per query: 3n distances per lap in LDS, K rounds of a wave-wide arg-min per lap"}
         if not args.no_cpu_baseline and world == 1 and not lmpc and not iac:
             res["cpu_baseline"] = cpu_baseline(pkg, N, B)
+        default_run = (world == 1 and not lmpc and not iac and not f32 and not mixed and N == 20 and B == 4096)
+        if default_run and not args.no_others:
+            res["others"] = other_configs(args.steps, args.warmup)
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()

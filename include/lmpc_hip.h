@@ -329,6 +329,16 @@ int lmpc_shift_batch(lmpc_handle* h, int32_t batch, const lmpc_track* track, con
 int lmpc_plant_step_batch(lmpc_handle* h, int32_t batch, const lmpc_track* track, double* x,
                           const double* u, double dt_sim, int32_t n_sub);
 
+/* Layout of the RESULT arrays X_optm, U_optm, dU_optm of the lmpc_solve_batch* entry points (inputs, status, iters, kkt
+ * and convex_combi_optm are not affected).  LMPC_LAYOUT_SOA (default): [component][knot][batch], what batch-parallel
+ * consumers (lmpc_shift_batch, lmpc_plant_step_batch, a result gather) read coalesced.  LMPC_LAYOUT_AOS: [batch][knot]
+ * [component] -- per problem the reference's own DM layout (column-major 6 x N, 2 x (N-1); racing_mpc.cpp:347-349), for a
+ * consumer that takes one problem's plan at a time; one wavefront's 196 results then leave as full cache lines instead of
+ * eight-byte stores at stride B (measured HBM write traffic of the QP kernel: profiles/r03_*). */
+#define LMPC_LAYOUT_SOA 0
+#define LMPC_LAYOUT_AOS 1
+int lmpc_set_output_layout(lmpc_handle* h, int32_t layout);
+
 /* Grow the handle's device workspace (stage linearisations, 432 B per stage per problem) so
  * that no later *_batch call with batch <= max_batch allocates. */
 int lmpc_reserve(lmpc_handle* h, int32_t max_batch);

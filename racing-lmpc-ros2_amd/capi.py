@@ -20,7 +20,7 @@ _ABI_SYMBOLS = ("lmpc_create", "lmpc_destroy", "lmpc_last_error", "lmpc_set_stre
                 "lmpc_prepare_batch", "lmpc_reserve", "lmpc_query_launch", "lmpc_enable_timing",
                 "lmpc_last_kernel_ms", "lmpc_query_residency", "lmpc_solve_host", "lmpc_shift_batch",
                 "lmpc_plant_step_batch", "lmpc_solve_full_dynamics_batch", "lmpc_solve_full_dynamics_host", "lmpc_set_regression_laps", "lmpc_regress_batch", "lmpc_ss_query_host", "lmpc_solve_batch_f32",
-                "lmpc_solve_batch_mixed", "lmpc_prepare_failed_batch", "lmpc_set_launch_order", "lmpc_launch_order_from_iters")
+                "lmpc_solve_batch_mixed", "lmpc_prepare_failed_batch", "lmpc_set_launch_order", "lmpc_launch_order_from_iters", "lmpc_set_output_layout")
 
 
 class LmpcError(RuntimeError):
@@ -81,7 +81,9 @@ def _fill(struct, values: dict):
 
 
 def library_path() -> Path:
-    return _HERE / "lib" / "liblmpc_hip.so"
+    """The built library; LMPC_HIP_LIBRARY names another build of it (A/B timing of a variant, scratch/)."""
+    import os
+    return Path(os.environ["LMPC_HIP_LIBRARY"]) if os.environ.get("LMPC_HIP_LIBRARY") else _HERE / "lib" / "liblmpc_hip.so"
 
 
 def load_library():
@@ -259,6 +261,12 @@ class Solver:
         self._check(rc, "lmpc_shift_batch")
         return out
 
+    def set_output_layout(self, layout: str = "soa"):
+        """"soa": results [component][knot][batch] (default); "aos": [batch][knot][component] (include/lmpc_hip.h).  The caller
+        passes result tensors of the matching shape (alloc_outputs follows the setting)."""
+        self._aos = {"soa": False, "aos": True}[layout]
+        self._check(self.lib.lmpc_set_output_layout(self._h, C.c_int32(int(self._aos))), "lmpc_set_output_layout")
+
     # ---- launch order (longest job first; include/lmpc_hip.h) ----
     def set_launch_order(self, order):
         """order: int32 device tensor [batch] (kept alive here; applies to solves of that batch size) or None for the default mapping."""
@@ -306,8 +314,9 @@ class Solver:
         torch = self._torch
         N = self.N
         kw = dict(dtype=torch.float64, device=self.device)
-        return {"X_optm": torch.empty((6, N, B), **kw), "U_optm": torch.empty((2, N - 1, B), **kw),
-                "dU_optm": torch.empty((2, N - 1, B), **kw),
+        shapes = ((B, N, 6), (B, N - 1, 2)) if getattr(self, "_aos", False) else ((6, N, B), (2, N - 1, B))
+        return {"X_optm": torch.empty(shapes[0], **kw), "U_optm": torch.empty(shapes[1], **kw),
+                "dU_optm": torch.empty(shapes[1], **kw),
                 "status": torch.empty((B,), dtype=torch.int32, device=self.device),
                 "iters": torch.empty((B,), dtype=torch.int32, device=self.device),
                 "kkt": torch.empty((4, B), **kw)}

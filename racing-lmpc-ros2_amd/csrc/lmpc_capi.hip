@@ -52,6 +52,7 @@ struct lmpc_handle {
   int order_n = 0;
   double* ws = nullptr;  // [cap][N-1][LMPC_LIN_RECORD]
   int* unverified = nullptr;  // [cap + 1]: the problems a mixed first pass could not verify, and their number
+  double* save = nullptr;     // [cap][10 N - 4]: the polish's save area
   size_t ws_cap = 0;
   float* ws_f32 = nullptr;  // the same for the single-precision solve
   size_t ws_f32_cap = 0;
@@ -340,6 +341,7 @@ void lmpc_destroy(lmpc_handle* h) {
   (void)hipStreamSynchronize(h->stream);
   if (h->ws) (void)hipFree(h->ws);
   if (h->unverified) (void)hipFree(h->unverified);
+  if (h->save) (void)hipFree(h->save);
   if (h->ws_f32) (void)hipFree(h->ws_f32);
   if (h->ss_npts) (void)hipFree(h->ss_npts);
   if (h->ss_off) (void)hipFree(h->ss_off);
@@ -390,6 +392,10 @@ int lmpc_reserve(lmpc_handle* h, int32_t max_batch) {
   if (h->unverified) HIP_TRY(h, hipFree(h->unverified));
   h->unverified = nullptr;
   HIP_TRY(h, hipMalloc(&h->unverified, ((size_t)max_batch + 1) * sizeof(int)));
+  if (h->save) HIP_TRY(h, hipFree(h->save));
+  h->save = nullptr;
+  HIP_TRY(h, hipMalloc(&h->save, (size_t)max_batch * (10 * h->P.N - 4) * sizeof(double)));
+  h->P.save = h->save;
   h->ws_cap = (size_t)max_batch;
   return LMPC_OK;
 }
@@ -542,6 +548,10 @@ int lmpc_solve_batch_f32(lmpc_handle* h, int32_t batch, const float* x_ic, const
                    : kq == 14         ? reinterpret_cast<const void*>(&lmpc_solve_kernel<float, 14, 0, float>)
                                       : nullptr;
   if (!fn) return fail(h, LMPC_ERR_UNSUPPORTED, "no single-precision kernel for this N");
+  if ((size_t)batch > h->ws_cap) {  // (the polish's save area grows with the fp64 workspace)
+    const int rc = lmpc_reserve(h, batch);
+    if (rc != LMPC_OK) return rc;
+  }
   if ((size_t)batch > h->ws_f32_cap) {
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     if (h->ws_f32) HIP_TRY(h, hipFree(h->ws_f32));
@@ -1002,6 +1012,13 @@ int lmpc_set_regression_laps(lmpc_handle* h, int32_t n_laps, const int32_t* n_pt
   h->reg_total = (int)total;
   h->reg_spec = *spec;
   h->reg_on = true;
+  return LMPC_OK;
+}
+
+int lmpc_set_output_layout(lmpc_handle* h, int32_t layout) {
+  if (!h) return LMPC_ERR_ARGUMENT;
+  if (layout != LMPC_LAYOUT_SOA && layout != LMPC_LAYOUT_AOS) return fail(h, LMPC_ERR_ARGUMENT, "lmpc_set_output_layout: unknown layout");
+  h->P.out_aos = layout == LMPC_LAYOUT_AOS;
   return LMPC_OK;
 }
 

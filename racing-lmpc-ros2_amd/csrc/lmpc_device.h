@@ -7,6 +7,7 @@
 // Everything the kernels need from lmpc_config / lmpc_vehicle, pre-digested on the host
 // (lmpc_create).  Passed by value as a kernel argument (lands in the kernarg segment / SGPRs).
 struct lmpc_params {
+  void* save;  // device [batch][10 N - 4] doubles: where a polish attempt puts the iterate aside (handle-owned, lmpc_reserve)
   const int* launch_order;  // device [batch] or null: workgroup w solves problem launch_order[w] (set per launch by the host
                             // layer from lmpc_set_launch_order, only when the batch size matches the registered length)
   int N;          // knot points
@@ -32,7 +33,7 @@ struct lmpc_params {
   // two-pass mixed precision (set per launch by the host layer): the fp32 iteration marks a problem whose answer it could not
   // verify (polish refused) with LMPC_SOLVE_UNVERIFIED instead of OPTIMAL; lmpc_cleanup_kernel behind it solves those in fp64
   int flag_unverified;
-  int pad1;
+  int out_aos;  // lmpc_set_output_layout: results [batch][knot][component] instead of [component][knot][batch]
   lmpc_vehicle veh;
 };
 

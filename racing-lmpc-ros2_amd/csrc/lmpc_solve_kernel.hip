@@ -1496,29 +1496,38 @@ __device__ __forceinline__ void lmpc_solve_problem(
   const bool polish_on = LMPC_POLISH_BUILD && P.polish >= 0;
   bool polished = false, pol_early_done = false, reentry = false;
   int pol_rounds = 0;
-  // The iterate as it stands goes to the result arrays (the abscissa without the single-precision shift, so that it
-  // reads back exactly) and comes back from them when a polish round is over: nothing is held in registers for it, and
-  // every lane reads back what it wrote itself.
-  auto put_primal = [&](bool shifted) {
-    for (int e = lane; e < 6 * N; e += 64) {
-      const int k = e / N, i = e - k * N;
-      X_out[(size_t)(k * N + i) * B + b] = io(L.kn(i)[k]) + ((shifted && k == 0) ? s_shift : io(0));
-    }
-    for (int e = lane; e < 2 * NS; e += 64) {
-      const int k = e / NS, i = e - k * NS;
-      U_out[(size_t)(k * NS + i) * B + b] = io(L.kn(i + 1)[6 + k]);
-      dU_out[(size_t)(k * NS + i) * B + b] = io(L.kn(i)[8 + k]);
+  // A polish attempt puts the iterate aside in the handle's save area -- one contiguous block of 10 N - 4 values per problem
+  // (full-line writes; the strided result arrays would cost four times the traffic), values as they stand in LDS, so that
+  // they read back exactly -- and takes it back from there at the start of every round and when it is refused: nothing is
+  // held in registers for it, and every lane reads back what it wrote itself.
+  io* const keep = reinterpret_cast<io*>(P.save) + (size_t)b * (10 * N - 4);
+  auto put_primal = [&](bool final_) {
+    if (final_) {
+      // result layout by strides (lmpc_set_output_layout): [component][knot][batch] by default -- what batch-parallel consumers
+      // read coalesced -- or [batch][knot][component], one problem's plan contiguous (the reference's DM layout).  One code
+      // path: element (k, i) of problem b at k sk + i si + b sb.
+      const size_t xk = P.out_aos ? 1 : (size_t)N * B, xi = P.out_aos ? 6 : (size_t)B, xb = P.out_aos ? (size_t)6 * N : 1;
+      const size_t uk = P.out_aos ? 1 : (size_t)NS * B, ui = P.out_aos ? 2 : (size_t)B, ub = P.out_aos ? (size_t)2 * NS : 1;
+      for (int e = lane; e < 6 * N; e += 64) {
+        const int k = e / N, i = e - k * N;
+        X_out[k * xk + i * xi + b * xb] = io(L.kn(i)[k]) + (k == 0 ? s_shift : io(0));
+      }
+      for (int e = lane; e < 2 * NS; e += 64) {
+        const int k = e / NS, i = e - k * NS;
+        U_out[k * uk + i * ui + b * ub] = io(L.kn(i + 1)[6 + k]);
+        dU_out[k * uk + i * ui + b * ub] = io(L.kn(i)[8 + k]);
+      }
+    } else {
+      for (int e = lane; e < 10 * N - 4; e += 64) {  // knot i: z [8] (x_i, u_{i-1}) at 10 i - 2 .. (knot 0: x_0 only is not kept), v_i [2] behind it
+        const int i = (e + 2) / 10, o = e + 2 - 10 * i;
+        keep[e] = io(L.kn(i)[o]);
+      }
     }
   };
   auto get_primal = [&]() {
-    for (int e = lane; e < 6 * N; e += 64) {
-      const int k = e / N, i = e - k * N;
-      if (i >= 1) L.kn(i)[k] = real(X_out[(size_t)(k * N + i) * B + b]);
-    }
-    for (int e = lane; e < 2 * NS; e += 64) {
-      const int k = e / NS, i = e - k * NS;
-      L.kn(i + 1)[6 + k] = real(U_out[(size_t)(k * NS + i) * B + b]);
-      L.kn(i)[8 + k] = real(dU_out[(size_t)(k * NS + i) * B + b]);
+    for (int e = lane; e < 10 * N - 4; e += 64) {
+      const int i = (e + 2) / 10, o = e + 2 - 10 * i;
+      if (i >= 1 || o >= 8) L.kn(i)[o] = real(keep[e]);
     }
   };
 

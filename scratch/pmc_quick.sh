@@ -1,6 +1,6 @@
 export TMPDIR=/tmp; ROOT=$(pwd); OUT=$ROOT/gpurun_out/pmcq; rm -rf $OUT; mkdir -p $OUT; cd /tmp
-rocprofv3 --pmc FETCH_SIZE -d $OUT/p3 -o run -- python $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-batch1 --streams 1 > $OUT/p3.log 2>&1
-rocprofv3 --pmc WRITE_SIZE -d $OUT/p4 -o run -- python $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-batch1 --streams 1 > $OUT/p4.log 2>&1
+rocprofv3 --pmc FETCH_SIZE -d $OUT/p3 -o run -- python $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-batch1 --no-others --no-pmc --streams 1 > $OUT/p3.log 2>&1
+rocprofv3 --pmc WRITE_SIZE -d $OUT/p4 -o run -- python $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-batch1 --no-others --no-pmc --streams 1 > $OUT/p4.log 2>&1
 cd $ROOT
 python - <<'PY'
 import sqlite3

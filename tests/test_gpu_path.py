@@ -951,3 +951,18 @@ def test_launch_order_changes_the_schedule_not_the_answers(pkg):
     for k in ref:
         assert torch.equal(again[k], ref[k]) and torch.equal(rev[k], ref[k]), k
         assert torch.equal(small[k], ref[k][..., :7]), k
+
+
+def test_aos_result_layout_holds_the_same_numbers(pkg):
+    """lmpc_set_output_layout(LMPC_LAYOUT_AOS): per problem the reference's DM layout (column-major 6 x N) -- the same bits
+    as the default layout, transposed; status / iters / kkt are not affected."""
+    veh, cfg, solver, tr, x, u = make(pkg, "barc20", 333, 8)
+    inp = S.cold_start_inputs(cfg, veh, tr, x, u, 0.025)
+    soa = to_np(solver.solve(inp))
+    solver.set_output_layout("aos")
+    aos = to_np(solver.solve(inp))
+    solver.set_output_layout("soa")
+    assert aos["X_optm"].shape == (333, 20, 6) and aos["U_optm"].shape == (333, 19, 2)
+    for k in ("X_optm", "U_optm", "dU_optm"):
+        assert np.array_equal(aos[k].transpose(2, 1, 0), soa[k]), k
+    assert np.array_equal(aos["status"], soa["status"]) and np.array_equal(aos["iters"], soa["iters"])
