@@ -46,11 +46,19 @@ struct lmpc_params {
 #define LMPC_TERM_CELLS 236
 #define LMPC_LIN_RECORD 54  // per stage in the linearisation workspace: ABt[8][6] | g[6]
 
+// the lean layout (fp64, N > 40; lmpc_solve_kernel.hip): stage records without the stage model, which is streamed
+// through two chunk buffers of LMPC_LEAN_CHUNK workspace records
+#define LMPC_LEAN_STAGE_STRIDE 24
+#define LMPC_LEAN_CHUNK 8
+static inline int lmpc_is_lean(int N, int real_bytes) { return real_bytes == 8 && (11 * N + 63) / 64 > 7; }
+
 // LDS bytes per problem; real_bytes = 8 (fp64 records) or 4 (fp32 records: single-precision and mixed solves)
 static inline size_t lmpc_lds_bytes(int N, int learning, int S, int real_bytes) {
   const int ks = !learning ? 0 : (S <= 128 ? 2 : 3);
-  const size_t records = (size_t)((N - 1) * LMPC_STAGE_STRIDE + N * LMPC_KNOT_STRIDE + LMPC_TAIL_DOUBLES) * (size_t)real_bytes;
-  return records + (learning ? (size_t)(LMPC_TERM_CELLS + 6 * 64 * ks) * 8 : 0);
+  const int lean = lmpc_is_lean(N, real_bytes);
+  const size_t records = (size_t)((N - 1) * (lean ? LMPC_LEAN_STAGE_STRIDE : LMPC_STAGE_STRIDE) + N * LMPC_KNOT_STRIDE + LMPC_TAIL_DOUBLES) *
+                         (size_t)real_bytes;
+  return records + (learning ? (size_t)(LMPC_TERM_CELLS + 6 * 64 * ks) * 8 : 0) + (lean ? (size_t)2 * LMPC_LEAN_CHUNK * LMPC_LIN_RECORD * 8 : 0);
 }
 
 #endif

@@ -755,9 +755,62 @@ template <typename real>
 struct Lds {
   real* base;
   int N;
-  __device__ __forceinline__ real* st(int i) const { return base + i * LMPC_STAGE_STRIDE; }
-  __device__ __forceinline__ real* kn(int i) const { return base + (N - 1) * LMPC_STAGE_STRIDE + i * LMPC_KNOT_STRIDE; }
-  __device__ __forceinline__ real* tail() const { return base + (N - 1) * LMPC_STAGE_STRIDE + N * LMPC_KNOT_STRIDE; }
+  int stride;  // of a stage record: LMPC_STAGE_STRIDE, or LMPC_LEAN_STAGE_STRIDE in the lean layout (below)
+  __device__ __forceinline__ real* st(int i) const { return base + i * stride; }
+  __device__ __forceinline__ real* kn(int i) const { return base + (N - 1) * stride + i * LMPC_KNOT_STRIDE; }
+  __device__ __forceinline__ real* tail() const { return base + (N - 1) * stride + N * LMPC_KNOT_STRIDE; }
+};
+
+// ---- the LEAN layout (fp64, N > 40) -----------------------------------------------------------------------------------
+// At long horizons the stage records are what limits residency: 78 doubles per stage, 48 of them the stage model [A B],
+// which the iteration only reads.  The lean layout keeps the model OUT of the records: every sweep streams it from the
+// linearisation workspace (L2 / MALL resident, written by lmpc_linearize_kernel just before) through two chunk buffers of
+// LN_CHUNK stages each, filled by asynchronous global -> LDS copies (global_load_lds_dwordx4: no registers, no ds_write)
+// one chunk ahead of the sweep.  A stage record shrinks to what the factorisation produces:
+//     K_j[c] @ 2 c + j (c < 8) | Hinv (h00, h01) @16, h11 @18 | dt @19 | kff rhs0 [2] @20 | kff rhs1 [2] @22        (24)
+// and a chunk slot holds the workspace record as it is: ABt[8][6] (row c of it = column c of [A B]: the rows the backward
+// sweeps read are contiguous 48-byte runs on distinct banks, the columns the forward sweep reads are stride-6) | g [6].
+// N = 60: 57 KB -> 38 KB per problem, 2 -> 4 resident problems per CU (the register file allows no more); N = 80: 2 -> 3.
+#define LN_CHUNK 8
+#define LN_REC LMPC_LIN_RECORD
+#define LN_HI 16
+#define LN_HI11 18
+#define LN_DT 19
+#define LN_KFF(s) ((s) ? 22 : 20)
+constexpr bool lmpc_lean(int real_bytes, int kq) { return real_bytes == 8 && kq >= 11; }
+template <typename real>
+struct ModelStream {
+  const real* ws;  // this problem's [N - 1][LN_REC] in the workspace (HBM / L2)
+  real* buf;       // LDS: 2 chunks of LN_CHUNK records
+  int NS, lane;
+  int have0 = -1, have1 = -1;  // the chunk each buffer holds (or is being filled with): a sweep that finds its first chunks
+                               // resident -- the forward sweep after a backward one, the factorisation after a forward sweep --
+                               // starts without a fetch
+  __device__ __forceinline__ void ensure(int ch) {
+    if ((ch & 1 ? have1 : have0) != ch) fetch(ch);
+  }
+  // chunk ch -> buffer (ch & 1), asynchronously: 16 bytes per lane per instruction, the wave's lanes in address order
+  __device__ __forceinline__ void fetch(int ch) {
+    if (ch & 1) have1 = ch; else have0 = ch;
+    const int lo = ch * LN_CHUNK * LN_REC;
+    const int n = min(LN_CHUNK * LN_REC, NS * LN_REC - lo);
+    real* const dst = buf + (ch & 1) * LN_CHUNK * LN_REC;
+#pragma unroll
+    for (int j = 0; j < (LN_CHUNK * LN_REC + 127) / 128; ++j) {
+      const int e = 128 * j + 2 * lane;
+      if (e < n)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ws + lo + e),
+                                         (__attribute__((address_space(3))) void*)(dst + 128 * j), 16, 0, 0);
+    }
+  }
+  // every copy issued so far has landed (vmcnt counts them), and no later LDS read moves ahead of this point
+  __device__ __forceinline__ void wait() const {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wave_fence();
+  }
+  __device__ __forceinline__ const real* stage(int i) const {
+    return buf + ((i / LN_CHUNK) & 1) * LN_CHUNK * LN_REC + (i % LN_CHUNK) * LN_REC;
+  }
 };
 
 // true cost Hessian entry on z_i (no barrier terms), racing_mpc.cpp:459-476; terminal knot or a knot 1 <= i <= N-2
@@ -794,7 +847,7 @@ __device__ __forceinline__ real qz_entry(const real* ct, bool terminal, int r, i
 // Phi has no identity block), so the iteration uses it only once mu <= JOSEPH_MU: about two factorisations per solve.
 #define JOSEPH_MU 1e-8
 template <bool HAS_PT, bool JOSEPH, typename real, typename ptreal>
-__device__ void riccati_factor(const Lds<real>& L, int lane, const ptreal* PT) {
+__device__ __forceinline__ void riccati_factor(const Lds<real>& L, int lane, const ptreal* PT) {
   const int N = L.N, r = lane >> 3, c = lane & 7;
   real* T = L.tail();
   real* MP = T + TL_P;
@@ -1005,7 +1058,7 @@ __device__ __forceinline__ void row_bcast67(real v, real& a, real& b) {  // lane
 // for the condensed 2-vector; ~400 cycles per stage under load).  Stage operands are fetched one stage ahead; the
 // results a stage leaves behind (kff, dz, dv) are stored off the chain.
 template <int NRHS, typename real>
-__device__ void riccati_solve(const Lds<real>& L, int lane, Prof& pf) {
+__device__ __forceinline__ void riccati_solve(const Lds<real>& L, int lane, Prof& pf) {
   const int N = L.N;
   const int r = lane & 7, s = (lane >> 4) & (NRHS - 1);
   const bool own = (lane & 8) == 0 && lane < 16 * NRHS;
@@ -1095,7 +1148,7 @@ __device__ void riccati_solve(const Lds<real>& L, int lane, Prof& pf) {
 // The same solve with the running vector exchanged through LDS (what riccati_solve did until round 2): the form the
 // one-wave-per-SIMD instantiations keep (see the call site).
 template <int NRHS, typename real>
-__device__ void riccati_solve_lds(const Lds<real>& L, int lane, Prof& pf) {
+__device__ __forceinline__ void riccati_solve_lds(const Lds<real>& L, int lane, Prof& pf) {
   const int N = L.N;
   const int r = lane & 7, s = (lane >> 3) & (NRHS - 1);
   const bool own = lane < 8 * NRHS;
@@ -1211,7 +1264,7 @@ __device__ void riccati_solve_lds(const Lds<real>& L, int lane, Prof& pf) {
 // the start trajectory is generated under the stabilising Riccati feedback.  Same lane roles as the
 // forward sweep of riccati_solve.
 template <typename real>
-__device__ void feedback_rollout(const Lds<real>& L, int lane) {
+__device__ __forceinline__ void feedback_rollout(const Lds<real>& L, int lane) {
   const int N = L.N, r = lane & 7;
   const bool own = lane < 8;
   real* T = L.tail();
@@ -1243,6 +1296,359 @@ __device__ void feedback_rollout(const Lds<real>& L, int lane) {
   }
 }
 
+// ---- the sweeps of the lean layout: the same arithmetic, stage by stage, with the stage model read from the chunk slots
+// ---- of a ModelStream and K / Hinv / kff in the 24-cell records -------------------------------------------------------
+// Streaming discipline of a sweep that walks the stages downwards (factor, backward vector sweep): the chunk it starts in
+// is fetched and waited for, the one below it is fetched at once; the stage that reads ahead into the next chunk waits for
+// it first and, the chunk just left being dead by then, fetches the one after into its buffer.  Upwards (forward sweep,
+// rollout) the mirror image.  One fetch is in flight at a time; a chunk is 8 stages of work ahead of its first use.
+template <bool HAS_PT, bool JOSEPH, typename real, typename ptreal>
+__device__ __forceinline__ void riccati_factor_lean(const Lds<real>& L, ModelStream<real>& M, int lane, const ptreal* PT) {
+  const int N = L.N, r = lane >> 3, c = lane & 7;
+  real* T = L.tail();
+  real* MP = T + TL_P;
+  real* MW = T + TL_W;
+  real* MY = T + TL_Y;
+  const real* ct = T + TL_CT;
+  const bool diag = r == c;
+  const real m_diag = diag ? real(1) : real(0), m_r1 = r == 1 ? real(1) : real(0);
+  const real m_r6 = r >= 6 ? real(1) : real(0), m_c6 = c >= 6 ? real(1) : real(0);
+  const real qmid = qz_entry(ct, false, r, c);
+  real pown;
+  {
+    const int ch = (N - 2) / LN_CHUNK;
+    M.ensure(ch);
+    const real* kn = L.kn(N - 1);
+    real e = qz_entry(ct, true, r, c);
+    const real th = kn[KN_R0 + r] + (r == 1 ? kn[KN_EY] : real(0));
+    if (diag) e += th;
+    if (HAS_PT && r < 6 && c < 6) e += real(PT[r <= c ? r * 6 + c : c * 6 + r]);
+    pown = e;
+    MP[r * MROW + c] = e;
+    M.wait();
+    if (ch > 0) M.ensure(ch - 1);
+  }
+  const bool upper = r <= c;
+  real* const p_dst0 = upper ? MP + r * MROW + c : MW + r * MROW + c;
+  real* const p_dst1 = upper ? MP + c * MROW + r : MW + r * MROW + c;
+  const int res_off = lane < 16 ? 2 * c + r : (lane == 18 ? LN_HI11 : LN_HI + (lane - 16));
+  const bool res_on = lane < 19;
+  real* const res_junk = MW + r * MROW + c;
+  real ar[6], ac[6];
+  {
+    const real* ab = M.stage(N - 2);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      ar[k] = ab[6 * r + k];
+      ac[k] = ab[6 * c + k];
+    }
+  }
+  const real sv00 = uni(ct[CT_SV + 0]), sv01 = uni(ct[CT_SV + 1]), sv11 = uni(ct[CT_SV + 3]);
+  wave_sync();
+  for (int i = N - 2; i >= 0; --i) {
+    real* st = L.st(i);
+    const real* kn = L.kn(i);
+    const real* ab = M.stage(i);
+    const bool cross = (i % LN_CHUNK) == 0 && i > 0;  // the read-ahead of this stage is the first read of the chunk below
+    real pr[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) pr[k] = MP[c * MROW + k];
+    pown = MP[r * MROW + c];
+    ISSUE_ORDER();
+    const real t = st[LN_DT], thr = kn[KN_R0 + r], ey = kn[KN_EY], thv0 = kn[KN_R0 + 8], thv1 = kn[KN_R0 + 9];
+    ISSUE_ORDER();
+    real w = m_r6 * pown;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) w += ar[k] * pr[k];
+    MW[r * MROW + c] = w;
+    wave_sync();
+    real wr[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) wr[k] = MW[r * MROW + k];
+    real y = m_c6 * w;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) y += wr[k] * ac[k];
+    MY[r * MROW + c] = y;
+    wave_sync();
+    const real y6r = MY[6 * MROW + r], y7r = MY[7 * MROW + r];
+    const real y6c = MY[6 * MROW + c], y7c = MY[7 * MROW + c];
+    AFTER_VALUE(y);
+    if constexpr (!JOSEPH) {
+      if (cross) M.wait();
+      const real* abn = M.stage(i > 0 ? i - 1 : 0);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        ar[k] = abn[6 * r + k];
+        ac[k] = abn[6 * c + k];
+      }
+      if (cross && i / LN_CHUNK >= 2) {
+        wave_fence();
+        M.fetch(i / LN_CHUNK - 2);
+      }
+    }
+    ISSUE_ORDER();
+    const real y66 = lane_bcast(y, 54), y67 = lane_bcast(y, 55), y77 = lane_bcast(y, 63);
+    const real tt = t * t;
+    const real h00 = sv00 + thv0 + tt * y66;
+    const real h01 = sv01 + tt * y67;
+    const real h11 = sv11 + thv1 + tt * y77;
+    const real idet = frcp(h00 * h11 - h01 * h01);
+    const real hi00 = h11 * idet, hi01 = -h01 * idet, hi11 = h00 * idet;
+    const real g0 = t * y6c, g1 = t * y7c;
+    const real k0c = hi00 * g0 + hi01 * g1;
+    const real k1c = hi01 * g0 + hi11 * g1;
+    real pn;
+    if constexpr (JOSEPH) {
+      const real g0r = t * y6r, g1r = t * y7r;
+      const real k0r = hi00 * g0r + hi01 * g1r;
+      const real k1r = hi01 * g0r + hi11 * g1r;
+      {
+        real b0[6], b1[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+          b0[k] = ab[36 + k];
+          b1[k] = ab[42 + k];
+        }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+          ar[k] -= t * (b0[k] * k0r + b1[k] * k1r);
+          ac[k] -= t * (b0[k] * k0c + b1[k] * k1c);
+        }
+      }
+      const real fr6 = (r == 6 ? real(1) : real(0)) - t * k0r, fr7 = (r == 7 ? real(1) : real(0)) - t * k1r;
+      const real fc6 = (c == 6 ? real(1) : real(0)) - t * k0c, fc7 = (c == 7 ? real(1) : real(0)) - t * k1c;
+      real w2 = 0.0;
+      {
+        real pc[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) pc[k] = MP[c * MROW + k];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) w2 += ar[k] * pc[k];
+        w2 += fr6 * pc[6] + fr7 * pc[7];
+      }
+      MW[r * MROW + c] = w2;
+      wave_sync();
+      real y2 = 0.0;
+      {
+        real w2r[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) w2r[k] = MW[r * MROW + k];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) y2 += w2r[k] * ac[k];
+        y2 += w2r[6] * fc6 + w2r[7] * fc7;
+      }
+      {
+        if (cross) M.wait();
+        const real* abn = M.stage(i > 0 ? i - 1 : 0);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+          ar[k] = abn[6 * r + k];
+          ac[k] = abn[6 * c + k];
+        }
+        if (cross && i / LN_CHUNK >= 2) {
+          wave_fence();
+          M.fetch(i / LN_CHUNK - 2);
+        }
+      }
+      const real v00 = sv00 + thv0, v11 = sv11 + thv1;
+      pn = qmid + y2 + k0r * (v00 * k0c + sv01 * k1c) + k1r * (sv01 * k0c + v11 * k1c);
+    } else {
+      pn = qmid + y - t * (y6r * k0c + y7r * k1c);
+    }
+    const real th = rfma(m_r1, ey, thr);
+    pn = rfma(m_diag, th, pn);
+    *p_dst0 = pn;
+    *p_dst1 = pn;
+    const real res = lane < 8 ? k0c : (lane < 16 ? k1c : (lane == 16 ? hi00 : (lane == 17 ? hi01 : hi11)));
+    *(res_on ? st + res_off : res_junk) = res;
+    wave_sync();
+  }
+  // what follows is a vector solve, whose backward sweep starts at the top again: its first chunks are on their way while
+  // the gradient is assembled (both buffers are free: the factor is done with them)
+  if ((N - 2) / LN_CHUNK >= 2) {
+    M.fetch((N - 2) / LN_CHUNK);
+    M.fetch((N - 2) / LN_CHUNK - 1);
+  }
+}
+
+template <int NRHS, typename real>
+__device__ __forceinline__ void riccati_solve_lean(const Lds<real>& L, ModelStream<real>& M, int lane, Prof& pf) {
+  const int N = L.N;
+  const int r = lane & 7, s = (lane >> 3) & (NRHS - 1);
+  const bool own = lane < 8 * NRHS;
+  const int reg = KN_R0 + 10 * s;
+  real* T = L.tail();
+  real* const junk0 = T + TL_W + lane;
+  real* const junk1 = T + TL_W + 80 + lane;
+  real* const pvec = T + TL_PV + 8 * s;
+  real* const pdst = own ? pvec + r : junk0;
+  auto spread2 = [&](real v, real& a, real& b) {
+    if constexpr (NRHS == 2) {
+      a = group_bcast<0x00D8>(v);
+      b = group_bcast<0x00F8>(v);
+    } else {
+      a = lane_bcast(v, 6);
+      b = lane_bcast(v, 7);
+    }
+  };
+  // ---- backward
+  {
+    const int ch = (N - 2) / LN_CHUNK;
+    M.ensure(ch);
+    M.wait();
+    if (ch > 0) M.ensure(ch - 1);
+  }
+  real p = L.kn(N - 1)[reg + r];
+  *pdst = p;
+  real row[6];
+  {
+    const real* ab = M.stage(N - 2);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) row[k] = ab[6 * r + k];
+  }
+  wave_sync();
+  for (int i = N - 2; i >= 0; --i) {
+    real* st = L.st(i);
+    const real* kn = L.kn(i);
+    const bool cross = (i % LN_CHUNK) == 0 && i > 0;
+    real pb[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) pb[k] = pvec[k];
+    ISSUE_ORDER();
+    const real k0r = st[2 * r], k1r = st[2 * r + 1], t = st[LN_DT];
+    const real qz = kn[reg + r], qv0 = kn[reg + 8], qv1 = kn[reg + 9];
+    const real hi00 = st[LN_HI], hi01 = st[LN_HI + 1], hi11 = st[LN_HI11];
+    ISSUE_ORDER();
+    real w = (r >= 6) ? p : 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) w = rfma(row[k], pb[k], w);
+    AFTER_VALUE(w);
+    real w6, w7;
+    spread2(w, w6, w7);
+    ISSUE_ORDER();
+    {
+      if (cross) M.wait();
+      const real* abn = M.stage(i > 0 ? i - 1 : 0);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) row[k] = abn[6 * r + k];
+      if (cross && i / LN_CHUNK >= 2) {
+        wave_fence();
+        M.fetch(i / LN_CHUNK - 2);
+      }
+    }
+    ISSUE_ORDER();
+    const real hv0 = rfma(t, w6, qv0);
+    const real hv1 = rfma(t, w7, qv1);
+    p = qz + w - (k0r * hv0 + k1r * hv1);
+    *pdst = p;
+    const real kff = (r == 0) ? hi00 * hv0 + hi01 * hv1 : hi01 * hv0 + hi11 * hv1;
+    *((own && r < 2) ? st + LN_KFF(s) + r : junk1) = kff;
+    wave_sync();
+  }
+  PT_MARK(8 + NRHS - 1)
+  // ---- forward: lanes r < 6 take a state row of [A B] (column reads of the chunk slot, stride 6), lanes 6, 7 a row of K
+  // (chunks 0 and 1 are what the backward sweep has left in the two buffers: no fetch, no wait)
+  const int nch = (N - 2) / LN_CHUNK + 1;
+  M.ensure(0);
+  *(own ? L.kn(0) + reg + r : junk0) = 0.0;
+  M.wait();
+  if (nch > 1) M.ensure(1);
+  const int cb = r < 6 ? r : 0;  // (lanes 6, 7: the model operands are not used)
+  real col[8], a0, b0n, b1n;
+  auto load_stage = [&](int i) {
+    const real* ab = M.stage(i);
+    const real* st = L.st(i);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) col[k] = r < 6 ? ab[6 * k + cb] : st[2 * k + (r - 6)];
+    a0 = st[LN_KFF(s) + (r & 1)];
+    b0n = ab[36 + cb];
+    b1n = ab[42 + cb];
+  };
+  load_stage(0);
+  wave_sync();
+  for (int i = 0; i < N - 1; ++i) {
+    const real* st = L.st(i);
+    real* kn = L.kn(i);
+    const bool cross = (i % LN_CHUNK) == LN_CHUNK - 1 && i < N - 2;
+    real dz[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) dz[k] = kn[reg + k];
+    ISSUE_ORDER();
+    const real b0 = b0n, b1 = b1n, t = st[LN_DT];
+    ISSUE_ORDER();
+    real acc = (r >= 6) ? a0 : 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) acc = rfma(col[k], dz[k], acc);
+    const real ax = acc;
+    acc = rfma(col[6], dz[6], acc);
+    acc = rfma(col[7], dz[7], acc);
+    AFTER_VALUE(acc);
+    const real dv = -acc;
+    const real du = rfma(t, dv, (r == 6) ? dz[6] : dz[7]);
+    real du0, du1;
+    spread2(du, du0, du1);
+    ISSUE_ORDER();
+    {
+      if (cross) M.wait();
+      load_stage(i < N - 2 ? i + 1 : i);
+      if (cross && i / LN_CHUNK + 2 < nch) {
+        wave_fence();
+        M.fetch(i / LN_CHUNK + 2);
+      }
+    }
+    ISSUE_ORDER();
+    const real nx = rfma(b1, du1, rfma(b0, du0, ax));
+    const real d = (r < 6) ? nx : du;
+    *(own ? kn + LMPC_KNOT_STRIDE + reg + r : junk0) = d;
+    *((own && r >= 6) ? kn + reg + 2 + r : junk1) = dv;
+    wave_sync();
+  }
+  PT_MARK(10 + NRHS - 1)
+}
+
+template <typename real>
+__device__ __forceinline__ void feedback_rollout_lean(const Lds<real>& L, ModelStream<real>& M, int lane) {
+  const int N = L.N, r = lane & 7;
+  const bool own = lane < 8;
+  real* T = L.tail();
+  real* const junk0 = T + TL_W + lane;
+  real* const junk1 = T + TL_W + 80 + lane;
+  const int nch = (N - 2) / LN_CHUNK + 1;
+  const int cb = r < 6 ? r : 0;
+  M.ensure(0);
+  M.wait();
+  if (nch > 1) M.ensure(1);
+  for (int i = 0; i < N - 1; ++i) {
+    const real* st = L.st(i);
+    const real* ab = M.stage(i);
+    real* kn = L.kn(i);
+    real dz[8], col[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) dz[k] = kn[k];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) col[k] = r < 6 ? ab[6 * k + cb] : st[2 * k + (r - 6)];
+    const real t = st[LN_DT];
+    const real g = ab[48 + cb];
+    real acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) acc = rfma(col[k], dz[k], acc);
+    const real ax = acc;
+    acc = rfma(col[6], dz[6], acc);
+    acc = rfma(col[7], dz[7], acc);
+    const real v = -acc;
+    const real u = rfma(t, v, (r == 6) ? dz[6] : dz[7]);
+    const real u0 = lane_bcast(u, 6), u1 = lane_bcast(u, 7);
+    const real nx = g + rfma(col[7], u1, rfma(col[6], u0, ax));
+    *(own ? kn + LMPC_KNOT_STRIDE + r : junk0) = (r < 6) ? nx : u;
+    *((own && r >= 6) ? kn + 2 + r : junk1) = v;
+    wave_sync();
+    if ((i % LN_CHUNK) == LN_CHUNK - 1 && i < N - 2) {  // the next stage is the first of the chunk above
+      M.wait();
+      if (i / LN_CHUNK + 2 < nch) M.fetch(i / LN_CHUNK + 2);
+    }
+  }
+}
+
 // `real` is the arithmetic and LDS type, `io` the type of the arrays in HBM: <double, double> is the reference's
 // precision, <float, float> the single-precision path, <float, double> the mixed path (fp64 linearisation, regression,
 // safe-set centring and results around an fp32 interior-point iteration).
@@ -1264,24 +1670,34 @@ __device__ __forceinline__ void lmpc_solve_problem(
   const real inf = real(INFINITY), marg = real(P.marg), qsig = real(P.qsig), tol = lim::tol(P.tol);
   // single precision carries the abscissa relative to x_ic[0] (the QP is invariant to the shift: A(:, s) = e_s)
   const io s_shift = sizeof(real) == 4 ? x_ic[b] : io(0);
-  Lds<real> L{lds, N};
+  constexpr bool LEAN = lmpc_lean(sizeof(real), KQ);
+  Lds<real> L{lds, N, LEAN ? LMPC_LEAN_STAGE_STRIDE : LMPC_STAGE_STRIDE};
   real* T = L.tail();
   real* ct = T + TL_CT;
   real* KN0 = L.kn(0);
   // terminal region (learning only): treal cells behind the records; 16-byte aligned because every record size is even
   treal* const TT = reinterpret_cast<treal*>(T + LMPC_TAIL_DOUBLES);
+  // lean layout: the chunk buffers sit behind everything else (records, tail, terminal region)
+  ModelStream<real> MS{nullptr, nullptr, NS, lane, -1, -1};
+  if constexpr (LEAN) {
+    static_assert(!LEAN || (std::is_same<real, double>::value && std::is_same<io, double>::value), "the lean layout streams the fp64 workspace as it is");
+    MS.ws = reinterpret_cast<const real*>(ws_lin) + (size_t)b * NS * LMPC_LIN_RECORD;
+    MS.buf = reinterpret_cast<real*>(reinterpret_cast<unsigned char*>(TT) + (KS > 0 ? (LMPC_TERM_CELLS + 6 * 64 * KS) * sizeof(treal) : 0));
+  }
   const treal tinf = treal(INFINITY);
   PT_DECL
 
   // ---------------- load: linearisation records, per-knot data, constant tables ----------------
   {
-    const io* wsb = ws_lin + (size_t)b * NS * LMPC_LIN_RECORD;
-    for (int e = lane; e < NS * LMPC_LIN_RECORD; e += 64) {
-      const int i = e / LMPC_LIN_RECORD, o = e - i * LMPC_LIN_RECORD;
-      const int c = o / 6;
-      L.st(i)[o < 48 ? ST_ROW(c) + (o - c * 6) : ST_G + (o - 48)] = real(wsb[e]);
+    if constexpr (!LEAN) {  // (the lean layout leaves the model in the workspace and streams it, sweep by sweep)
+      const io* wsb = ws_lin + (size_t)b * NS * LMPC_LIN_RECORD;
+      for (int e = lane; e < NS * LMPC_LIN_RECORD; e += 64) {
+        const int i = e / LMPC_LIN_RECORD, o = e - i * LMPC_LIN_RECORD;
+        const int c = o / 6;
+        L.st(i)[o < 48 ? ST_ROW(c) + (o - c * 6) : ST_G + (o - 48)] = real(wsb[e]);
+      }
     }
-    for (int i = lane; i < NS; i += 64) L.st(i)[ST_DT] = real(T_ref[(size_t)i * B + b]);
+    for (int i = lane; i < NS; i += 64) L.st(i)[LEAN ? LN_DT : ST_DT] = real(T_ref[(size_t)i * B + b]);
     for (int i = lane; i < N; i += 64) {
       real* kn = L.kn(i);
       kn[KN_QLIN] = P.learning ? real(0) : real(i == N - 1 ? P.qv_term : P.qv_stage) * real(vref[(size_t)i * B + b]);
@@ -1326,7 +1742,7 @@ __device__ __forceinline__ void lmpc_solve_problem(
   // clear flag; a lane's surplus slots (j >= 11 N) point at a dead record inside the factor's work
   // matrices, so their loads and stores are harmless.
   const bool has_sigma = P.has_sigma != 0;
-  const int KNB = NS * LMPC_STAGE_STRIDE;            // knot 0, offset from the LDS base (doubles)
+  const int KNB = NS * L.stride;                     // knot 0, offset from the LDS base (doubles)
   const int JB = KNB + N * LMPC_KNOT_STRIDE + TL_W;  // dead record (34 cells of W)
   const int CTB = KNB + N * LMPC_KNOT_STRIDE + TL_CT;
   int o_val[KQ];  // the constrained value; its Newton step sits at +10 (rhs0) and +20 (rhs1)
@@ -1463,8 +1879,13 @@ __device__ __forceinline__ void lmpc_solve_problem(
     if (lane < 36) TT[TL_PT + lane] = (lane % 7 == 0) ? TT[TL_E + lane / 7] : treal(0);
   }
   wave_sync();
-  riccati_factor<(KS > 0), false>(L, lane, TT + TL_PT);
-  feedback_rollout(L, lane);
+  if constexpr (LEAN) {
+    riccati_factor_lean<(KS > 0), false>(L, MS, lane, TT + TL_PT);
+    feedback_rollout_lean(L, MS, lane);
+  } else {
+    riccati_factor<(KS > 0), false>(L, lane, TT + TL_PT);
+    feedback_rollout(L, lane);
+  }
   if constexpr (KS > 0) {
     treal ul[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
@@ -1692,7 +2113,10 @@ __device__ __forceinline__ void lmpc_solve_problem(
       hsig = uni(qsig + wave_sum(eysum));
       ++pol_rounds;
       wave_sync();
-      riccati_factor<(KS > 0), true>(L, lane, TT + TL_PT);
+      if constexpr (LEAN)
+        riccati_factor_lean<(KS > 0), true>(L, MS, lane, TT + TL_PT);
+      else
+        riccati_factor<(KS > 0), true>(L, lane, TT + TL_PT);
       bool nan_step = false;
       // ---- pol::steps multiplier steps on that factor, each from the point the one before has reached ----
       for (int k = 0; k < pol::steps; ++k) {
@@ -1764,7 +2188,12 @@ __device__ __forceinline__ void lmpc_solve_problem(
           if (lane < 6) L.kn(N - 1)[KN_R0 + lane] += real(TT[TL_TG + lane]);
         }
         wave_sync();
-        if constexpr (lmpc_waves_per_simd(sizeof(real), KQ, KS) < 2) {
+        if constexpr (LEAN) {
+          if (k == 0 && has_sigma)
+            riccati_solve_lean<2>(L, MS, lane, pf);
+          else
+            riccati_solve_lean<1>(L, MS, lane, pf);
+        } else if constexpr (lmpc_waves_per_simd(sizeof(real), KQ, KS) < 2) {
           if (k == 0 && has_sigma)
             riccati_solve_lds<2>(L, lane, pf);
           else
@@ -2177,7 +2606,12 @@ __device__ __forceinline__ void lmpc_solve_problem(
       }
       wave_sync();
       PT_MARK(2)
-      if (sizeof(real) == 8 && mu <= real(JOSEPH_MU))  // (single precision stops at mu ~ 2e-6)
+      if constexpr (LEAN) {
+        if (mu <= real(JOSEPH_MU))
+          riccati_factor_lean<(KS > 0), true>(L, MS, lane, TT + TL_PT);
+        else
+          riccati_factor_lean<(KS > 0), false>(L, MS, lane, TT + TL_PT);
+      } else if (sizeof(real) == 8 && mu <= real(JOSEPH_MU))  // (single precision stops at mu ~ 2e-6)
         riccati_factor<(KS > 0), (sizeof(real) == 8)>(L, lane, TT + TL_PT);
       else
         riccati_factor<(KS > 0), false>(L, lane, TT + TL_PT);
@@ -2279,7 +2713,12 @@ __device__ __forceinline__ void lmpc_solve_problem(
       // 11.03 against 11.05 ms; the learning kernel 3 %), and the most register-starved of them (KQ = 14, KS = 3) was NOT
       // reproducible from run to run with it, for a reason that was not found -- so none of that
       // family takes the risk.  Every instantiation as built is bitwise reproducible (scratch/r2_det_all.sh).
-      if constexpr (lmpc_waves_per_simd(sizeof(real), KQ, KS) < 2) {
+      if constexpr (LEAN) {
+        if (pass == 0 && ipm && has_sigma)
+          riccati_solve_lean<2>(L, MS, lane, pf);
+        else
+          riccati_solve_lean<1>(L, MS, lane, pf);
+      } else if constexpr (lmpc_waves_per_simd(sizeof(real), KQ, KS) < 2) {
         if (pass == 0 && ipm && has_sigma)
           riccati_solve_lds<2>(L, lane, pf);
         else
