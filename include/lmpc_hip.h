@@ -211,12 +211,15 @@ int lmpc_solve_host(lmpc_handle* h, const double* x_ic, const double* u_ic, cons
  * x_{i+1} = f_d(x_i, u_i, k_i, t_i), :162-166, instead of their linearisation; the node uses it for its very first
  * solve, racing_mpc_node.cpp:299-314).  Sequential QPs over the batched kernels, globalised by a backtracking line search
  * on the l1 merit function cost + nu |dynamics defect|_1 (csrc/lmpc_sqp_kernel.hip): linearise about the iterate, solve
- * the QP, step, until the scaled step falls below step_tol or max_sqp QPs are spent.  The iterate starts at
+ * the QP, step, until the QP's own step falls below step_tol (scaled) or max_sqp QPs are spent.  A QP that is infeasible
+ * about a new iterate (the step outran its linearisation) moves the iterate half way back and is linearised again, up to
+ * 6 times in a row, before the problem stops with that status.  The iterate starts at
  * (X_ref, U_ref) -- the node hands its zero-input rollout, racing_mpc_node.cpp:210-235 -- with dU = 0, lambda = 0.
- * DEVICE pointers, layouts of lmpc_solve_batch.  Outputs: the iterate reached; status [B] = status of the last QP taken
- * into it; iters [B] = interior-point iterations summed over its QPs; sqp_iters [B] = steps taken; sqp_move [B] = scaled
- * size of the last step (converged iff <= step_tol); defect [B] = |x_{i+1} - f_d(x_i, u_i)|_inf / scale_x of the
- * iterate.  The first call for a batch size allocates a work area (like lmpc_reserve); synchronises the stream once per
+ * DEVICE pointers, layouts of lmpc_solve_batch.  Outputs: the iterate reached; status [B] = status of the last QP solved
+ * for the problem; iters [B] = interior-point iterations summed over the QPs solved while the problem was still moving;
+ * sqp_iters [B] = those QPs (steps taken + back-offs); sqp_move [B] = scaled |X_QP - X| of the last QP, the step it
+ * proposed whatever part of it the line search took (converged iff <= step_tol); defect [B] =
+ * |x_{i+1} - f_d(x_i, u_i)|_inf / scale_x of the iterate.  The first call for a batch size allocates a work area (like lmpc_reserve); synchronises the stream once per
  * QP (it has to know whether any problem is still moving). */
 int lmpc_solve_full_dynamics_batch(lmpc_handle* h, int32_t batch, const double* x_ic, const double* u_ic, const double* X_ref,
                                    const double* U_ref, const double* T_ref, const double* bound_left,

@@ -69,12 +69,19 @@ def solve_nlp_dense(cfg: MPCConfig, veh: Vehicle, pr: dict, max_sqp: int = 40, t
     X, U = np.array(pr["X_ref"], dtype=float), np.array(pr["U_ref"], dtype=float)
     dU, sigma, nu = np.zeros((2, N - 1)), 0.0, 1e-3
     info = {"status": 1, "sqp_iters": 0}
+    prev, backoffs, move = None, 0, np.inf
     for it in range(max_sqp):
         qp = Q.build_qp(cfg, veh, _at(pr, X, U))
         y, qi = Q.solve_dense(qp)
+        info["sqp_iters"] = it + 1
         if qi["status"] != 0:
+            if prev is not None and backoffs < 6:   # the step outran its linearisation: half way back, linearise again
+                backoffs += 1
+                X, U, dU, sigma = 0.5 * (X + prev[0]), 0.5 * (U + prev[1]), 0.5 * (dU + prev[2]), 0.5 * (sigma + prev[3])
+                continue
             info["status"] = 2
             break
+        backoffs = 0
         o = qp.split(y)
         y0 = Q.pack(qp, X, U, dU, sigma=sigma)
         a = 1.0
@@ -90,10 +97,10 @@ def solve_nlp_dense(cfg: MPCConfig, veh: Vehicle, pr: dict, max_sqp: int = 40, t
                 if merit_cost(qp, ya) + nu * np.abs(defect(veh, pr, oa["X_optm"], oa["U_optm"])).sum() <= phi0 + 1e-4 * a * D + 1e-14 * (1 + abs(phi0)) or t == 7:
                     break
                 a *= 0.5
-        move = np.abs(a * (o["X_optm"] - X) / SCALE_X[:, None]).max()
+        move = np.abs((o["X_optm"] - X) / SCALE_X[:, None]).max()   # the step proposed, whatever part of it is taken
+        prev = (X, U, dU, sigma)
         X, U, dU = X + a * (o["X_optm"] - X), U + a * (o["U_optm"] - U), dU + a * (o["dU_optm"] - dU)
         sigma = sigma + a * (o.get("sigma", 0.0) - sigma)
-        info["sqp_iters"] = it + 1
         if move <= tol:
             info["status"] = 0
             break

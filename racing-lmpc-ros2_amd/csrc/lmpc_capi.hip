@@ -206,7 +206,11 @@ int launch_cleanup(lmpc_handle* h, const void* fn, const solve_args& a) {
 }
 
 // pass: 0 a plain solve; 1 the fp32 iteration of a two-pass mixed solve (marks what it could not verify)
-int launch_solve(lmpc_handle* h, const void* fn, const solve_args& a, int pass = 0) {
+int launch_solve(lmpc_handle* h, const void* fn, const solve_args& a_in, int pass = 0) {
+  // LMPC_LDS_PAD (bytes, measurement only): over-allocate LDS per problem to cap the problems resident on a CU
+  static const int lds_pad = [] { const char* e = getenv("LMPC_LDS_PAD"); return e ? atoi(e) : 0; }();
+  solve_args a = a_in;
+  a.lds_bytes += lds_pad;
   HIP_TRY(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)a.lds_bytes));
   lmpc_params P = h->P;
   P.flag_unverified = pass == 1;
@@ -591,8 +595,8 @@ int reserve_sqp(lmpc_handle* h, size_t B) {
   h->sqp_ws = nullptr;
   h->sqp_int = nullptr;
   h->sqp_cap = 0;
-  HIP_TRY(h, hipMalloc(&h->sqp_ws, (6 * N + 4 * (N - 1) + S + 1) * B * sizeof(double)));
-  HIP_TRY(h, hipMalloc(&h->sqp_int, (3 * B + 1) * sizeof(int)));
+  HIP_TRY(h, hipMalloc(&h->sqp_ws, (2 * (6 * N + 4 * (N - 1) + S) + 1) * B * sizeof(double)));
+  HIP_TRY(h, hipMalloc(&h->sqp_int, (4 * B + 1) * sizeof(int)));
   if (!h->sqp_count_host) HIP_TRY(h, hipHostMalloc(&h->sqp_count_host, sizeof(int)));
   h->sqp_cap = B;
   return LMPC_OK;
@@ -615,7 +619,8 @@ int lmpc_solve_full_dynamics_batch(lmpc_handle* h, int32_t batch, const double* 
   HIP_TRY(h, hipSetDevice(h->device));
   const size_t B = (size_t)batch, N = (size_t)h->P.N, NS = N - 1, S = (size_t)h->P.S;
   const size_t nX = 6 * N * B, nU = 2 * NS * B, nL = S * B;
-  // work area: QP solution (Xq, Uq, dUq, lamq), penalty weights; ints: status_q, iters_q, active, counter
+  // work area: QP solution (Xq, Uq, dUq, lamq), the iterate before the last step (Xp, Up, dUp, lamp), penalty weights;
+  // ints: status_q, iters_q, active, consecutive back-offs, counter
   {
     const int rc = reserve_sqp(h, B);
     if (rc != LMPC_OK) return rc;
@@ -624,11 +629,16 @@ int lmpc_solve_full_dynamics_batch(lmpc_handle* h, int32_t batch, const double* 
   double* Uq = Xq + nX;
   double* dUq = Uq + nU;
   double* lamq = dUq + nU;
-  double* nu = lamq + nL;
+  double* Xp = lamq + nL;
+  double* Up = Xp + nX;
+  double* dUp = Up + nU;
+  double* lamp = dUp + nU;
+  double* nu = lamp + nL;
   int* status_q = h->sqp_int;
   int* iters_q = status_q + B;
   int* active = iters_q + B;
-  int* counter = active + B;
+  int* backoffs = active + B;
+  int* counter = backoffs + B;
   // the iterate lives in the caller's output arrays: start = the reference trajectory (the node's zero-input rollout,
   // racing_mpc_node.cpp:210-235), dU = 0, lambda = 0 (its convex_combi_optm_ref)
   HIP_TRY(h, hipMemcpyAsync(X_optm, X_ref, nX * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
@@ -636,6 +646,7 @@ int lmpc_solve_full_dynamics_batch(lmpc_handle* h, int32_t batch, const double* 
   HIP_TRY(h, hipMemsetAsync(dU_optm, 0, nU * sizeof(double), h->stream));
   if (S) HIP_TRY(h, hipMemsetAsync(convex_combi_optm, 0, nL * sizeof(double), h->stream));
   HIP_TRY(h, hipMemsetAsync(nu, 0, B * sizeof(double), h->stream));
+  HIP_TRY(h, hipMemsetAsync(backoffs, 0, B * sizeof(int), h->stream));
   HIP_TRY(h, hipMemsetAsync(iters, 0, B * sizeof(int), h->stream));
   HIP_TRY(h, hipMemsetAsync(sqp_iters, 0, B * sizeof(int), h->stream));
   HIP_TRY(h, hipMemsetAsync(defect, 0, B * sizeof(double), h->stream));
@@ -649,6 +660,8 @@ int lmpc_solve_full_dynamics_batch(lmpc_handle* h, int32_t batch, const double* 
   lmpc_sqp_arrays A{};
   A.X = X_optm; A.U = U_optm; A.dU = dU_optm; A.lam = S ? convex_combi_optm : nullptr;
   A.Xq = Xq; A.Uq = Uq; A.dUq = dUq; A.lamq = S ? lamq : nullptr;
+  A.Xp = Xp; A.Up = Up; A.dUp = dUp; A.lamp = S ? lamp : nullptr;
+  A.backoffs = backoffs; A.iters_q = iters_q; A.iters = iters;
   A.status_q = status_q;
   A.T_ref = T_ref; A.curv = curvatures; A.bl = bound_left; A.br = bound_right; A.vref = vel_ref; A.ss_x = ss_x; A.ss_j = ss_j;
   A.nu = nu; A.active = active; A.status = status; A.sqp_iters = sqp_iters; A.move = sqp_move; A.defect = defect;
@@ -662,7 +675,6 @@ int lmpc_solve_full_dynamics_batch(lmpc_handle* h, int32_t batch, const double* 
     hipLaunchKernelGGL(lmpc_sqp_linesearch_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, h->stream, h->P, batch, A,
                        it == 0 ? 1 : 0, step_tol);
     HIP_TRY(h, hipGetLastError());
-    hipLaunchKernelGGL(lmpc_sqp_accumulate_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, h->stream, batch, iters_q, iters);
     HIP_TRY(h, hipMemcpyAsync(h->sqp_count_host, counter, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     if (*h->sqp_count_host == 0) break;

@@ -17,10 +17,18 @@
 // Every row of the NLP other than the dynamics is LINEAR and holds at w_QP; it holds at the iterate too from the first
 // full step on, hence along the whole segment -- the line search only has to look at cost and defect.  The very first
 // step is taken in full (the cold-start iterate is a zero-input rollout: c = 0, but outside the boxes).
+//   back-off when the QP about the new iterate is infeasible (its linearised dynamics cannot meet the hard boxes: the step
+//            went too far for the linearisation that proposed it) the iterate is moved half way back to the previous one
+//            and linearised again, up to LMPC_SQP_BACKOFF times in a row -- the role of IPOPT's restoration phase upstream.
+//            Only after that does the problem stop with the QP's status.
+//   move     the convergence measure is the size of the QP's own step |w_QP - w| (scaled), not of the shortened step
+//            taken: a collapsed line search cannot pass for convergence.
 #include <hip/hip_runtime.h>
 
 #include "lmpc_device.h"
 #include "lmpc_dynamics.hip.h"
+
+#define LMPC_SQP_BACKOFF 6
 
 struct lmpc_sqp_arrays {
   // iterate (updated in place) and QP solution, [field][knot][batch]
@@ -29,12 +37,17 @@ struct lmpc_sqp_arrays {
   const int* status_q;
   // problem data
   const double *T_ref, *curv, *bl, *br, *vref, *ss_x, *ss_j;
+  // the iterate before the last step taken (for the back-off), same layout as the iterate
+  double *Xp, *Up, *dUp, *lamp;
+  int* backoffs;   // consecutive back-offs (in/out)
+  const int* iters_q;  // interior-point iterations of this pass's QP
+  int* iters;          // their sum over the QPs this problem took part in (in/out)
   // per problem
   double* nu;      // penalty weight (in/out)
   int* active;     // 1 while the problem is still iterating (in/out)
   int* status;     // status of the last QP taken into the iterate (out)
-  int* sqp_iters;  // steps taken (in/out)
-  double* move;    // largest scaled change of X in the last step (out)
+  int* sqp_iters;  // QPs solved for this problem: steps taken + back-offs (in/out)
+  double* move;    // largest scaled |X_QP - X| of the last QP (out): the step proposed, whatever part of it was taken
   double* defect;  // |c|_inf of the iterate after the step (out)
   int* n_active;   // device counter of problems still active after this step (atomic)
 };
@@ -107,10 +120,24 @@ __global__ __launch_bounds__(64) void lmpc_sqp_linesearch_kernel(lmpc_params P, 
   if (b >= B || !A.active[b]) return;
   const int N = P.N, NS = N - 1, S = P.S;
   A.status[b] = A.status_q[b];
-  if (A.status_q[b] != LMPC_SOLVE_OPTIMAL) {  // the QP failed: the problem keeps its last iterate and reports that status
-    A.active[b] = 0;
+  A.iters[b] += A.iters_q[b];
+  A.sqp_iters[b] += 1;
+  if (A.status_q[b] != LMPC_SOLVE_OPTIMAL) {
+    if (!first && A.backoffs[b] < LMPC_SQP_BACKOFF) {  // half way back to the iterate the last step started from
+      A.backoffs[b] += 1;
+      for (int e = 0; e < 6 * N; ++e) A.X[(size_t)e * B + b] = 0.5 * (A.X[(size_t)e * B + b] + A.Xp[(size_t)e * B + b]);
+      for (int e = 0; e < 2 * NS; ++e) {
+        A.U[(size_t)e * B + b] = 0.5 * (A.U[(size_t)e * B + b] + A.Up[(size_t)e * B + b]);
+        A.dU[(size_t)e * B + b] = 0.5 * (A.dU[(size_t)e * B + b] + A.dUp[(size_t)e * B + b]);
+      }
+      for (int j = 0; j < S; ++j) A.lam[(size_t)j * B + b] = 0.5 * (A.lam[(size_t)j * B + b] + A.lamp[(size_t)j * B + b]);
+      atomicAdd(A.n_active, 1);
+      return;
+    }
+    A.active[b] = 0;  // the problem keeps its last iterate and reports the QP's status
     return;
   }
+  A.backoffs[b] = 0;
   double J0, c0, ci0, J1, c1, ci1;
   sqp_eval(P, A, B, b, 0.0, J0, c0, ci0);
   sqp_eval(P, A, B, b, 1.0, J1, c1, ci1);
@@ -134,30 +161,28 @@ __global__ __launch_bounds__(64) void lmpc_sqp_linesearch_kernel(lmpc_params P, 
   const double isc[6] = {1.0 / 2000.0, 1.0 / 10.0, 1.0 / 0.1, 1.0 / 80.0, 1.0 / 2.0, 1.0 / 2.0};
   double mv = 0.0;
   for (int e = 0; e < 6 * N; ++e) {
-    const double c = A.X[(size_t)e * B + b], d = a * (A.Xq[(size_t)e * B + b] - c);
+    const double c = A.X[(size_t)e * B + b], d = A.Xq[(size_t)e * B + b] - c;
     mv = fmax(mv, fabs(d) * isc[e / N]);
-    A.X[(size_t)e * B + b] = c + d;
+    A.Xp[(size_t)e * B + b] = c;
+    A.X[(size_t)e * B + b] = c + a * d;
   }
   for (int e = 0; e < 2 * NS; ++e) {
     const double c = A.U[(size_t)e * B + b];
+    A.Up[(size_t)e * B + b] = c;
     A.U[(size_t)e * B + b] = c + a * (A.Uq[(size_t)e * B + b] - c);
     const double v = A.dU[(size_t)e * B + b];
+    A.dUp[(size_t)e * B + b] = v;
     A.dU[(size_t)e * B + b] = v + a * (A.dUq[(size_t)e * B + b] - v);
   }
   for (int j = 0; j < S; ++j) {
     const double l = A.lam[(size_t)j * B + b];
+    A.lamp[(size_t)j * B + b] = l;
     A.lam[(size_t)j * B + b] = l + a * (A.lamq[(size_t)j * B + b] - l);
   }
   A.move[b] = mv;
   A.defect[b] = cinf;
-  A.sqp_iters[b] += 1;
   const int still = mv > step_tol ? 1 : 0;
   A.active[b] = still;
   if (still) atomicAdd(A.n_active, 1);
 }
 
-// iters += iters_q (interior-point iterations summed over the QPs of a problem)
-__global__ void lmpc_sqp_accumulate_kernel(int B, const int* __restrict__ iters_q, int* __restrict__ iters) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b < B) iters[b] += iters_q[b];
-}

@@ -61,6 +61,8 @@ class RacingMPCNodeCore {
   void set_speed_scale(const double& speed_scale);  // :583-598 (out of (0, 1] resets to 0.2)
   const DM& last_x() const { return last_x_; }
   const DM& last_u() const { return last_u_; }
+  const DM& last_du() const { return last_du_; }
+  const DMDict& sol_in() const { return sol_in_; }  // what the last step handed to the controller (step-level parity tests)
 
  private:
   void discrete_dynamics(const double* x, const double* u, double* xn) const;  // model step with the track curvature at x[s]

@@ -1,7 +1,10 @@
 // Drives RacingMPCNodeCore -- the ROS-free restatement of RacingMPCNode::on_step_timer (racing_mpc_node.cpp:150-477) --
 // in closed loop with a host plant on the reference's BARC race line, the way sim_barc_tracking_mpc wires node and
 // simulator: state message (global pose + body velocities) in, actuation message out, every 25 ms.
-// usage: test_node_core <15_barc_optm.txt> <N> <laps> [step|continuous]
+// usage: test_node_core <15_barc_optm.txt> <N> <laps> [step|continuous] [dump_file dump_steps]
+// With a dump file, the first dump_steps ticks are written out in full -- the state and actuation messages that went in,
+// the plan the node held before the tick, the sol_in it handed to the controller, the plan and the actuation that came
+// out -- for the step-for-step comparison with oracle/node_step.py (tests/test_gpu_facade.py).
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -15,8 +18,16 @@ using namespace lmpc::mpc::racing_mpc;
 namespace rt = lmpc::vehicle_model::racing_trajectory;
 namespace stm = lmpc::vehicle_model::single_track_planar_model;
 
+static void dump(std::FILE* f, const char* key, const lmpc::DM& m) {
+  std::fprintf(f, "%s %zu %zu", key, m.rows, m.cols);
+  for (double v : m.data) std::fprintf(f, " %.17g", v);
+  std::fputc('\n', f);
+}
+
 int main(int argc, char** argv) {
   if (argc < 4) return 2;
+  std::FILE* df = argc > 6 ? std::fopen(argv[5], "w") : nullptr;
+  const int dump_steps = argc > 6 ? std::atoi(argv[6]) : 0;
   const int N = std::atoi(argv[2]);
   const double laps_wanted = std::atof(argv[3]);
   const bool step_mode = argc > 4 && std::strcmp(argv[4], "step") == 0;
@@ -60,7 +71,22 @@ int main(int argc, char** argv) {
     VehicleState st;
     st.t = t; st.x = gp.position.x; st.y = gp.position.y; st.psi = gp.yaw;
     st.v_long = x[3]; st.v_tran = x[4]; st.w_psi = x[5];
+    const bool dumping = df && k < dump_steps;
+    if (dumping) {
+      std::fprintf(df, "tick %d\nstate 7 1 %.17g %.17g %.17g %.17g %.17g %.17g %.17g\nfrenet 3 1 %.17g %.17g %.17g\nact_in 2 1 %.17g %.17g\n", k, st.t,
+                   st.x, st.y, st.psi, st.v_long, st.v_tran, st.w_psi, x[0], x[1], x[2], act.u_a, act.u_steer);
+      dump(df, "prev_X", node.last_x());
+      dump(df, "prev_U", node.last_u());
+      dump(df, "prev_dU", node.last_du());
+    }
     const auto r = node.step(st, act, tel);
+    if (dumping) {
+      std::fprintf(df, "result 1 1 %d\n", (int)r);
+      for (const auto& kv : node.sol_in()) dump(df, ("in_" + kv.first).c_str(), kv.second);
+      dump(df, "X_optm", node.last_x());
+      dump(df, "U_optm", node.last_u());
+      std::fprintf(df, "act_out 2 1 %.17g %.17g\n", act.u_a, act.u_steer);
+    }
     if (r == RacingMPCNodeCore::Result::INITIAL_SOLVE) ++n_initial;
     if (r == RacingMPCNodeCore::Result::INITIAL_SOLVE_FAILED) { std::puts("FAIL: initial full-dynamics solve"); return 1; }
     if (r == RacingMPCNodeCore::Result::JIT_DISCARDED) ++n_discarded;
@@ -91,6 +117,7 @@ int main(int argc, char** argv) {
   std::printf("laps %.3f time %.3f published %d failed %d initial %d discarded %d worst_excess %.4f mean_step_ms %.3f\n",
               travelled / L, t, n_published, n_failed, n_initial, n_discarded, worst_excess, solve_ms / (n_published ? n_published : 1));
   const bool ok = travelled >= laps_wanted * L && n_initial == 1 && n_discarded == 1 && n_failed <= n_published / 100 && worst_excess < 0.02;
+  if (df) std::fclose(df);
   std::puts(ok ? "PASS" : "FAIL");
   return ok ? 0 : 1;
 }

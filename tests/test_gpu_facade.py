@@ -95,6 +95,94 @@ def test_node_core_drives_two_laps_of_the_reference_barc_track(N, mode):
     print(f"N={N} {mode}: {laps:.2f} laps in {t:.2f} s, {published} steps, {failed} failed, {step_ms:.2f} ms per step")
 
 
+def _read_ticks(path):
+    ticks, cur = [], None
+    for line in open(path):
+        f = line.split()
+        if f[0] == "tick":
+            cur = {}
+            ticks.append(cur)
+            continue
+        r, c = int(f[1]), int(f[2])
+        cur[f[0]] = np.array([float(v) for v in f[3:]]).reshape(c, r).T if r * c else np.zeros((r, c))
+    return ticks
+
+
+@pytest.mark.parametrize("mode", ["continuous", "step"])
+def test_node_core_step_for_step_against_the_restatement(mode, tmp_path):
+    """Every tick of RacingMPCNodeCore::step against oracle/node_step.py, the restatement of on_step_timer
+    (racing_mpc_node.cpp:181-292, :385-402), on 15_barc_optm.txt: the inputs the node hands to the controller (x_ic, u_ic,
+    the shifted plan with its rolled-out last knot, boundaries, curvatures, the clamped velocity reference) from the same
+    state message, actuation message and previous plan; the plan carried from one tick to the next; the actuation message
+    from column delay_step of the new plan through to_base_control.  Tolerances: exact (0.0) for copies and
+    shifts; 1e-11 .. 1e-12 where the host spline and model meet scipy's spline and the numpy model (measured: 3e-14 on the
+    rolled-out knots, 4e-13 on curvatures); 1e-8 on the Frenet projection, a minimiser stopped at |step| < 1e-12 (measured:
+    5e-10), and on what follows from it in CONTINUOUS mode, where the measured state is not visible in sol_in."""
+    from oracle import node_step
+    from oracle.params import barc_vehicle
+    from oracle.trajectory import TrackOracle
+    exe = LIB / "test_node_core"
+    assert exe.exists(), "run __graft_entry__.build() first"
+    track_file = ROOT / "tests" / "golden" / "barc_track" / "15_barc_optm.txt"
+    N, n_ticks, dt = 20, 60, 0.025
+    out = tmp_path / "ticks.txt"
+    r = subprocess.run([str(exe), str(track_file), str(N), "0.5", mode, str(out), str(n_ticks)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "PASS" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+    ticks = _read_ticks(out)
+    assert len(ticks) == n_ticks
+    track, veh = TrackOracle(np.loadtxt(track_file)), barc_vehicle()
+    worst = {}
+
+    def close(name, got, want, tol):
+        d = float(np.abs(np.asarray(got, float).reshape(-1) - np.asarray(want, float).reshape(-1)).max())
+        worst[name] = max(worst.get(name, 0.0), d)
+        assert d <= tol, (name, k, d)
+
+    published = 0
+    for k, t in enumerate(ticks):
+        first = k == 0
+        state, act_in = t["state"][:, 0], t["act_in"][:, 0]
+        assert int(t["result"][0, 0]) == (0 if first else 2 if k == 1 else 3)   # initial solve, jit discard, then published
+        # the Frenet projection: the pose the plant sent, recovered; and the oracle's centre line maps it back to the message
+        where = track.eval(t["frenet"][0, 0])
+        close("pose_round_trip", [where["x"] - t["frenet"][1, 0] * np.sin(where["yaw"]), where["y"] + t["frenet"][1, 0] * np.cos(where["yaw"])],
+              state[1:3], 1e-12)
+        x_meas = np.concatenate([t["frenet"][:, 0], state[4:7]])
+        if first or mode == "step":
+            close("projection", t["in_x_ic"][:3, 0], t["frenet"][:, 0], 1e-8)
+            x_meas = t["in_x_ic"][:, 0]          # what the node measured is visible: the rest is compared exactly
+        last = None if first else (t["prev_X"], t["prev_U"], t["prev_dU"])
+        if not first:                             # the plan is carried from tick to tick
+            close("carried_X", t["prev_X"], ticks[k - 1]["X_optm"], 0.0)
+            close("carried_U", t["prev_U"], ticks[k - 1]["U_optm"], 0.0)
+        want = node_step.step_inputs(track, veh, N, dt, 1.0, x_meas, act_in, last, continuous=(mode == "continuous"),
+                                     speed_limit=6.0, speed_scale=0.9)
+        tol_meas = 0.0 if (first or mode == "step") else 1e-8
+        close("x_ic", t["in_x_ic"], want["x_ic"], tol_meas)
+        close("u_ic", t["in_u_ic"], want["u_ic"], 0.0)
+        close("t_ic", t["in_t_ic"], state[0], 0.0)
+        close("T_ref", t["in_T_ref"], want["T_ref"], 0.0)
+        close("total_length", t["in_total_length"], track.L, 0.0)
+        for key in ("X_ref", "X_optm_ref"):
+            close(key, t["in_" + key], want[key], 1e-11)
+        for key in ("U_ref", "U_optm_ref", "dU_optm_ref"):
+            close(key, t["in_" + key], want[key], 0.0)
+        close("bound_left", t["in_bound_left"], want["bound_left"], 1e-12)
+        close("bound_right", t["in_bound_right"], want["bound_right"], 1e-12)
+        close("curvatures", t["in_curvatures"], want["curvatures"], 1e-10)
+        close("vel_ref", t["in_vel_ref"], want["vel_ref"], 1e-12)
+        if not first and k > 1:
+            ua, us = node_step.actuation(t["U_optm"], 0)
+            close("act_out", t["act_out"][:, 0], [ua, us], 1e-15)
+            published += 1
+    assert published == n_ticks - 2
+    # the clamp was exercised: some knot's reference is the +- max_vel_ref_diff edge, some knot's is the scaled profile
+    v = np.stack([t["in_vel_ref"][0] for t in ticks[1:]])
+    cur = np.stack([t["in_X_ref"][3] for t in ticks[1:]])
+    assert (np.abs(np.abs(v - cur) - 1.0) < 1e-12).any() and (np.abs(v - cur) < 1.0 - 1e-6).any()
+    print(mode, {n: f"{d:.1e}" for n, d in worst.items()})
+
+
 def test_host_model_matches_the_device_model(pkg):
     """single_track_model.cpp (what the node core steps on the host) against the device kernels: the cold-start rollout of
     lmpc_prepare_batch is the same sequence of discrete_dynamics calls."""

@@ -488,14 +488,22 @@ def test_full_dynamics_sqp_reaches_kkt_points_of_the_nlp(pkg):
     one = to_np(solver.solve(inp))
     nlp = to_np(solver.solve_full_dynamics(inp, max_sqp=40, tol=1e-9))
     conv = (nlp["status"] == 0) & (nlp["sqp_move"] <= 1e-8)
-    # Starts below ~1.5 m/s sit where the RK4 map of the tyre model is unstable (|eig A| > 1, up to ~15-25 per step below
-    # 1 m/s): the QP about a
-    # given trajectory is still well posed (tests/test_long_horizon.py), but the NLP's own dynamics rows are then a chaotic
-    # map of the inputs and a local method -- this one or the oracle's dense SQP -- need not converge; such problems
-    # must say so (status / sqp_move), never report a converged point with a defect.
-    fast = x[:, 3] >= 1.6
-    print("full dynamics: converged", conv.mean(), "of all,", conv[fast].mean(), "of the starts above 1.6 m/s; QP status", np.bincount(nlp["status"], minlength=3))
-    assert conv[fast].mean() > 0.94, (conv[fast].mean(), np.bincount(nlp["status"]), np.sort(nlp["sqp_move"][fast])[-5:])
+    # Where does a local method have to converge?  Wherever the discrete model is a model: the reference integrates the tyre
+    # dynamics with RK4 at 25 ms, and below ~1.5 m/s the lateral dynamics are too stiff for that step -- the step map's
+    # Jacobian A_i has spectral radius up to ~25 PER STEP on the cold-start rollout (outside RK4's stability region; the
+    # continuous dynamics are stable).  The NLP's own rows are then an exploding recursion and neither this SQP nor the
+    # oracle's dense one need converge; such problems must say so (status / sqp_move), never report a converged point with a
+    # defect.  The class is a property of the problem data, computed here with the oracle's Jacobian: every start whose
+    # rollout keeps rho(A_i) <= 2 converges.
+    rho = np.zeros(len(x))
+    for b in range(len(x)):
+        A_, _, _ = Q.linearise(cfg, veh, S.problem(inp, b))
+        rho[b] = max(np.abs(np.linalg.eigvals(A_[i])).max() for i in range(A_.shape[0]))
+    model_ok = rho <= 2.0
+    print("full dynamics: converged", conv.mean(), "of all,", conv[model_ok].mean(), "of the", model_ok.sum(), "starts with rho(A) <= 2; slowest converged",
+          x[conv, 3].min(), "largest rho converged", rho[conv].max(), "; QP status", np.bincount(nlp["status"], minlength=3))
+    assert model_ok.sum() >= 60 and conv[model_ok].mean() >= 0.99, (conv[model_ok].mean(), np.bincount(nlp["status"]), np.sort(nlp["sqp_move"][model_ok])[-5:])
+    assert conv.mean() > 0.78
     assert nlp["defect"][conv].max() < 1e-7 and (nlp["sqp_iters"][conv] >= 2).all()
 
     def defect(o):
@@ -528,6 +536,31 @@ def test_full_dynamics_sqp_reaches_kkt_points_of_the_nlp(pkg):
     u_lo, u_hi, _, _ = Q.effective_bounds(cfg, veh)
     assert (nlp["U_optm"][:, :, conv] <= u_hi[:, None, None] + 1e-8).all() and (nlp["U_optm"][:, :, conv] >= u_lo[:, None, None] - 1e-8).all()
     assert (nlp["X_optm"][3, 1:-1][:, conv] >= cfg.x_min[3] - 1e-8).all()
+
+
+def test_full_dynamics_sqp_converges_wherever_the_model_is_stable(pkg):
+    """A second, larger unclipped sample for the class statement of the test above: of the starts whose cold-start rollout
+    stays inside RK4's stability region (rho(A_i) <= 2) at least 99 % reach a first-order point.  The QP's Hessian is the
+    cost's (no constraint curvature -- the QP kernel carries diagonal state weights), so the local rate is linear, not
+    IPOPT's quadratic one: most problems take 6..15 QPs, the tail needs up to ~150; max_sqp = 200 here (40 is the
+    facade's default for the node's first solve, a benign start)."""
+    veh, cfg, solver, tr, x, u = make(pkg, "barc20", 256, 3)
+    inp = S.cold_start_inputs(cfg, veh, tr, x, u, 0.025)
+    nlp = to_np(solver.solve_full_dynamics(inp, max_sqp=200, tol=1e-9))
+    conv = (nlp["status"] == 0) & (nlp["sqp_move"] <= 1e-8)
+    rho = np.zeros(len(x))
+    for b in range(len(x)):
+        A_, _, _ = Q.linearise(cfg, veh, S.problem(inp, b))
+        rho[b] = max(np.abs(np.linalg.eigvals(A_[i])).max() for i in range(A_.shape[0]))
+    model_ok = rho <= 2.0
+    q = np.quantile(nlp["sqp_iters"][conv & model_ok], [0.5, 0.9, 0.99])
+    print("full dynamics, 256 starts:", conv.mean(), "of all,", conv[model_ok].mean(), "of the", model_ok.sum(), "with rho(A) <= 2; QPs per converged problem: median",
+          q[0], "90 %", q[1], "99 %", q[2])
+    assert model_ok.sum() >= 150 and conv[model_ok].mean() >= 0.99, (conv[model_ok].mean(), np.sort(nlp["sqp_move"][model_ok])[-5:])
+    assert nlp["defect"][conv].max() < 1e-7
+    # a problem that stopped on a failed QP went through its back-offs first
+    failed = nlp["status"] != 0
+    assert (nlp["sqp_iters"][failed] >= 2).all()
 
 
 @pytest.mark.parametrize("key,vx0", [("iac40", 5.0), ("barc20", 1.5)])
