@@ -50,8 +50,10 @@ typedef enum lmpc_status {
 #define LMPC_SOLVE_OPTIMAL 0
 #define LMPC_SOLVE_MAX_ITER 1
 #define LMPC_SOLVE_INFEASIBLE 2 /* x_ic outside [x_min, x_max] at knot 0, row residual stalls, NaN */
-#define LMPC_SOLVE_UNVERIFIED 3 /* lmpc_solve_batch_mixed with lmpc_config.polish = 1 only: the fp32 iteration converged but its
-                                   polish was refused (the default two-pass solve re-solves these in fp64 and never reports 3) */
+#define LMPC_SOLVE_UNVERIFIED 3 /* lmpc_solve_batch_mixed with lmpc_config.polish = 1 only: the fp32 iteration did not reach an
+                                   answer it could verify -- polish refused, out of iterations, or infeasible by its
+                                   single-precision residuals (the default two-pass solve re-solves these in fp64, which has
+                                   the last word, and never reports 3) */
 
 /* vehicle_model_factory.cpp:31-49 -- same selector names; only the first is built */
 #define LMPC_MODEL_SINGLE_TRACK_PLANAR 0
@@ -109,9 +111,22 @@ typedef struct lmpc_config {
   double R_d[4];
   double x_max[LMPC_NX], x_min[LMPC_NX]; /* +-INFINITY allowed                              */
   double u_max[LMPC_NU], u_min[LMPC_NU];
-  double convex_hull_slack[LMPC_NX];
+  double convex_hull_slack[LMPC_NX]; /* cost weights of the hull residual x_T - SS lambda (racing_mpc.cpp:493-499); a zero
+                                        component leaves that component of the residual free; ALL zero is the hard
+                                        equality x_T = SS lambda of :500-502, see LMPC_HARD_HULL_WEIGHT            */
   double max_vel_ref_diff;
 } lmpc_config;
+
+/* Hard convex-hull equality (all-zero convex_hull_slack, racing_mpc.cpp:500-502).  The terminal block eliminates the hull
+ * residual eps = x_T - SS lambda through its weight (E^-1 in the Schur complement); the equality is the limit E^-1 -> 0,
+ * taken numerically: the residual carries the weight LMPC_HARD_HULL_WEIGHT, at which the answer is within 1e-7 (scaled)
+ * of the equality-constrained optimum (eps = multiplier / (2 weight); measured against the dense oracle with eps pinned
+ * to zero, tests/test_gpu_mixed_lmpc.py) and the two-level elimination still has two decades of headroom (it breaks down
+ * past 1e13).  A problem whose terminal state cannot reach the hull -- infeasible upstream -- is left with a residual the
+ * weight does not close: scaled |eps|_inf > LMPC_HARD_HULL_RESIDUAL reports LMPC_SOLVE_INFEASIBLE.  fp64 only: the
+ * single-precision and mixed entry points refuse it (LMPC_ERR_UNSUPPORTED). */
+#define LMPC_HARD_HULL_WEIGHT 1e11
+#define LMPC_HARD_HULL_RESIDUAL 1e-5
 
 /* Closed track as uniform periodic tables over [0, L): sample j sits at s = j*L/M.
  * Lookup is periodic linear interpolation.  (The reference interpolates cubic

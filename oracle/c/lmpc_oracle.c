@@ -217,6 +217,7 @@ typedef struct {
   /* LMPC terminal block */
   double ssx[6][SMAX], ssj[SMAX], chs2[6]; /* safe-set points CENTRED on ss0 = first point; 2*convex_hull_slack */
   double ss0[6];
+  int hard_hull; /* all-zero convex_hull_slack: the hull row is an equality, realised as the penalty limit */
   /* bounds per slot */
   double hi[NMAX][NSLOT], lo[NMAX][NSLOT];
   int act[NMAX][NSLOT][2]; /* [upper, lower] */
@@ -1333,6 +1334,13 @@ static int ipm_solve(prob_t* p, work_t* w, polish_t* pq, int* iters_out, double*
     kkt_out[2] = mu;
     kkt_out[3] = p->sigma;
   }
+  /* hard hull equality (penalty limit): a terminal state the hull cannot reach leaves a residual the weight does not close */
+  if (p->S && p->hard_hull && status == LMPC_SOLVE_OPTIMAL) {
+    static const double isc[6] = {1.0 / 2000.0, 1.0 / 10.0, 1.0 / 0.1, 1.0 / 80.0, 1.0 / 2.0, 1.0 / 2.0};
+    /* (eps_T is that of the final point: cost_gradient above) */
+    for (int k = 0; k < 6; ++k)
+      if (fabs(w->eps_T[k]) * isc[k] > LMPC_HARD_HULL_RESIDUAL) status = LMPC_SOLVE_INFEASIBLE;
+  }
   *iters_out = it + pol_rounds; /* a polish round costs about what an iteration does and is counted as one */
   return status;
 }
@@ -1386,8 +1394,11 @@ static void setup_problem(prob_t* p, const lmpc_config* cfg, const lmpc_vehicle*
     }
   p->qsig = 2.0 * cfg->q_boundary;
   if (p->S) {
+    int any_slack = 0;
+    for (int k = 0; k < 6; ++k) any_slack |= cfg->convex_hull_slack[k] > 0.0;
+    p->hard_hull = !any_slack; /* racing_mpc.cpp:500-502: x_T = SS lambda, no slack variable */
     for (int k = 0; k < 6; ++k) {
-      p->chs2[k] = 2.0 * cfg->convex_hull_slack[k];
+      p->chs2[k] = any_slack ? 2.0 * cfg->convex_hull_slack[k] : 2.0 * LMPC_HARD_HULL_WEIGHT;
       p->ss0[k] = ss_x[(size_t)(k * p->S) * B + b];
       for (int j = 0; j < p->S; ++j) p->ssx[k][j] = ss_x[(size_t)(k * p->S + j) * B + b] - p->ss0[k];
     }

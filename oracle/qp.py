@@ -150,8 +150,7 @@ def build_qp(cfg: MPCConfig, veh: Vehicle, inp: dict, ss_x=None, ss_j=None) -> D
         H[qp.isig, qp.isig] += 2 * cfg.q_boundary  # :539
     if learning:
         # build_lmpc_cost, :479-522
-        if not np.any(cfg.convex_hull_slack > 0):
-            raise NotImplementedError("hard convex-hull equality (all-zero convex_hull_slack)")
+        # all-zero convex_hull_slack: no slack variable, x_T = SS lambda (:500-502) -- eps is pinned to zero below
         for k in range(NX):
             H[qp.ieps + k, qp.ieps + k] += 2 * cfg.convex_hull_slack[k]
         h[qp.ilam: qp.ilam + S] += ss_j
@@ -189,6 +188,9 @@ def build_qp(cfg: MPCConfig, veh: Vehicle, inp: dict, ss_x=None, ss_j=None) -> D
             co = [(qp.ix(N - 1, k), 1.0), (qp.ieps + k, -1.0)]
             co += [(qp.ilam + j, -ss_x[k, j]) for j in range(S)]
             eq(co, 0.0)
+        if not np.any(cfg.convex_hull_slack > 0):
+            for k in range(NX):
+                eq([(qp.ieps + k, 1.0)], 0.0)
     qp.A = np.array(rowsA)
     qp.b = np.array(rhsb)
 

@@ -10,6 +10,8 @@ struct lmpc_params {
   void* save;  // device [batch][10 N - 4] doubles: where a polish attempt puts the iterate aside (handle-owned, lmpc_reserve)
   const int* launch_order;  // device [batch] or null: workgroup w solves problem launch_order[w] (set per launch by the host
                             // layer from lmpc_set_launch_order, only when the batch size matches the registered length)
+  const int* order_count;   // device scalar or null: only the first *order_count entries of launch_order are problems (the
+                            // fp64 second pass of a mixed solve: the list of problems the fp32 pass could not verify)
   int N;          // knot points
   int has_sigma;  // q_boundary > 0: one shared boundary slack (racing_mpc.cpp:529-539)
   int learning;   // LMPC terminal set + cost (racing_mpc.cpp:479-522)
@@ -33,6 +35,7 @@ struct lmpc_params {
   // two-pass mixed precision (set per launch by the host layer): the fp32 iteration marks a problem whose answer it could not
   // verify (polish refused) with LMPC_SOLVE_UNVERIFIED instead of OPTIMAL; lmpc_cleanup_kernel behind it solves those in fp64
   int flag_unverified;
+  int hard_hull;  // all-zero convex_hull_slack: chs2 = 2 LMPC_HARD_HULL_WEIGHT and the residual is checked at the exit
   int out_aos;  // lmpc_set_output_layout: results [batch][knot][component] instead of [component][knot][batch]
   lmpc_vehicle veh;
 };

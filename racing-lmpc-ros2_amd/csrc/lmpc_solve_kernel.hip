@@ -3003,8 +3003,20 @@ __device__ __forceinline__ void lmpc_solve_problem(
   if (it < 0) it = 0;
   it += pol_rounds;  // (a polish round costs about what an iteration does and is counted as one)
   if (!feasible) status = LMPC_SOLVE_INFEASIBLE;
-  // two-pass mixed precision: an answer the fp32 iteration could not verify is marked for the fp64 kernel behind it
-  if (P.flag_unverified && status == LMPC_SOLVE_OPTIMAL && polish_on && !polished) status = LMPC_SOLVE_UNVERIFIED;
+  if constexpr (KS > 0) {
+    // hard hull equality (the penalty limit, LMPC_HARD_HULL_WEIGHT): a terminal state the hull cannot reach leaves a
+    // residual the weight does not close -- the reference's QP is infeasible there
+    if (P.hard_hull && status == LMPC_SOLVE_OPTIMAL) {
+      wave_sync();
+      treal worst = 0;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) worst = fmax(worst, fabs(TT[TL_EPS + k]) * treal(slot_inv_scale(k)));
+      if (worst > treal(LMPC_HARD_HULL_RESIDUAL)) status = LMPC_SOLVE_INFEASIBLE;
+    }
+  }
+  // two-pass mixed precision: an answer the fp32 iteration could not verify -- or did not reach: out of iterations, or
+  // "infeasible" by single-precision residuals -- is marked for the fp64 kernel behind it, which has the last word
+  if (P.flag_unverified && (status != LMPC_SOLVE_OPTIMAL || (polish_on && !polished))) status = LMPC_SOLVE_UNVERIFIED;
 
   // ---------------- write back: X [6][N][B], U, dU [2][N-1][B] ----------------
   wave_sync();
@@ -3058,7 +3070,10 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
   // w takes problem launch_order[w]: the hardware starts workgroups in index order, so the long problems go first and the
   // short ones fill the tail of the second residency round.
   int b = (int)(blockIdx.x & 7) * ((B + 7) >> 3) + (int)(blockIdx.x >> 3);
-  if (P.launch_order) b = (int)blockIdx.x < B ? P.launch_order[blockIdx.x] : B;
+  if (P.launch_order) {
+    const int n = P.order_count ? *P.order_count : B;  // (a list: the workgroups past its end have nothing to do)
+    b = (int)blockIdx.x < n ? P.launch_order[blockIdx.x] : B;
+  }
   if (b >= B) return;
   lmpc_solve_problem<real, KQ, KS, io>(P, B, b, lds_raw, ws_lin, x_ic, u_ic, T_ref, bl, br, vref, ss_x, ss_j, lam_out, X_out, U_out,
                                        dU_out, status_out, iters_out, kkt_out);
@@ -3068,6 +3083,22 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
 // LMPC_SOLVE_UNVERIFIED, solved in fp64.  `list` [count] holds them (lmpc_collect_unverified_kernel); a small fixed grid
 // of workgroups takes list entries in turn -- launching one workgroup per problem of the batch to have 99 % of them
 // return at once costs more than the solves (38 KB of LDS and 500 registers to allocate per workgroup: 1.3 ms per 8192).
+// The solve is a CALL here, not inlined into the loop: with the 3000-line body inlined under a loop the <double, 7, 3>
+// instance computed garbage (nondeterministically; the same body without the loop, or called once per workgroup, is bit
+// for bit the direct kernel -- scratch/r3_cleanup_dbg.py); behind a call boundary every instance is.  The callee names the
+// workgroup's dynamic LDS block itself, so its accesses stay in the LDS address space.
+template <typename real, int KQ, int KS, typename io>
+__device__ __attribute__((noinline)) void lmpc_solve_problem_call(
+    const lmpc_params& P, const int B, const int b, const io* __restrict__ ws_lin, const io* __restrict__ x_ic,
+    const io* __restrict__ u_ic, const io* __restrict__ T_ref, const io* __restrict__ bl, const io* __restrict__ br,
+    const io* __restrict__ vref, const io* __restrict__ ss_x, const io* __restrict__ ss_j, io* __restrict__ lam_out,
+    io* __restrict__ X_out, io* __restrict__ U_out, io* __restrict__ dU_out, int* __restrict__ status_out,
+    int* __restrict__ iters_out, io* __restrict__ kkt_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  lmpc_solve_problem<real, KQ, KS, io>(P, B, b, lds_raw, ws_lin, x_ic, u_ic, T_ref, bl, br, vref, ss_x, ss_j, lam_out, X_out, U_out,
+                                       dU_out, status_out, iters_out, kkt_out);
+}
+
 template <typename real, int KQ, int KS, typename io>
 __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void lmpc_cleanup_kernel(
     lmpc_params P, int B, const int* __restrict__ list, const int* __restrict__ count, const io* __restrict__ ws_lin,
@@ -3076,11 +3107,11 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
     const io* __restrict__ ss_j, io* __restrict__ lam_out, io* __restrict__ X_out,
     io* __restrict__ U_out, io* __restrict__ dU_out, int* __restrict__ status_out,
     int* __restrict__ iters_out, io* __restrict__ kkt_out) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  const int n = *count;
+  const int n = __builtin_amdgcn_readfirstlane(*count);
   for (int w = blockIdx.x; w < n; w += gridDim.x) {
-    lmpc_solve_problem<real, KQ, KS, io>(P, B, list[w], lds_raw, ws_lin, x_ic, u_ic, T_ref, bl, br, vref, ss_x, ss_j, lam_out, X_out,
-                                         U_out, dU_out, status_out, iters_out, kkt_out);
+    const int b = __builtin_amdgcn_readfirstlane(list[w]);  // (wave-uniform: keep the problem index in a scalar register)
+    lmpc_solve_problem_call<real, KQ, KS, io>(P, B, b, ws_lin, x_ic, u_ic, T_ref, bl, br, vref, ss_x, ss_j, lam_out, X_out, U_out, dU_out,
+                                              status_out, iters_out, kkt_out);
     wave_fence();
   }
 }

@@ -82,4 +82,5 @@ if __name__ == "__main__":
     if "trk80" in which: case("barc", 80, 4096)
     if "trk48" in which: case("barc", 48, 4096)
     if "lmpc" in which: case("lmpc", 20, 4096, ("f64", "mixed")); case("lmpc", 20, 32768, ("f64", "mixed"))
+    if "lmpc40" in which: case("lmpc", 40, 4096, ("f64", "mixed"))
     if "iac" in which: case("iac", 40, 8192, ("f64", "mixed", "f32"))

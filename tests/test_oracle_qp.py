@@ -100,3 +100,33 @@ def test_zero_components_of_the_hull_slack_weight(golden):
         assert np.abs((out["X_optm"][:, :, b] - ex["X_optm"]) / P.SCALE_X[:, None]).max() < 2e-6, b
         assert np.abs((out["U_optm"][:, :, b] - ex["U_optm"]) / P.SCALE_U[:, None]).max() < 2e-6, b
         assert np.abs(ex["X_optm"][:, :, ] - g["X_optm"][:, :, b]).max() > 1e-6      # and it is a different problem
+
+
+def test_hard_convex_hull_equality_twin_against_dense():
+    """All-zero convex_hull_slack (racing_mpc.cpp:500-502: x_T = SS lambda, no slack).  Dense QP: the residual pinned to
+    zero by six equality rows.  Twin: the penalty limit LMPC_HARD_HULL_WEIGHT of its terminal elimination -- within 1e-7 of
+    the equality-constrained optimum wherever that exists; not OPTIMAL where the hull cannot be reached."""
+    import dataclasses
+    import lmpc_scenario as LS
+    veh, cfg, tr, laps, inp, q = LS.make(24, 5)
+    ss_x, ss_j, _ = LS.oracle_safe_set(cfg, laps, q)
+    hard = dataclasses.replace(cfg, convex_hull_slack=np.zeros(6))
+    tw = cbind.solve_batch(hard, veh, inp, ss_x, ss_j)
+    n_ok = 0
+    for b in range(24):
+        qp = Q.build_qp(hard, veh, S.problem(inp, b), ss_x=ss_x[:, :, b], ss_j=ss_j[:, b])
+        try:
+            y, info = Q.solve_dense(qp)
+        except np.linalg.LinAlgError:
+            info = {"status": 9}
+        if info["status"] != 0:
+            assert tw["status"][b] != 0, b
+            continue
+        ex = qp.split(y)
+        assert tw["status"][b] == 0, b
+        assert np.abs((tw["X_optm"][:, :, b] - ex["X_optm"]) / P.SCALE_X[:, None]).max() < 2e-7, b
+        assert np.abs((tw["U_optm"][:, :, b] - ex["U_optm"]) / P.SCALE_U[:, None]).max() < 2e-7, b
+        eps = tw["X_optm"][:, -1, b] - ss_x[:, :, b] @ tw["convex_combi_optm"][:, b]
+        assert np.abs(eps / P.SCALE_X).max() < 1e-7
+        n_ok += 1
+    assert n_ok >= 15
