@@ -189,9 +189,14 @@ int lmpc_solve_batch(lmpc_handle* h, int32_t batch, const double* x_ic, const do
  * block (racing_mpc.cpp:484-504).  In fp32: the stage records in LDS, the Riccati factor and sweeps and the stage rows --
  * half the LDS footprint, so twice the resident problems per CU where fp64 is capacity-bound.  Horizons: every N the
  * fp64 entry accepts for the tracking problem (iac_car_tracking_mpc.param.yaml ships N = 80); N <= 23 for the learning
- * problem (longer: LMPC_ERR_UNSUPPORTED, the fp64 entry serves them).  Stated accuracy: 1e-3 (scaled) of the fp64
- * answer on every problem; fit for well-scaled problems (IAC) and for the learning problem, NOT for the BARC tracking
- * problem at low speed, whose soft boundary needs complementarity below 1e-9. */
+ * problem (longer: LMPC_ERR_UNSUPPORTED, the fp64 entry serves them; so does the hard hull equality).
+ * Two passes when lmpc_config.polish = 0 (the default): the fp32 kernel ends with the active-set polish and a KKT test of
+ * its answer (rows 1e-5, multipliers -1e-3, last step 1e-4, scaled); every problem whose answer did not pass -- polish
+ * refused, out of iterations, infeasible by single-precision residuals -- is solved again by the fp64 kernel behind it,
+ * which writes the fp64 entry's own answer and status over it (a percent of a batch).  Stated accuracy: 1e-3 (scaled) of
+ * the fp64 answer on every problem; fit for well-scaled problems (IAC) and for the learning problem, NOT for the BARC
+ * tracking problem at low speed, whose soft boundary needs complementarity below 1e-9.
+ * polish < 0: one pass, the fp32 interior point's own answers (faster, a tail of problems up to 3e-2 away). */
 int lmpc_solve_batch_mixed(lmpc_handle* h, int32_t batch, const double* x_ic, const double* u_ic,
                            const double* X_ref, const double* U_ref, const double* T_ref,
                            const double* bound_left, const double* bound_right, const double* curvatures,
@@ -203,7 +208,10 @@ int lmpc_solve_batch_mixed(lmpc_handle* h, int32_t batch, const double* x_ic, co
  * array in float and the interior point / Riccati recursion in fp32 (the linearisation is evaluated in fp64 and
  * rounded).  Same layouts and meaning as lmpc_solve_batch, no safe-set arguments; kkt [4][B] optional.  The abscissa
  * is carried relative to x_ic[0] inside the kernel (the QP is invariant to that shift), so a 2.8 km lap keeps its
- * resolution.  Stopping rule: complementarity <= max(tol, 2e-6), row residuals <= 1e-4. */
+ * resolution.  Stopping rule: complementarity <= max(tol, 2e-6), row residuals <= 1e-4, then the active-set polish in
+ * fp32 (lmpc_config.polish >= 0).  There is no fp64 pass behind this entry (its arrays are float): an answer the polish
+ * could not verify keeps status OPTIMAL at the interior point's accuracy.  Measured against fp64 on the IAC problem:
+ * worst 4.6e-4 (scaled). */
 int lmpc_solve_batch_f32(lmpc_handle* h, int32_t batch, const float* x_ic, const float* u_ic, const float* X_ref,
                          const float* U_ref, const float* T_ref, const float* bound_left, const float* bound_right,
                          const float* curvatures, const float* vel_ref, float* X_optm, float* U_optm, float* dU_optm,
