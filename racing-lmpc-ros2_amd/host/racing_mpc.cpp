@@ -21,7 +21,7 @@ double align_abscissa(double s1, double s2, double s_total) {
 
 RacingMPC::RacingMPC(RacingMPCConfig::SharedPtr mpc_config, VehicleModel::SharedPtr model, const bool& full_dynamics,
                      int device)
-    : config_(mpc_config), model_(model), full_dynamics_(full_dynamics), solved_(false), h_(nullptr) {
+    : config_(mpc_config), model_(model), full_dynamics_(full_dynamics), solved_(false), ran_(false), h_(nullptr) {
   if (!config_ || !model_) throw std::invalid_argument("RacingMPC: null config or model");
   if (model_->name != "single_track_planar_model")
     throw std::runtime_error("RacingMPC: vehicle model '" + model_->name + "' is not built");
@@ -65,9 +65,18 @@ void RacingMPC::solve(const DMDict& in, DMDict& out, Dict& stats) {
   const DM& bound_right = in.at("bound_right");
   const DM& curvatures = in.at("curvatures");
   const DM& vel_ref = in.at("vel_ref");
-  // warm start keys are accepted; the interior-point solve does not use a primal warm start, but
-  // T_optm_ref replaces T_ref exactly as upstream (racing_mpc.cpp:293-315)
-  const DM& T = in.count("X_optm_ref") ? in.at("T_optm_ref") : in.at("T_ref");
+  // Warm start (racing_mpc.cpp:287-327).  With the keys: all four are required (upstream reads them with at()), and
+  // T_optm_ref replaces T_ref.  Without them upstream restarts from its own previous solution -- and throws when there is
+  // none.  The interior-point solve does not use a primal warm start, so only the contract is kept: the keys are
+  // checked, and a controller that has never run its solver refuses a call without them.
+  const bool warm = in.count("X_optm_ref") > 0;
+  if (warm) {
+    (void)in.at("U_optm_ref");
+    (void)in.at("dU_optm_ref");
+  } else if (!ran_) {
+    throw std::runtime_error("No warm start given and no previous solution found.");
+  }
+  const DM& T = warm ? in.at("T_optm_ref") : in.at("T_ref");
   if (X_ref.rows != 6 || X_ref.cols != N || U_ref.rows != 2 || U_ref.cols != N - 1 || T.data.size() != N - 1 ||
       bound_left.data.size() != N || bound_right.data.size() != N || curvatures.data.size() != N ||
       vel_ref.data.size() != N || x_ic.data.size() != 6 || u_ic.data.size() != 2)
@@ -119,6 +128,7 @@ void RacingMPC::solve(const DMDict& in, DMDict& out, Dict& stats) {
       return;
     }
     total_iters = iters;
+    ran_ = true;
     stats["sqp_iter_count"] = static_cast<double>(sqp_iters);
     stats["dynamics_defect"] = defect;
     if (status == LMPC_SOLVE_OPTIMAL && !(move <= 1e-8)) status = LMPC_SOLVE_MAX_ITER;
@@ -133,6 +143,7 @@ void RacingMPC::solve(const DMDict& in, DMDict& out, Dict& stats) {
       return;
     }
     total_iters = iters;
+    ran_ = true;  // upstream: sol_ is set whenever solve_limited() returned (racing_mpc.cpp:343-345)
   }
   stats["iter_count"] = static_cast<double>(total_iters);
   if (status != LMPC_SOLVE_OPTIMAL) {

@@ -67,7 +67,9 @@ class RacingMPC {
 
   const RacingMPCConfig& get_config() const;
   // Same contract as the reference: on solver failure a message goes to std::cerr, `out` lacks
-  // "X_optm" and solved() is unchanged (racing_mpc.cpp:343-371); missing keys throw std::out_of_range.
+  // "X_optm" and solved() is unchanged (racing_mpc.cpp:343-371); missing keys throw std::out_of_range.  Warm start keys
+  // (X_optm_ref, U_optm_ref, dU_optm_ref, T_optm_ref): all or none; none on a controller whose solver has never run throws
+  // std::runtime_error("No warm start given and no previous solution found.") as upstream does (:310-313).
   void solve(const DMDict& in, DMDict& out, Dict& stats);
   // racing_mpc.cpp:374-430: throws std::length_error / std::range_error on the same conditions.
   void create_warm_start(const DMDict& in, DMDict& out);
@@ -79,6 +81,7 @@ class RacingMPC {
   VehicleModel::SharedPtr model_;
   bool full_dynamics_;
   bool solved_;
+  bool ran_;  // the solver has produced a solution object before (upstream's sol_ != nullptr)
   lmpc_handle* h_;
   // LMPC (config.learning): the safe set and its recorder, as racing_mpc.hpp:88-90 upstream
   std::unique_ptr<lmpc::vehicle_model::racing_trajectory::SafeSetManager> ss_manager_;

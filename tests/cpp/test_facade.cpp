@@ -50,6 +50,16 @@ int main(int argc, char** argv) {
   in["total_length"] = DM(15.6);
   DM Xe = read_dm(f), Ue = read_dm(f);
   if (mpc.solved()) return 3;
+  {  // racing_mpc.cpp:310-313: no warm start and no previous solution -> std::runtime_error
+    bool refused = false;
+    try { mpc.solve(in, out, stats); } catch (const std::runtime_error&) { refused = true; }
+    if (!refused || mpc.solved()) { std::puts("FAIL: a first call without warm start keys must throw"); return 1; }
+  }
+  // the node's first call (racing_mpc_node.cpp:225-234): the reference doubles as the warm start
+  in["X_optm_ref"] = in["X_ref"];
+  in["U_optm_ref"] = in["U_ref"];
+  in["dU_optm_ref"] = DM(2, static_cast<std::size_t>(N) - 1);
+  in["T_optm_ref"] = in["T_ref"];
   mpc.solve(in, out, stats);
   if (!out.count("X_optm") || !mpc.solved()) { std::puts("FAIL: no X_optm"); return 1; }
   const double sx[6] = {2000.0, 10.0, 0.1, 80.0, 2.0, 2.0}, su[2] = {10.0, 0.3};
@@ -64,6 +74,15 @@ int main(int argc, char** argv) {
   in2["x_ic"](3, 0) = 0.01;
   mpc.solve(in2, out2, stats);
   if (out2.count("X_optm")) { std::puts("FAIL: infeasible problem returned X_optm"); return 1; }
+  // once a solution exists a call without the warm start keys goes through (upstream restarts from sol_)
+  {
+    DMDict in4 = in, out4;
+    for (const char* k : {"X_optm_ref", "U_optm_ref", "dU_optm_ref", "T_optm_ref"}) in4.erase(k);
+    mpc.solve(in4, out4, stats);
+    if (!out4.count("X_optm")) { std::puts("FAIL: solve without warm start keys after a first solution"); return 1; }
+    for (std::size_t e = 0; e < out4["X_optm"].data.size(); ++e)
+      if (out4["X_optm"].data[e] != out["X_optm"].data[e]) { std::puts("FAIL: warm start keys changed the answer"); return 1; }
+  }
   // missing key throws like DMDict::at
   bool threw = false;
   try { DMDict in3 = in; in3.erase("u_ic"); mpc.solve(in3, out2, stats); } catch (const std::out_of_range&) { threw = true; }

@@ -56,6 +56,11 @@ int main(int argc, char** argv) {
   in["t_ic"] = DM(0.0);
   in["total_length"] = DM(L);
   DM Xe = read_dm(f), Ue = read_dm(f), ssx = read_dm(f), ssj = read_dm(f);
+  // warm start keys as the node hands them (racing_mpc_node.cpp:225-234); without them a first call throws
+  in["X_optm_ref"] = in["X_ref"];
+  in["U_optm_ref"] = in["U_ref"];
+  in["dU_optm_ref"] = DM(2, in["U_ref"].cols);
+  in["T_optm_ref"] = in["T_ref"];
   mpc.solve(in, out, stats);
   if (!out.count("X_optm") || !out.count("convex_combi_optm") || !out.count("ss_x")) { std::puts("FAIL: outputs missing"); return 1; }
   // the safe set the facade found = the oracle's (points identical, costs up to the J[0] offset the solver removes)
