@@ -47,6 +47,7 @@ struct lmpc_params {
 // learning: the terminal region behind the records -- always fp64 cells, whatever the records' type: the terminal-block
 // scratch (lmpc_solve_kernel.hip TL_*) and the (centred) safe-set points [6][64 KS], KS = 2 up to 128 points, 3 up to 192
 #define LMPC_TERM_CELLS 236
+#define LMPC_SS_STRIDE(S) ((S) + 1)  // safe-set points kept behind the terminal cells, 6 cells each: S of them + one zero point
 #define LMPC_LIN_RECORD 54  // per stage in the linearisation workspace: ABt[8][6] | g[6]
 
 // the lean layout (fp64, N > 40; lmpc_solve_kernel.hip): stage records without the stage model, which is streamed
@@ -61,7 +62,8 @@ static inline size_t lmpc_lds_bytes(int N, int learning, int S, int real_bytes) 
   const int lean = lmpc_is_lean(N, real_bytes);
   const size_t records = (size_t)((N - 1) * (lean ? LMPC_LEAN_STAGE_STRIDE : LMPC_STAGE_STRIDE) + N * LMPC_KNOT_STRIDE + LMPC_TAIL_DOUBLES) *
                          (size_t)real_bytes;
-  return records + (learning ? (size_t)(LMPC_TERM_CELLS + 6 * 64 * ks) * 8 : 0) + (lean ? (size_t)2 * LMPC_LEAN_CHUNK * LMPC_LIN_RECORD * 8 : 0);
+  (void)ks;
+  return records + (learning ? (size_t)(LMPC_TERM_CELLS + 6 * LMPC_SS_STRIDE(S)) * 8 : 0) + (lean ? (size_t)2 * LMPC_LEAN_CHUNK * LMPC_LIN_RECORD * 8 : 0);
 }
 
 #endif

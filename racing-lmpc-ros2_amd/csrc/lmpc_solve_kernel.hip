@@ -121,7 +121,7 @@ struct Prof {};
 #define TL_XA 222    // their step d lambda_A (read back by the owner lanes)
 #define TL_S11 228   // s11 = 1'M^-1 1
 #define TL_E 230     // E = 2 convex_hull_slack (exact, whatever `real` is)
-#define TL_UL 236    // the (centred) safe-set points, [6][64 KS]
+#define TL_UL 236    // the (centred) safe-set points, point-major [S][6]
 #define MA_MAX 4       // explicit points at most (the smallest theta below tau); supports of 1-3 points are what occurs
 #define TAU_REL 1e-5   // tau = TAU_REL * max_j u_j'E u_j: cond(F_B) <= ~1e5 whatever the iteration does
 #define STALL_MU 1e-9  // complementarity below which a step that does not lower it ends the solve
@@ -737,11 +737,15 @@ struct SimplexRows {
   int aidx[KS];  // slot of the point among the explicit ones of this iteration, -1: eliminated through 1/theta
   real lm[KS], t[KS], l[KS], p[KS], j[KS], dl[KS];
   real sv[KS];  // lambda at the start of a polish (restored when it is refused)
-  const real* ul;  // the (centred) points in LDS, component k of point j at ul[k * 64 KS + j]: read-only after the load, 36
-                   // registers (KS = 3) the iteration's row state needs more -- consecutive lanes read consecutive cells
+  const real* ul;  // the (centred) points in LDS, point-major: component k of point j at ul[6 j + k], S points -- read-only
+                   // after the load, 36 registers (KS = 3) the iteration's row state needs more.  A point is 48 bytes = three
+                   // 16-byte reads; 16 consecutive lanes at a 48-byte stride cover all 64 banks once, so the reads are
+                   // conflict-free.  A lane slot past S reads the zero point stored behind the last one (uz[q] = its index).
+  int uz[KS];      // 6 * (index of the point this lane's slot q reads)
   __device__ __forceinline__ void load_u(int q, int lane, real (&u)[6]) const {
+    const real* p = ul + uz[q];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) u[k] = ul[k * 64 * KS + lane + 64 * q];
+    for (int k = 0; k < 6; ++k) u[k] = p[k];
   }
   real ss0[6];
   real r1;   // 1 - 1'lambda
@@ -1682,7 +1686,7 @@ __device__ __forceinline__ void lmpc_solve_problem(
   if constexpr (LEAN) {
     static_assert(!LEAN || (std::is_same<real, double>::value && std::is_same<io, double>::value), "the lean layout streams the fp64 workspace as it is");
     MS.ws = reinterpret_cast<const real*>(ws_lin) + (size_t)b * NS * LMPC_LIN_RECORD;
-    MS.buf = reinterpret_cast<real*>(reinterpret_cast<unsigned char*>(TT) + (KS > 0 ? (LMPC_TERM_CELLS + 6 * 64 * KS) * sizeof(treal) : 0));
+    MS.buf = reinterpret_cast<real*>(reinterpret_cast<unsigned char*>(TT) + (KS > 0 ? (LMPC_TERM_CELLS + 6 * LMPC_SS_STRIDE(P.S)) * sizeof(treal) : 0));
   }
   const treal tinf = treal(INFINITY);
   PT_DECL
@@ -1822,8 +1826,11 @@ __device__ __forceinline__ void lmpc_solve_problem(
     for (int q = 0; q < KS; ++q) {
       const int j = lane + 64 * q;
       sx.on[q] = j < S;
+      sx.uz[q] = 6 * (sx.on[q] ? j : S);
 #pragma unroll
-      for (int k = 0; k < 6; ++k) UL[k * 64 * KS + j] = sx.on[q] ? treal(ss_x[((size_t)k * S + j) * B + b] - c0[k]) : treal(0);
+      for (int k = 0; k < 6; ++k)
+        if (sx.on[q]) UL[6 * j + k] = treal(ss_x[((size_t)k * S + j) * B + b] - c0[k]);
+      if (q == 0 && lane < 6) UL[6 * S + lane] = treal(0);  // the zero point
       sx.j[q] = sx.on[q] ? treal(ss_j[(size_t)j * B + b]) : treal(0);
       sx.lm[q] = sx.on[q] ? 1.0 / S : 0.0;
       sx.t[q] = sx.on[q] ? 1.0 / S : 1.0;
