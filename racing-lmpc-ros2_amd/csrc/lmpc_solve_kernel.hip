@@ -48,6 +48,9 @@
 // resident waves per SIMD the register allocation is sized for: the fp64 tracking kernels up to N = 23 and every fp32
 // kernel up to N = 40 run two (three for fp32, N <= 23); the fp64 LMPC and long-horizon kernels need the full file
 constexpr int lmpc_waves_per_simd(int real_bytes, int kq, int ks) {
+#ifdef LMPC_EXP_F32_LMPC_1WAVE
+  if (real_bytes == 4 && ks > 0) return 1;
+#endif
   return real_bytes == 4 ? ((kq <= 4 && ks == 0) ? OCCF : (kq <= 7 ? 2 : 1)) : ((ks == 0 && kq <= 4) ? 2 : 1);
 }
 

@@ -79,6 +79,8 @@ if __name__ == "__main__":
     if "trk20" in which: case("barc", 20, 4096); case("barc", 20, 65536)
     if "trk40" in which: case("barc", 40, 4096)
     if "trk60" in which: case("barc", 60, 4096)
+    if "trkmix" in which:
+        for n in (20, 40, 60, 80): case("barc", n, 4096, ("f64", "mixed"))
     if "trk80" in which: case("barc", 80, 4096)
     if "trk48" in which: case("barc", 48, 4096)
     if "lmpc" in which: case("lmpc", 20, 4096, ("f64", "mixed")); case("lmpc", 20, 32768, ("f64", "mixed"))

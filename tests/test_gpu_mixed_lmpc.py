@@ -168,4 +168,13 @@ def test_learning_problem_at_full_size_in_fp64(pkg):
         qp = Q.build_qp(P.barc_lmpc(20, 5), P.barc_vehicle(), S.problem(npinp, int(b)), ss_x=ss_x.cpu().numpy()[:, :, b], ss_j=ss_j.cpu().numpy()[:, b])
         _, info = Q.solve_dense(qp)
         assert info["status"] != 0, (int(b), int(o["status"][b]), "kernel failed where the dense solver succeeds")
-    print("learning problem at full size: solved %.5f, degenerate among the sample %.2f" % (ok.mean(), frac))
+    # EVERY problem of the batch against the serial twin: same statuses, answers within the twin tolerance
+    from oracle import cbind
+    from tolerances import TOL_TWIN
+    tw = cbind.solve_batch(P.barc_lmpc(20, 5), P.barc_vehicle(), npinp, ss_x.cpu().numpy(), ss_j.cpu().numpy())
+    both = ok & (tw["status"] == 0)
+    assert (ok == (tw["status"] == 0)).mean() > 0.999, (np.bincount(tw["status"]), np.bincount(o["status"]))
+    e, ed = per_problem_err({k: o[k][..., both] for k in ("X_optm", "U_optm", "dU_optm")}, {k: tw[k][..., both] for k in ("X_optm", "U_optm", "dU_optm")})
+    print("learning problem at full size: solved %.5f, degenerate among the sample %.2f; against the twin on all %d: %.1e / dU %.1e"
+          % (ok.mean(), frac, both.sum(), e.max(), ed.max()))
+    assert e.max() < TOL_TWIN and ed.max() < TOL_TWIN, (e.max(), ed.max())
