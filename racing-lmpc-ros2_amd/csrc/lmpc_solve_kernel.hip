@@ -48,9 +48,6 @@
 // resident waves per SIMD the register allocation is sized for: the fp64 tracking kernels up to N = 23 and every fp32
 // kernel up to N = 40 run two (three for fp32, N <= 23); the fp64 LMPC and long-horizon kernels need the full file
 constexpr int lmpc_waves_per_simd(int real_bytes, int kq, int ks) {
-#ifdef LMPC_EXP_F32_LMPC_1WAVE
-  if (real_bytes == 4 && ks > 0) return 1;
-#endif
   return real_bytes == 4 ? ((kq <= 4 && ks == 0) ? OCCF : (kq <= 7 ? 2 : 1)) : ((ks == 0 && kq <= 4) ? 2 : 1);
 }
 
@@ -796,19 +793,24 @@ struct ModelStream {
   __device__ __forceinline__ void ensure(int ch) {
     if ((ch & 1 ? have1 : have0) != ch) fetch(ch);
   }
-  // chunk ch -> buffer (ch & 1), asynchronously: 16 bytes per lane per instruction, the wave's lanes in address order
+  // chunk ch -> buffer (ch & 1), asynchronously: 16 bytes per lane per instruction, the wave's lanes in address order.
+  // ONE per-lane address and one LDS base for the whole chunk, the instruction's immediate offset (applied to both sides)
+  // steps through it: with an address per instruction the compiler kept seven 64-bit addresses per call site alive,
+  // spilled them, and every copy then waited (vmcnt counts the reload and the copies alike) for the one before it.
   __device__ __forceinline__ void fetch(int ch) {
     if (ch & 1) have1 = ch; else have0 = ch;
     const int lo = ch * LN_CHUNK * LN_REC;
     const int n = min(LN_CHUNK * LN_REC, NS * LN_REC - lo);
     real* const dst = buf + (ch & 1) * LN_CHUNK * LN_REC;
-#pragma unroll
-    for (int j = 0; j < (LN_CHUNK * LN_REC + 127) / 128; ++j) {
-      const int e = 128 * j + 2 * lane;
-      if (e < n)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ws + lo + e),
-                                         (__attribute__((address_space(3))) void*)(dst + 128 * j), 16, 0, 0);
-    }
+    const real* const src = ws + lo + 2 * lane;
+    const int e = 2 * lane;
+    static_assert(sizeof(real) == 8 && (LN_CHUNK * LN_REC + 127) / 128 == 4, "four 1 KB slices per chunk");
+#define LMPC_GLDS(J)                                                                                                   \
+  if (e + 128 * J < n)                                                                                                 \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,                               \
+                                     (__attribute__((address_space(3))) void*)dst, 16, 1024 * J, 0);
+    LMPC_GLDS(0) LMPC_GLDS(1) LMPC_GLDS(2) LMPC_GLDS(3)
+#undef LMPC_GLDS
   }
   // every copy issued so far has landed (vmcnt counts them), and no later LDS read moves ahead of this point
   __device__ __forceinline__ void wait() const {
@@ -1561,12 +1563,16 @@ __device__ __forceinline__ void riccati_solve_lean(const Lds<real>& L, ModelStre
   M.wait();
   if (nch > 1) M.ensure(1);
   const int cb = r < 6 ? r : 0;  // (lanes 6, 7: the model operands are not used)
+  const int cstride = r < 6 ? 6 : 2;
   real col[8], a0, b0n, b1n;
   auto load_stage = [&](int i) {
     const real* ab = M.stage(i);
     const real* st = L.st(i);
+    {  // one base and one stride per lane (state rows: the chunk slot, stride 6; rows of K: the stage record, stride 2)
+      const real* const cbase = r < 6 ? ab + cb : st + (r - 6);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) col[k] = r < 6 ? ab[6 * k + cb] : st[2 * k + (r - 6)];
+      for (int k = 0; k < 8; ++k) col[k] = cbase[k * cstride];
+    }
     a0 = st[LN_KFF(s) + (r & 1)];
     b0n = ab[36 + cb];
     b1n = ab[42 + cb];

@@ -7,7 +7,8 @@ from __graft_entry__ import load_package
 pkg = load_package()
 import importlib
 capi = importlib.import_module(pkg.__name__ + ".capi")
-capi.library_path = lambda: ROOT / "racing-lmpc-ros2_amd" / "lib" / "liblmpc_hip_prof.so"
+import os
+capi.library_path = lambda: Path(os.environ.get("LMPC_PROF_LIB", str(ROOT / "racing-lmpc-ros2_amd" / "lib" / "liblmpc_hip_prof.so")))
 capi._LIB = None
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
