@@ -798,6 +798,7 @@ struct ModelStream {
   // steps through it: with an address per instruction the compiler kept seven 64-bit addresses per call site alive,
   // spilled them, and every copy then waited (vmcnt counts the reload and the copies alike) for the one before it.
   __device__ __forceinline__ void fetch(int ch) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (no LDS read of the buffer about to be overwritten is still in flight)
     if (ch & 1) have1 = ch; else have0 = ch;
     const int lo = ch * LN_CHUNK * LN_REC;
     const int n = min(LN_CHUNK * LN_REC, NS * LN_REC - lo);
@@ -817,8 +818,9 @@ struct ModelStream {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     wave_fence();
   }
-  __device__ __forceinline__ const real* stage(int i) const {
-    return buf + ((i / LN_CHUNK) & 1) * LN_CHUNK * LN_REC + (i % LN_CHUNK) * LN_REC;
+  __device__ __forceinline__ const real* stage(int i) const {  // (i is wave-uniform: keep the slot arithmetic on the scalar unit)
+    const int off = __builtin_amdgcn_readfirstlane(((i / LN_CHUNK) & 1) * LN_CHUNK * LN_REC + (i % LN_CHUNK) * LN_REC);
+    return buf + off;
   }
 };
 
@@ -1519,7 +1521,14 @@ __device__ __forceinline__ void riccati_solve_lean(const Lds<real>& L, ModelStre
   for (int i = N - 2; i >= 0; --i) {
     real* st = L.st(i);
     const real* kn = L.kn(i);
-    const bool cross = (i % LN_CHUNK) == 0 && i > 0;
+    // a chunk's last stage looks ahead into the next chunk: wait for it (fetched a chunk ago) and start the copy of the
+    // one after it into the buffer this stage no longer reads (its own operands are in registers since the stage before).
+    // At the TOP of the body, where the loop header is a block boundary anyway: a branch in mid-stage makes the compiler
+    // drain every LDS read in flight there, and the look-ahead loses its overlap.
+    if ((i % LN_CHUNK) == 0 && i > 0) {
+      M.wait();
+      if (i / LN_CHUNK >= 2) M.fetch(i / LN_CHUNK - 2);
+    }
     real pb[6];
 #pragma unroll
     for (int k = 0; k < 6; ++k) pb[k] = pvec[k];
@@ -1536,14 +1545,9 @@ __device__ __forceinline__ void riccati_solve_lean(const Lds<real>& L, ModelStre
     spread2(w, w6, w7);
     ISSUE_ORDER();
     {
-      if (cross) M.wait();
       const real* abn = M.stage(i > 0 ? i - 1 : 0);
 #pragma unroll
       for (int k = 0; k < 6; ++k) row[k] = abn[6 * r + k];
-      if (cross && i / LN_CHUNK >= 2) {
-        wave_fence();
-        M.fetch(i / LN_CHUNK - 2);
-      }
     }
     ISSUE_ORDER();
     const real hv0 = rfma(t, w6, qv0);
@@ -1582,7 +1586,10 @@ __device__ __forceinline__ void riccati_solve_lean(const Lds<real>& L, ModelStre
   for (int i = 0; i < N - 1; ++i) {
     const real* st = L.st(i);
     real* kn = L.kn(i);
-    const bool cross = (i % LN_CHUNK) == LN_CHUNK - 1 && i < N - 2;
+    if ((i % LN_CHUNK) == LN_CHUNK - 1 && i < N - 2) {  // (see the backward sweep)
+      M.wait();
+      if (i / LN_CHUNK + 2 < nch) M.fetch(i / LN_CHUNK + 2);
+    }
     real dz[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) dz[k] = kn[reg + k];
@@ -1601,14 +1608,7 @@ __device__ __forceinline__ void riccati_solve_lean(const Lds<real>& L, ModelStre
     real du0, du1;
     spread2(du, du0, du1);
     ISSUE_ORDER();
-    {
-      if (cross) M.wait();
-      load_stage(i < N - 2 ? i + 1 : i);
-      if (cross && i / LN_CHUNK + 2 < nch) {
-        wave_fence();
-        M.fetch(i / LN_CHUNK + 2);
-      }
-    }
+    load_stage(i < N - 2 ? i + 1 : i);
     ISSUE_ORDER();
     const real nx = rfma(b1, du1, rfma(b0, du0, ax));
     const real d = (r < 6) ? nx : du;
