@@ -12,8 +12,10 @@ s0 = rng.uniform(0, tab["L"], B)
 x0 = np.stack([s0, rng.uniform(-0.08, 0.08, B), rng.normal(0, 0.03, B), rng.uniform(0.6, 0.95, B) * np.interp(s0, np.arange(1024) * tab["L"] / 1024, tab["vel"]), np.zeros(B), np.zeros(B)])
 steps = int(3.2 * tab["L"] / 3.0 / 0.025)
 res = {}
+import os
 for graph, lf in ((False, False), (True, False), (True, True)):
-    solver = pkg.Solver(pkg.presets.barc_tracking_mpc(N), pkg.presets.barc_vehicle(), 0)
+    preset = dict(pkg.presets.barc_tracking_mpc(N)); preset["polish"] = int(os.environ.get("POLISH", "0"))
+    solver = pkg.Solver(preset, pkg.presets.barc_vehicle(), 0)
     torch.cuda.synchronize(); t0 = time.time()
     r = pkg.closed_loop.run(solver, tab, torch.as_tensor(x0, device="cuda"), torch.zeros((2, B), dtype=torch.float64, device="cuda"), steps=steps, speed_scale=0.9, graph=graph, longest_first=lf)
     torch.cuda.synchronize(); dt = time.time() - t0
