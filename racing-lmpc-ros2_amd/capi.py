@@ -350,8 +350,9 @@ class Solver:
         B, N = a[0].shape[1], self.N
         if out is None:
             kw = dict(dtype=torch.float32, device=self.device)
-            out = {"X_optm": torch.empty((6, N, B), **kw), "U_optm": torch.empty((2, N - 1, B), **kw),
-                   "dU_optm": torch.empty((2, N - 1, B), **kw), "kkt": torch.empty((4, B), **kw),
+            shapes = ((B, N, 6), (B, N - 1, 2)) if getattr(self, "_aos", False) else ((6, N, B), (2, N - 1, B))  # lmpc_set_output_layout
+            out = {"X_optm": torch.empty(shapes[0], **kw), "U_optm": torch.empty(shapes[1], **kw),
+                   "dU_optm": torch.empty(shapes[1], **kw), "kkt": torch.empty((4, B), **kw),
                    "status": torch.empty((B,), dtype=torch.int32, device=self.device),
                    "iters": torch.empty((B,), dtype=torch.int32, device=self.device)}
         rc = self.lib.lmpc_solve_batch_f32(self._h, C.c_int32(B), *[_ptr(t) for t in a], _ptr(out["X_optm"]),
