@@ -51,3 +51,13 @@ for name, track, fveh, fcfg, N, seed, share in CASES:
     per, ped = np.array(per), np.array(ped)
     print(f"{name}: {B} problems, dense solved {have.sum()}, twin solved {(tw['status'] == 0).sum()}, status agree {(have == (tw['status'] == 0)).mean():.4f}; "
           f"X/U max {per.max():.1e} p99 {np.percentile(per, 99):.1e} median {np.median(per):.1e}; dU max {ped.max():.1e}; mean iterations {tw['iters'][both].mean():.2f}  ({time.time() - t0:.0f} s)", flush=True)
+    # where the dense solver gave up and the twin did not: the twin's point through the solver-independent KKT certificate
+    cert = []
+    for b in np.nonzero(~have & (tw["status"] == 0))[0]:
+        qp = Q.build_qp(cfg, veh, S.problem(inp, int(b)))
+        c = Q.kkt_certificate(qp, Q.pack(qp, tw["X_optm"][:, :, b], tw["U_optm"][:, :, b], tw["dU_optm"][:, :, b], sigma=tw["kkt"][3, b]))
+        gs = max(1.0, float(np.abs(qp.H @ Q.pack(qp, tw["X_optm"][:, :, b], tw["U_optm"][:, :, b], tw["dU_optm"][:, :, b], sigma=tw["kkt"][3, b]) + qp.h).max()))
+        cert.append((c["stat"] / gs, c["eq"], c["ineq"], c["comp"]))
+    if cert:
+        c = np.array(cert)
+        print(f"   {len(cert)} problems the dense solver gave up on, twin's point certified: stationarity (relative to |gradient|) max {c[:, 0].max():.1e}, equalities {c[:, 1].max():.1e}, inequalities {c[:, 2].max():.1e}, complementarity {c[:, 3].max():.1e}", flush=True)
