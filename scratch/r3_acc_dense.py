@@ -61,3 +61,29 @@ for name, track, fveh, fcfg, N, seed, share in CASES:
     if cert:
         c = np.array(cert)
         print(f"   {len(cert)} problems the dense solver gave up on, twin's point certified: stationarity (relative to |gradient|) max {c[:, 0].max():.1e}, equalities {c[:, 1].max():.1e}, inequalities {c[:, 2].max():.1e}, complementarity {c[:, 3].max():.1e}", flush=True)
+
+# ---- the learning problem on the reference's recorded laps (tests/lmpc_scenario.py): 96 safe-set points, N = 20
+if not ONLY or any("learning" in o for o in ONLY):
+    import lmpc_scenario as LS
+    B = max(16, B0 // 8)
+    veh, cfg, tr, laps, inp, q = LS.make(B, 21)
+    ss_x, ss_j, _ = LS.oracle_safe_set(cfg, laps, q)
+    G.update(cfg=cfg, veh=veh, inp=inp, ss_x=ss_x, ss_j=ss_j)
+    def dense_l(b):
+        qp = Q.build_qp(G["cfg"], G["veh"], S.problem(G["inp"], b), ss_x=G["ss_x"][:, :, b], ss_j=G["ss_j"][:, b])
+        try:
+            y, info = Q.solve_dense(qp)
+        except np.linalg.LinAlgError:
+            return None
+        if info["status"] != 0: return None
+        o = qp.split(y)
+        return o["X_optm"], o["U_optm"], o["dU_optm"]
+    t0 = time.time()
+    with ProcessPoolExecutor(16) as ex:
+        res = list(ex.map(dense_l, range(B), chunksize=4))
+    tw = cbind.solve_batch(cfg, veh, inp, ss_x, ss_j)
+    have = np.array([r is not None for r in res]); both = have & (tw["status"] == 0)
+    per = np.array([max(np.abs((tw["X_optm"][:, :, b] - res[b][0]) / P.SCALE_X[:, None]).max(), np.abs((tw["U_optm"][:, :, b] - res[b][1]) / P.SCALE_U[:, None]).max()) for b in np.nonzero(both)[0]])
+    ped = np.array([np.abs((tw["dU_optm"][:, :, b] - res[b][2]) / P.SCALE_U[:, None]).max() for b in np.nonzero(both)[0]])
+    print(f"barc learning N=20, 96 points (recorded laps): {B} problems, dense solved {have.sum()}, twin solved {(tw['status'] == 0).sum()}, status agree {(have == (tw['status'] == 0)).mean():.4f}; "
+          f"X/U max {per.max():.1e} p99 {np.percentile(per, 99):.1e} median {np.median(per):.1e}; dU max {ped.max():.1e}; mean iterations {tw['iters'][both].mean():.2f}  ({time.time() - t0:.0f} s)", flush=True)
