@@ -178,3 +178,24 @@ def test_learning_problem_at_full_size_in_fp64(pkg):
     print("learning problem at full size: solved %.5f, degenerate among the sample %.2f; against the twin on all %d: %.1e / dU %.1e"
           % (ok.mean(), frac, both.sum(), e.max(), ed.max()))
     assert e.max() < TOL_TWIN and ed.max() < TOL_TWIN, (e.max(), ed.max())
+
+
+def test_second_pass_is_the_direct_fp64_kernel_bit_for_bit():
+    """The fp64 second pass of the mixed solve (a persistent grid walking the list of marked problems and CALLING the
+    solve) against the direct fp64 kernel, on whole batches (LMPC_DEBUG_CLEANUP_ALL=1 hands every problem to the second
+    pass): same status, iteration count and bits for every problem, for every (KQ, KS) the second pass is built for.
+    Guards a failure seen in round 3: with the solve inlined under the persistent loop one instantiation computed garbage
+    while the direct kernel was right."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    here = Path(__file__).resolve().parent
+    env = dict(os.environ, LMPC_DEBUG_CLEANUP_ALL="1")
+    r = subprocess.run([sys.executable, str(here / "second_pass_check.py")], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rows = [json.loads(line) for line in r.stdout.splitlines() if line.startswith("{")]
+    assert len(rows) == 6, r.stdout
+    for row in rows:
+        assert row["same_bits"] and row["solved"] == row["solved_second_pass"] and row["solved"] >= 1020, row
