@@ -115,14 +115,18 @@ def shard_bounds(total: int, world: int, rank: int):
 
 
 def packed_numel(N: int, B: int) -> int:
-    return (10 * N - 4) * B  # X 6N + U 2(N-1) + dU 2(N-1) per problem
+    return (10 * N - 4 + 2) * B  # X 6N + U 2(N-1) + dU 2(N-1) per problem, + status and iters (results AND status)
 
 
 def pack_results(out: dict, flat):
-    """X_optm | U_optm | dU_optm of this rank's slice into one contiguous buffer for the gather."""
+    """X_optm | U_optm | dU_optm | status | iters of this rank's slice into one contiguous buffer for the gather (the two
+    integer arrays ride along in the buffer's floating type -- exact for these ranges -- so that one collective moves all of
+    it and rank 0 can tell which problems of which rank failed)."""
     import torch
 
-    torch.cat([out["X_optm"].reshape(-1), out["U_optm"].reshape(-1), out["dU_optm"].reshape(-1)], out=flat)
+    dt = flat.dtype
+    torch.cat([out["X_optm"].reshape(-1), out["U_optm"].reshape(-1), out["dU_optm"].reshape(-1), out["status"].to(dt), out["iters"].to(dt)],
+              out=flat)
     return flat
 
 
@@ -132,10 +136,13 @@ def unpack_results(gbuf, world: int, N: int, B: int) -> dict:
 
     per = gbuf.reshape(world, packed_numel(N, B))
     nX, nU = 6 * N * B, 2 * (N - 1) * B
+    o = nX + 2 * nU
     X = torch.cat([per[r, :nX].reshape(6, N, B) for r in range(world)], dim=2)
     U = torch.cat([per[r, nX:nX + nU].reshape(2, N - 1, B) for r in range(world)], dim=2)
-    dU = torch.cat([per[r, nX + nU:].reshape(2, N - 1, B) for r in range(world)], dim=2)
-    return {"X_optm": X, "U_optm": U, "dU_optm": dU}
+    dU = torch.cat([per[r, nX + nU:o].reshape(2, N - 1, B) for r in range(world)], dim=2)
+    status = torch.cat([per[r, o:o + B] for r in range(world)]).to(torch.int32)
+    iters = torch.cat([per[r, o + B:o + 2 * B] for r in range(world)]).to(torch.int32)
+    return {"X_optm": X, "U_optm": U, "dU_optm": dU, "status": status, "iters": iters}
 
 
 def usable_cores():
@@ -349,13 +356,9 @@ def main():
             pv = dict(pkg.presets.barc_vehicle())
             pv["mu"] *= 0.85
             plant = pkg.Solver(cfgd, pv, device=local)
-            rng = np.random.default_rng(7)
-            xa = np.concatenate(laps) + rng.normal(0, 1, (sum(l.shape[0] for l in laps), 6)) * np.array([0.0, 0.02, 0.02, 0.1, 0.03, 0.2])
-            ua = np.stack([rng.uniform(-0.005, 0.005, xa.shape[0]), rng.uniform(-0.15, 0.15, xa.shape[0])], axis=1)
-            ka = np.interp(xa[:, 0], np.arange(tr["M"]) * tr["L"] / tr["M"], tr["curvature"], period=tr["L"])
-            xb = plant.plant_step(tr, torch.as_tensor(xa.T.copy(), device=dev), torch.as_tensor(ua.T.copy(), device=dev), 0.03).cpu().numpy().T
-            reg_laps = [(np.stack([xa[j], xb[j]]), np.stack([ua[j], ua[j]]), np.array([ka[j], ka[j]]), np.array([0.0, 0.03]))
-                        for j in range(xa.shape[0])]
+            reg_laps = pkg.workloads.regression_sample_pairs(
+                tr, laps, lambda xa, ua: plant.plant_step(tr, torch.as_tensor(xa.T.copy(), device=dev), torch.as_tensor(ua.T.copy(), device=dev),
+                                                          0.03).cpu().numpy().T)
             plant.close()
 
         def make_solver():
@@ -541,6 +544,11 @@ def main():
     if world > 1:
         dist.barrier()
 
+    gathered = None
+    if gather and rank == 0:  # what rank 0 holds after the last gather: every rank's results and statuses
+        full = unpack_results(gbuf[(args.steps - 1) % S], world, N, B)
+        gathered = {"problems": int(full["status"].numel()), "solved_fraction": float((full["status"] == 0).float().mean()),
+                    "mean_iters": float(full["iters"].float().mean())}
     if rank == 0:
         value = world * B * args.steps / elapsed
         sol_avg = float(np.mean(sol_ms))
@@ -576,7 +584,7 @@ def main():
                        "batch_per_gpu": B, "horizon": N, "streams": S, "output_layout": args.output_layout,
                        "launch_order": ("longest first by the previous solve's iteration counts of the SAME batch (perfect foresight here)"
                                         if orders else "default"), "result_gather": "rccl all_gather (async)" if gather else "none",
-                       "ranks_seen": ranks_seen},
+                       "ranks_seen": ranks_seen, "gathered": gathered},
             "p50_solve_ms": float(np.percentile(lat, 50)), "p99_solve_ms": float(np.percentile(lat, 99)),
             "latency_samples": len(lat), "value_one_stream": one_stream_value,
             # one batch at a time: the figure that reconciles with kernels_ms and the rocprofv3 summaries (the headline
@@ -586,8 +594,7 @@ def main():
             "solved_fraction": float((st == 0).mean()), "mean_ipm_iters": float(iters.mean()),  # (interior-point iterations + polish rounds)
             "kernels_ms": {"linearize": float(np.mean(lin_ms)), "qp_solve": sol_avg,
                            **({"ss_query": float(np.mean(ss_ms))} if ss_ms else {})},
-            "launch": ({**solver.launch_info(), "lds_bytes_per_problem": solver.launch_info()["lds_bytes_per_problem"] // 2,
-                        "resident_problems_per_cu": None, "note": "fp32 records are half the fp64 size"} if (f32 or mixed) else solver.launch_info()),
+            "launch": solver.launch_info(args.precision),   # LDS bytes / resident problems per CU of the kernel this entry point launches
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_source,
@@ -604,7 +611,8 @@ def main():
             t_ss = float(np.mean(ss_ms)) * 1e-3
             res["ss_query_kernel"] = {"ms": t_ss * 1e3, "queries_per_s": B / t_ss, "algorithmic_bytes_per_query": q_bytes,
                                       "achieved_GBps": q_bytes * B / t_ss / 1e9, "frac_of_hbm_peak": q_bytes * B / t_ss / 1e9 / HBM_PEAK_GBS,
-                                      "note": "one wave per query: 3n distances per lap in LDS, K rounds of a wave-wide arg-min per lap"}
+                                      "note": "one wave per query: one distance pass per lap (two nearest of each lane's share in registers), bitonic sort of "
+                                              "the 64 lane minima, lanes 0..K-1 write the neighbours"}
         if not args.no_cpu_baseline and world == 1 and not lmpc and not iac:
             res["cpu_baseline"] = cpu_baseline(pkg, N, B)
         default_run = (world == 1 and not lmpc and not iac and not f32 and not mixed and N == 20 and B == 4096)

@@ -355,8 +355,11 @@ int lmpc_shift_batch(lmpc_handle* h, int32_t batch, const lmpc_track* track, con
 int lmpc_plant_step_batch(lmpc_handle* h, int32_t batch, const lmpc_track* track, double* x,
                           const double* u, double dt_sim, int32_t n_sub);
 
-/* Layout of the RESULT arrays X_optm, U_optm, dU_optm of the lmpc_solve_batch* entry points (inputs, status, iters, kkt
- * and convex_combi_optm are not affected).  LMPC_LAYOUT_SOA (default): [component][knot][batch], what batch-parallel
+/* Layout of the RESULT arrays X_optm, U_optm, dU_optm of lmpc_solve_batch and lmpc_solve_batch_mixed AS THE CALLER INVOKES THEM
+ * (inputs, status, iters, kkt and convex_combi_optm are not affected).  Nothing else follows the setting: lmpc_solve_batch_f32,
+ * lmpc_solve_full_dynamics_batch (its inner QPs feed the line search and the next linearisation), the single-problem host
+ * entry points (lmpc_solve_host, lmpc_solve_full_dynamics_host: column-major host arrays either way) and lmpc_shift_batch
+ * (which READS a solution) always use the default layout.  LMPC_LAYOUT_SOA (default): [component][knot][batch], what batch-parallel
  * consumers (lmpc_shift_batch, lmpc_plant_step_batch, a result gather) read coalesced.  LMPC_LAYOUT_AOS: [batch][knot]
  * [component] -- per problem the reference's own DM layout (column-major 6 x N, 2 x (N-1); racing_mpc.cpp:347-349), for a
  * consumer that takes one problem's plan at a time; one wavefront's 196 results then leave as full cache lines instead of
@@ -365,8 +368,10 @@ int lmpc_plant_step_batch(lmpc_handle* h, int32_t batch, const lmpc_track* track
 #define LMPC_LAYOUT_AOS 1
 int lmpc_set_output_layout(lmpc_handle* h, int32_t layout);
 
-/* Grow the handle's device workspace (stage linearisations, 432 B per stage per problem) so
- * that no later *_batch call with batch <= max_batch allocates. */
+/* Grow the handle's device workspace (stage linearisations, 432 B per stage per problem; the list of a mixed solve's
+ * unverified problems; the polish's save area, 10 N - 4 values per problem) so that no later *_batch call with
+ * batch <= max_batch allocates.  lmpc_solve_batch_f32 needs none of the fp64 workspace: it grows its own fp32 workspace and
+ * the save area on the first call for a batch size. */
 int lmpc_reserve(lmpc_handle* h, int32_t max_batch);
 
 /* Launch order of the QP kernel's workgroups (no counterpart upstream: a scheduling aid for closed-loop batches).  The
@@ -388,6 +393,14 @@ int lmpc_query_launch(const lmpc_handle* h, int32_t* lds_bytes_per_problem,
 
 /* Occupancy of the QP kernel as the runtime reports it: resident problems (= wavefronts) per CU. */
 int lmpc_query_residency(lmpc_handle* h, int32_t* problems_per_cu);
+
+/* The same two facts for the kernel a given entry point launches: LMPC_PRECISION_F64 (lmpc_solve_batch),
+ * LMPC_PRECISION_F32 (lmpc_solve_batch_f32) or LMPC_PRECISION_MIXED (the fp32 iteration of lmpc_solve_batch_mixed; its fp64
+ * second pass is the F64 kernel).  LMPC_ERR_UNSUPPORTED when that entry point has no kernel for the handle's (N, num_ss_pts). */
+#define LMPC_PRECISION_F64 0
+#define LMPC_PRECISION_F32 1
+#define LMPC_PRECISION_MIXED 2
+int lmpc_query_launch_for(lmpc_handle* h, int32_t precision, int32_t* lds_bytes_per_problem, int32_t* problems_per_cu);
 
 /* Per-kernel timing for benchmarks: when enabled, lmpc_solve_batch brackets its two launches
  * with HIP events on the handle's stream; lmpc_last_kernel_ms waits for them and returns the

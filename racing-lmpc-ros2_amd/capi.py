@@ -18,7 +18,7 @@ SOLVE_OPTIMAL, SOLVE_MAX_ITER, SOLVE_INFEASIBLE = 0, 1, 2
 _ABI_SYMBOLS = ("lmpc_create", "lmpc_destroy", "lmpc_last_error", "lmpc_set_stream", "lmpc_synchronize",
                 "lmpc_linearize_batch", "lmpc_solve_batch", "lmpc_set_safe_set", "lmpc_ss_query_batch",
                 "lmpc_prepare_batch", "lmpc_reserve", "lmpc_query_launch", "lmpc_enable_timing",
-                "lmpc_last_kernel_ms", "lmpc_query_residency", "lmpc_solve_host", "lmpc_shift_batch",
+                "lmpc_last_kernel_ms", "lmpc_query_residency", "lmpc_query_launch_for", "lmpc_solve_host", "lmpc_shift_batch",
                 "lmpc_plant_step_batch", "lmpc_solve_full_dynamics_batch", "lmpc_solve_full_dynamics_host", "lmpc_set_regression_laps", "lmpc_regress_batch", "lmpc_ss_query_host", "lmpc_solve_batch_f32",
                 "lmpc_solve_batch_mixed", "lmpc_prepare_failed_batch", "lmpc_set_launch_order", "lmpc_launch_order_from_iters", "lmpc_set_output_layout")
 
@@ -176,11 +176,13 @@ class Solver:
         self._check(self.lib.lmpc_last_kernel_ms(self._h, C.byref(a), C.byref(b)), "lmpc_last_kernel_ms")
         return a.value, b.value
 
-    def launch_info(self):
+    def launch_info(self, precision: str = "f64"):
+        """LDS bytes and resident problems per CU of the kernel the given entry point launches ("f64", "f32", "mixed")."""
         a, b = C.c_int32(0), C.c_int32(0)
         self._check(self.lib.lmpc_query_launch(self._h, C.byref(a), C.byref(b)), "lmpc_query_launch")
         c = C.c_int32(0)
-        self._check(self.lib.lmpc_query_residency(self._h, C.byref(c)), "lmpc_query_residency")
+        self._check(self.lib.lmpc_query_launch_for(self._h, C.c_int32({"f64": 0, "f32": 1, "mixed": 2}[precision]), C.byref(a), C.byref(c)),
+                    "lmpc_query_launch_for")
         return {"lds_bytes_per_problem": a.value, "threads_per_problem": b.value, "resident_problems_per_cu": c.value}
 
     # ---- input preparation (racing_mpc_node.cpp:210-235,261-292) ----
@@ -310,11 +312,15 @@ class Solver:
         return A, Bm, g
 
     # ---- RacingMPC::solve (racing_mpc.cpp:209-372) ----
-    def alloc_outputs(self, B: int):
+    def alloc_outputs(self, B: int, aos: bool | None = None):
+        """Result tensors for a batch of B in the layout lmpc_solve_batch / _mixed write (set_output_layout), or, with
+        aos=False, in the default layout whatever the setting (what every other entry point writes)."""
         torch = self._torch
         N = self.N
         kw = dict(dtype=torch.float64, device=self.device)
-        shapes = ((B, N, 6), (B, N - 1, 2)) if getattr(self, "_aos", False) else ((6, N, B), (2, N - 1, B))
+        if aos is None:
+            aos = getattr(self, "_aos", False)
+        shapes = ((B, N, 6), (B, N - 1, 2)) if aos else ((6, N, B), (2, N - 1, B))
         return {"X_optm": torch.empty(shapes[0], **kw), "U_optm": torch.empty(shapes[1], **kw),
                 "dU_optm": torch.empty(shapes[1], **kw),
                 "status": torch.empty((B,), dtype=torch.int32, device=self.device),
@@ -374,7 +380,7 @@ class Solver:
         a = {k: self._t(inp[k]) for k in ("x_ic", "u_ic", "X_ref", "U_ref", "T_ref", "bound_left", "bound_right",
                                           "curvatures", "vel_ref")}
         B = a["x_ic"].shape[1]
-        out = self.alloc_outputs(B)
+        out = self.alloc_outputs(B, aos=False)   # (the output layout setting applies to lmpc_solve_batch / _mixed only)
         kw = dict(device=self.device)
         out["sqp_iters"] = torch.zeros((B,), dtype=torch.int32, **kw)
         out["sqp_move"] = torch.zeros((B,), dtype=torch.float64, **kw)

@@ -48,11 +48,14 @@ struct lmpc_handle {
   lmpc_config cfg;
   int device = 0;
   hipStream_t stream = nullptr;  // nullptr = the device's default (null) stream
+  bool out_aos = false;  // lmpc_set_output_layout: applies to lmpc_solve_batch / lmpc_solve_batch_mixed as the CALLER invokes them; every
+                         // solve the library launches for itself (the SQP's QPs, the single-problem host path) writes the default layout
   const int* order = nullptr;  // lmpc_set_launch_order: device [order_n], applied to solves of that batch size only
   int order_n = 0;
   double* ws = nullptr;  // [cap][N-1][LMPC_LIN_RECORD]
   int* unverified = nullptr;  // [cap + 1]: the problems a mixed first pass could not verify, and their number
-  double* save = nullptr;     // [cap][10 N - 4]: the polish's save area
+  void* save = nullptr;       // [save_cap][10 N - 4] elements of save_elem bytes: the polish's save area (grown by reserve_save)
+  size_t save_cap = 0, save_elem = 0;
   size_t ws_cap = 0;
   float* ws_f32 = nullptr;  // the same for the single-precision solve
   size_t ws_f32_cap = 0;
@@ -127,6 +130,7 @@ struct solve_args {
   double *lam, *X, *U, *dU;
   int *status, *iters;
   double* kkt;
+  bool aos;  // results [batch][knot][component]
 };
 
 template <int KQ, int KS, typename real = double>
@@ -164,8 +168,13 @@ const void* pick_mixed_fn(int kq, int ks) {
   // fp32 kernel at one wave per SIMD) it ran 0.80 M solves/s against 0.70 M in fp64 with 13 % of the batch going to the
   // second pass, and one problem of 4096 passed its single-precision KKT test 3.6e-3 away from the fp64 answer -- outside
   // the 1e-3 this entry states, for a 1.14x gain
+#ifdef LMPC_MIXED_LONG_LEARNING
+  if (ks == 2) return kq <= 4 ? solve_fn<4, 2, float>() : kq == 7 ? solve_fn<7, 2, float>() : kq == 11 ? solve_fn<11, 2, float>() : nullptr;
+  if (ks == 3) return kq <= 4 ? solve_fn<4, 3, float>() : kq == 7 ? solve_fn<7, 3, float>() : kq == 11 ? solve_fn<11, 3, float>() : nullptr;
+#else
   if (ks == 2) return kq <= 4 ? solve_fn<4, 2, float>() : nullptr;
   if (ks == 3) return kq <= 4 ? solve_fn<4, 3, float>() : nullptr;
+#endif
   switch (kq) {
     case 2:
     case 4: return solve_fn<4, 0, float>();
@@ -176,8 +185,26 @@ const void* pick_mixed_fn(int kq, int ks) {
   return nullptr;
 }
 
+// fp32 arrays and iteration (lmpc_solve_batch_f32): the tracking problem
+const void* pick_f32_fn(int kq) {
+  switch (kq) {
+    case 2:
+    case 4: return reinterpret_cast<const void*>(&lmpc_solve_kernel<float, 4, 0, float>);
+    case 7: return reinterpret_cast<const void*>(&lmpc_solve_kernel<float, 7, 0, float>);
+    case 11: return reinterpret_cast<const void*>(&lmpc_solve_kernel<float, 11, 0, float>);
+    case 14: return reinterpret_cast<const void*>(&lmpc_solve_kernel<float, 14, 0, float>);
+  }
+  return nullptr;
+}
+
 // the fp64 second pass of a mixed solve, for the (KQ, KS) the mixed kernels exist for
 const void* pick_cleanup_fn(int kq, int ks) {
+#ifdef LMPC_MIXED_LONG_LEARNING
+  if (ks == 2 && kq == 7) return reinterpret_cast<const void*>(&lmpc_cleanup_kernel<double, 7, 2, double>);
+  if (ks == 3 && kq == 7) return reinterpret_cast<const void*>(&lmpc_cleanup_kernel<double, 7, 3, double>);
+  if (ks == 2 && kq == 11) return reinterpret_cast<const void*>(&lmpc_cleanup_kernel<double, 11, 2, double>);
+  if (ks == 3 && kq == 11) return reinterpret_cast<const void*>(&lmpc_cleanup_kernel<double, 11, 3, double>);
+#endif
   if (ks == 2) return kq <= 4 ? reinterpret_cast<const void*>(&lmpc_cleanup_kernel<double, 4, 2, double>) : nullptr;
   if (ks == 3) return kq <= 4 ? reinterpret_cast<const void*>(&lmpc_cleanup_kernel<double, 4, 3, double>) : nullptr;
   switch (kq) {
@@ -197,6 +224,8 @@ int launch_cleanup(lmpc_handle* h, const void* fn, const solve_args& a) {
   lmpc_params P = h->P;
   P.launch_order = nullptr;
   P.flag_unverified = 0;
+  P.out_aos = a.aos ? 1 : 0;
+  P.dbg_lds_bytes = (int)a.lds_bytes;
   int B = a.B;
   const double* ws = h->ws;
   const int* list = h->unverified;
@@ -204,7 +233,11 @@ int launch_cleanup(lmpc_handle* h, const void* fn, const solve_args& a) {
   void* args[] = {(void*)&P,      (void*)&B,    (void*)&list,  (void*)&count,  (void*)&ws,     (void*)&a.x_ic, (void*)&a.u_ic,
                   (void*)&a.T_ref, (void*)&a.bl, (void*)&a.br,  (void*)&a.vref, (void*)&a.ss_x, (void*)&a.ss_j, (void*)&a.lam,
                   (void*)&a.X,    (void*)&a.U,  (void*)&a.dU,  (void*)&a.status, (void*)&a.iters, (void*)&a.kkt};
-  static const bool wide = getenv("LMPC_DEBUG_CLEANUP_WIDE") != nullptr;  // (measurement only: one workgroup per problem)
+#ifdef LMPC_DEBUG_HOOKS  // (measurement builds only, `make debug`: one workgroup per problem)
+  static const bool wide = getenv("LMPC_DEBUG_CLEANUP_WIDE") != nullptr;
+#else
+  const bool wide = false;
+#endif
   const int grid = (a.B < 1024 || wide) ? a.B : 1024;  // (a percent of a batch is marked: 1024 workgroups take them in one or two turns)
   HIP_TRY(h, hipLaunchKernel(fn, dim3(grid), dim3(64), args, a.lds_bytes, h->stream));
   return LMPC_OK;
@@ -212,13 +245,17 @@ int launch_cleanup(lmpc_handle* h, const void* fn, const solve_args& a) {
 
 // pass: 0 a plain solve; 1 the fp32 iteration of a two-pass mixed solve (marks what it could not verify)
 int launch_solve(lmpc_handle* h, const void* fn, const solve_args& a_in, int pass = 0) {
-  // LMPC_LDS_PAD (bytes, measurement only): over-allocate LDS per problem to cap the problems resident on a CU
+#ifdef LMPC_DEBUG_HOOKS  // LMPC_LDS_PAD (bytes; measurement builds only): over-allocate LDS per problem to cap the problems resident on a CU
   static const int lds_pad = [] { const char* e = getenv("LMPC_LDS_PAD"); return e ? atoi(e) : 0; }();
+#else
+  const int lds_pad = 0;
+#endif
   solve_args a = a_in;
   a.lds_bytes += lds_pad;
   HIP_TRY(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)a.lds_bytes));
   lmpc_params P = h->P;
   P.flag_unverified = pass == 1;
+  P.out_aos = a.aos ? 1 : 0;
   // the registered order applies to solves of exactly its own batch size; every other launch through this handle (the
   // single-problem host path, the SQP's QPs on another batch, ...) keeps the default mapping
   P.launch_order = (h->order && a.B == h->order_n) ? h->order : nullptr;
@@ -256,6 +293,21 @@ extern "C" {
 
 namespace {
 int reserve_sqp(lmpc_handle* h, size_t B);
+// the polish's save area for `batch` problems of `elem`-byte values: the single-precision entry needs nothing else of
+// lmpc_reserve (no fp64 workspace, no list), and half the bytes
+int reserve_save(lmpc_handle* h, size_t batch, size_t elem) {
+  if (batch * elem <= h->save_cap * h->save_elem && h->save) return LMPC_OK;
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  if (h->save) HIP_TRY(h, hipFree(h->save));
+  h->save = nullptr;
+  h->P.save = nullptr;
+  h->save_cap = h->save_elem = 0;
+  HIP_TRY(h, hipMalloc(&h->save, batch * (size_t)(10 * h->P.N - 4) * elem));
+  h->P.save = h->save;
+  h->save_cap = batch;
+  h->save_elem = elem;
+  return LMPC_OK;
+}
 }
 
 int lmpc_create(const lmpc_config* cfg, const lmpc_vehicle* veh, int device, lmpc_handle** out) {
@@ -403,12 +455,8 @@ int lmpc_reserve(lmpc_handle* h, int32_t max_batch) {
   if (h->unverified) HIP_TRY(h, hipFree(h->unverified));
   h->unverified = nullptr;
   HIP_TRY(h, hipMalloc(&h->unverified, ((size_t)max_batch + 1) * sizeof(int)));
-  if (h->save) HIP_TRY(h, hipFree(h->save));
-  h->save = nullptr;
-  HIP_TRY(h, hipMalloc(&h->save, (size_t)max_batch * (10 * h->P.N - 4) * sizeof(double)));
-  h->P.save = h->save;
   h->ws_cap = (size_t)max_batch;
-  return LMPC_OK;
+  return reserve_save(h, (size_t)max_batch, sizeof(double));
 }
 
 int lmpc_query_launch(const lmpc_handle* h, int32_t* lds_bytes_per_problem, int32_t* threads_per_problem) {
@@ -428,6 +476,28 @@ int lmpc_query_residency(lmpc_handle* h, int32_t* problems_per_cu) {
   HIP_TRY(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, 64, lds));
   *problems_per_cu = n;
+  return LMPC_OK;
+}
+
+int lmpc_query_launch_for(lmpc_handle* h, int32_t precision, int32_t* lds_bytes_per_problem, int32_t* problems_per_cu) {
+  if (!h) return LMPC_ERR_ARGUMENT;
+  if (precision != LMPC_PRECISION_F64 && precision != LMPC_PRECISION_F32 && precision != LMPC_PRECISION_MIXED)
+    return fail(h, LMPC_ERR_ARGUMENT, "lmpc_query_launch_for: unknown precision");
+  HIP_TRY(h, hipSetDevice(h->device));
+  const int kq = kq_for(h->P.N), ks = ks_for(h->P.S);
+  const void* fn = nullptr;
+  if (precision == LMPC_PRECISION_F64) fn = pick_solve_fn(kq, ks);
+  if (precision == LMPC_PRECISION_MIXED) fn = pick_mixed_fn(kq, ks);
+  if (precision == LMPC_PRECISION_F32 && !h->P.learning) fn = pick_f32_fn(kq);
+  if (!fn) return fail(h, LMPC_ERR_UNSUPPORTED, "no kernel for this (N, num_ss_pts) at this precision");
+  const size_t lds = lmpc_lds_bytes(h->P.N, h->P.learning, h->P.S, precision == LMPC_PRECISION_F64 ? 8 : 4);
+  if (lds_bytes_per_problem) *lds_bytes_per_problem = (int32_t)lds;
+  if (problems_per_cu) {
+    int n = 0;
+    HIP_TRY(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, 64, lds));
+    *problems_per_cu = n;
+  }
   return LMPC_OK;
 }
 
@@ -464,7 +534,7 @@ int lmpc_linearize_batch(lmpc_handle* h, int32_t batch, const double* X_ref, con
 }
 
 namespace {
-int solve_batch_fp64_arrays(lmpc_handle* h, bool mixed, int32_t batch, const double* x_ic, const double* u_ic,
+int solve_batch_fp64_arrays(lmpc_handle* h, bool mixed, bool aos, int32_t batch, const double* x_ic, const double* u_ic,
                             const double* X_ref, const double* U_ref, const double* T_ref, const double* bound_left,
                             const double* bound_right, const double* curvatures, const double* vel_ref,
                             double total_length, const double* ss_x, const double* ss_j, double* X_optm, double* U_optm,
@@ -503,12 +573,17 @@ int solve_batch_fp64_arrays(lmpc_handle* h, bool mixed, int32_t batch, const dou
   a.ss_x = h->P.learning ? ss_x : nullptr; a.ss_j = h->P.learning ? ss_j : nullptr;
   a.lam = h->P.learning ? convex_combi_optm : nullptr;
   a.X = X_optm; a.U = U_optm; a.dU = dU_optm; a.status = status; a.iters = iters; a.kkt = kkt;
+  a.aos = aos;
   // Mixed precision is two launches when the polish is on: the fp32 iteration verifies its own answers (polish accepted =
   // KKT test passed) and marks the problems it could not verify -- a percent of a batch: active sets still ambiguous at
   // mu = 2e-6, or more than four free simplex weights -- and the fp64 kernel behind it solves exactly those.
   const bool two_pass = mixed && h->P.polish == 0;  // (polish = 1: the marks stay visible, no second pass -- diagnostics)
-  // LMPC_DEBUG_CLEANUP_ALL (measurement only): skip the fp32 pass and hand the whole batch to the fp64 second pass
+#ifdef LMPC_DEBUG_HOOKS  // LMPC_DEBUG_CLEANUP_ALL (the debug build, tests/second_pass_check.py): skip the fp32 pass and hand the
+                         // whole batch to the fp64 second pass
   static const bool cleanup_all = getenv("LMPC_DEBUG_CLEANUP_ALL") != nullptr;
+#else
+  const bool cleanup_all = false;
+#endif
   int rc = LMPC_OK;
   if (two_pass && cleanup_all)
     HIP_TRY(h, hipMemsetD32Async((hipDeviceptr_t)status, LMPC_SOLVE_UNVERIFIED, (size_t)batch, h->stream));
@@ -532,7 +607,7 @@ int lmpc_solve_batch(lmpc_handle* h, int32_t batch, const double* x_ic, const do
                      const double* curvatures, const double* vel_ref, double total_length, const double* ss_x,
                      const double* ss_j, double* X_optm, double* U_optm, double* dU_optm, double* convex_combi_optm,
                      int32_t* status, int32_t* iters, double* kkt) {
-  return solve_batch_fp64_arrays(h, false, batch, x_ic, u_ic, X_ref, U_ref, T_ref, bound_left, bound_right, curvatures,
+  return solve_batch_fp64_arrays(h, false, h && h->out_aos, batch, x_ic, u_ic, X_ref, U_ref, T_ref, bound_left, bound_right, curvatures,
                                  vel_ref, total_length, ss_x, ss_j, X_optm, U_optm, dU_optm, convex_combi_optm, status,
                                  iters, kkt);
 }
@@ -542,7 +617,7 @@ int lmpc_solve_batch_mixed(lmpc_handle* h, int32_t batch, const double* x_ic, co
                            const double* curvatures, const double* vel_ref, double total_length, const double* ss_x,
                            const double* ss_j, double* X_optm, double* U_optm, double* dU_optm,
                            double* convex_combi_optm, int32_t* status, int32_t* iters, double* kkt) {
-  return solve_batch_fp64_arrays(h, true, batch, x_ic, u_ic, X_ref, U_ref, T_ref, bound_left, bound_right, curvatures,
+  return solve_batch_fp64_arrays(h, true, h && h->out_aos, batch, x_ic, u_ic, X_ref, U_ref, T_ref, bound_left, bound_right, curvatures,
                                  vel_ref, total_length, ss_x, ss_j, X_optm, U_optm, dU_optm, convex_combi_optm, status,
                                  iters, kkt);
 }
@@ -560,15 +635,10 @@ int lmpc_solve_batch_f32(lmpc_handle* h, int32_t batch, const float* x_ic, const
   if (batch == 0) return LMPC_OK;
   HIP_TRY(h, hipSetDevice(h->device));
   const int N = h->P.N;
-  const int kq = kq_for(N);
-  const void* fn = kq == 2 || kq == 4 ? reinterpret_cast<const void*>(&lmpc_solve_kernel<float, 4, 0, float>)
-                   : kq == 7          ? reinterpret_cast<const void*>(&lmpc_solve_kernel<float, 7, 0, float>)
-                   : kq == 11         ? reinterpret_cast<const void*>(&lmpc_solve_kernel<float, 11, 0, float>)
-                   : kq == 14         ? reinterpret_cast<const void*>(&lmpc_solve_kernel<float, 14, 0, float>)
-                                      : nullptr;
+  const void* fn = pick_f32_fn(kq_for(N));
   if (!fn) return fail(h, LMPC_ERR_UNSUPPORTED, "no single-precision kernel for this N");
-  if ((size_t)batch > h->ws_cap) {  // (the polish's save area grows with the fp64 workspace)
-    const int rc = lmpc_reserve(h, batch);
+  {
+    const int rc = reserve_save(h, (size_t)batch, sizeof(float));
     if (rc != LMPC_OK) return rc;
   }
   if ((size_t)batch > h->ws_f32_cap) {
@@ -683,8 +753,9 @@ int lmpc_solve_full_dynamics_batch(lmpc_handle* h, int32_t batch, const double* 
   A.n_active = counter;
   for (int it = 0; it < max_sqp; ++it) {
     // QP about the iterate (racing_mpc.cpp:169-186 with X_ref, U_ref := the iterate)
-    const int rc = lmpc_solve_batch(h, batch, x_ic, u_ic, X_optm, U_optm, T_ref, bound_left, bound_right, curvatures, vel_ref,
-                                    total_length, ss_x, ss_j, Xq, Uq, dUq, S ? lamq : nullptr, status_q, iters_q, nullptr);
+    // (the default layout whatever lmpc_set_output_layout says: the line search and the next linearisation index it)
+    const int rc = solve_batch_fp64_arrays(h, false, false, batch, x_ic, u_ic, X_optm, U_optm, T_ref, bound_left, bound_right, curvatures,
+                                           vel_ref, total_length, ss_x, ss_j, Xq, Uq, dUq, S ? lamq : nullptr, status_q, iters_q, nullptr);
     if (rc != LMPC_OK) return rc;
     HIP_TRY(h, hipMemsetAsync(counter, 0, sizeof(int), h->stream));
     hipLaunchKernelGGL(lmpc_sqp_linesearch_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, h->stream, h->P, batch, A,
@@ -742,9 +813,9 @@ int solve_host_impl(lmpc_handle* h, const double* x_ic, const double* u_ic, cons
                                        total_length, S ? d + o_sx : nullptr, S ? d + o_sj : nullptr, max_sqp, step_tol,
                                        d + o_Xo, d + o_Uo, d + o_dUo, S ? d + o_lam : nullptr, h->stage_int,
                                        h->stage_int + 1, h->stage_int + 2, d + o_mv, d + o_mv + 1)
-      : lmpc_solve_batch(h, 1, d + o_x, d + o_u, d + o_X, d + o_U, d + o_T, d + o_bl, d + o_br, d + o_k, d + o_v,
-                         total_length, S ? d + o_sx : nullptr, S ? d + o_sj : nullptr, d + o_Xo, d + o_Uo,
-                         d + o_dUo, S ? d + o_lam : nullptr, h->stage_int, h->stage_int + 1, nullptr);
+      : solve_batch_fp64_arrays(h, false, false, 1, d + o_x, d + o_u, d + o_X, d + o_U, d + o_T, d + o_bl, d + o_br, d + o_k, d + o_v,
+                                total_length, S ? d + o_sx : nullptr, S ? d + o_sj : nullptr, d + o_Xo, d + o_Uo,
+                                d + o_dUo, S ? d + o_lam : nullptr, h->stage_int, h->stage_int + 1, nullptr);  // (the staging buffer is unpacked as [6][N])
   if (rc != LMPC_OK) return rc;
   int* const si = h->stage_int_host;
   HIP_TRY(h, hipMemcpyAsync(host + o_Xo, d + o_Xo, (total - o_Xo) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -1045,7 +1116,7 @@ int lmpc_set_regression_laps(lmpc_handle* h, int32_t n_laps, const int32_t* n_pt
 int lmpc_set_output_layout(lmpc_handle* h, int32_t layout) {
   if (!h) return LMPC_ERR_ARGUMENT;
   if (layout != LMPC_LAYOUT_SOA && layout != LMPC_LAYOUT_AOS) return fail(h, LMPC_ERR_ARGUMENT, "lmpc_set_output_layout: unknown layout");
-  h->P.out_aos = layout == LMPC_LAYOUT_AOS;
+  h->out_aos = layout == LMPC_LAYOUT_AOS;
   return LMPC_OK;
 }
 

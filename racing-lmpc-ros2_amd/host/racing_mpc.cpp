@@ -128,7 +128,6 @@ void RacingMPC::solve(const DMDict& in, DMDict& out, Dict& stats) {
       return;
     }
     total_iters = iters;
-    ran_ = true;
     stats["sqp_iter_count"] = static_cast<double>(sqp_iters);
     stats["dynamics_defect"] = defect;
     if (status == LMPC_SOLVE_OPTIMAL && !(move <= 1e-8)) status = LMPC_SOLVE_MAX_ITER;
@@ -143,7 +142,6 @@ void RacingMPC::solve(const DMDict& in, DMDict& out, Dict& stats) {
       return;
     }
     total_iters = iters;
-    ran_ = true;  // upstream: sol_ is set whenever solve_limited() returned (racing_mpc.cpp:343-345)
   }
   stats["iter_count"] = static_cast<double>(total_iters);
   if (status != LMPC_SOLVE_OPTIMAL) {
@@ -152,6 +150,9 @@ void RacingMPC::solve(const DMDict& in, DMDict& out, Dict& stats) {
     return;  // out lacks X_optm, solved_ unchanged (racing_mpc.cpp:358-371)
   }
   solved_ = true;
+  // upstream assigns sol_ from solve_limited() (racing_mpc.cpp:343-345), and its solver is built with error_on_fail = true
+  // (:86-103): a failed solve throws before the assignment, so only a successful one leaves a "previous solution" behind
+  ran_ = true;
   out["X_optm"] = X;
   out["U_optm"] = U;
   out["dU_optm"] = dU;

@@ -6,6 +6,7 @@
 #include <cmath>
 #include <iostream>
 #include <stdexcept>
+#include <string>
 
 #include "single_track_model.hpp"
 
@@ -30,6 +31,54 @@ RacingMPCNodeCore::RacingMPCNodeCore(RacingMPC::SharedPtr mpc, RacingMPC::Shared
 
 void RacingMPCNodeCore::discrete_dynamics(const double* x, const double* u, double* xn) const {
   stm::discrete_dynamics(mpc_->get_model().v, x, u, track_->curvature_interpolation(x[0]), dt_, xn);  // :68-76
+}
+
+DiagnosticStatus CycleWindow::status(const std::string& name, const std::string& message, double warn_threshold) const {
+  double mx = 0.0, mn = 0.0, mean = 0.0;  // an empty window reports zeros (cycle_profiler.hpp:108-113)
+  if (n_ > 0) {
+    mx = mn = buf_[0];
+    for (std::size_t i = 0; i < n_; ++i) {
+      mx = std::max(mx, buf_[i]);
+      mn = std::min(mn, buf_[i]);
+      mean += buf_[i];
+    }
+    mean /= static_cast<double>(n_);
+  }
+  DiagnosticStatus s;
+  s.values = {{"max", std::to_string(mx)}, {"mean", std::to_string(mean)}, {"min", std::to_string(mn)}};
+  s.level = mx > warn_threshold ? DiagnosticStatus::WARN : DiagnosticStatus::OK;
+  s.name = name;
+  s.message = message;
+  return s;
+}
+
+bool RacingMPCNodeCore::take_diagnostics(DiagnosticArray& diagnostics) {
+  if (!diagnostics_ready_) return false;
+  diagnostics = diagnostics_;
+  diagnostics_ready_ = false;
+  return true;
+}
+
+void RacingMPCNodeCore::change_trajectory(lmpc::vehicle_model::racing_trajectory::RacingTrajectory::SharedPtr new_track) {
+  using lmpc::FrenetPose2D;
+  using lmpc::Pose2D;
+  if (!new_track || new_track == track_) return;
+  if (mpc_->solved() && last_x_.cols > 0) {  // :540-551: the previous solution into the new coordinate system
+    for (std::size_t i = 0; i < last_x_.cols; ++i) {
+      FrenetPose2D old_fp, new_fp;
+      old_fp.position.s = last_x_(0, i);
+      old_fp.position.t = last_x_(1, i);
+      old_fp.yaw = last_x_(2, i);
+      Pose2D gp;
+      track_->frenet_to_global(old_fp, gp);
+      new_track->global_to_frenet(gp, new_fp);
+      last_x_(0, i) = new_fp.position.s;
+      last_x_(1, i) = new_fp.position.t;
+      last_x_(2, i) = new_fp.yaw;
+    }
+  }
+  track_ = new_track;  // discrete_dynamics() reads the curvature from track_ (:558-565)
+  sol_in_["total_length"] = DM(track_->total_length());
 }
 
 void RacingMPCNodeCore::set_speed_limit(const double& speed_limit) { speed_limit_ = speed_limit; }
@@ -160,6 +209,17 @@ RacingMPCNodeCore::Result RacingMPCNodeCore::step(const VehicleState& st, Vehicl
     return Result::JIT_DISCARDED;
   }
   tel.solve_time = std::chrono::duration<double, std::milli>(std::chrono::system_clock::now() - t0).count();
+  // :351-384: the two windows, and every `capacity` published steps the diagnostics array
+  profiler_.add(tel.solve_time);
+  if (stats.count("iter_count")) profiler_iter_count_.add(stats.at("iter_count"));
+  if (++profile_step_count_ % profiler_.capacity() == 0) {
+    diagnostics_ = DiagnosticArray();
+    diagnostics_.stamp = st.t;
+    diagnostics_.status.push_back(profiler_.status("Racing MPC Solve Time", "(ms)", dt_ * 1e3));
+    diagnostics_.status.push_back(profiler_iter_count_.status("Racing MPC Iteration Count", "Number of Solver Iterations", 50));
+    diagnostics_ready_ = true;
+    profile_step_count_ = 0;
+  }
   // actuation from column delay_step of the plan (:395-413)
   const std::size_t col = std::min(static_cast<std::size_t>(std::max(delay_step_, 0)), N - 2);
   double ub[3];

@@ -10,11 +10,15 @@
 //                     (:245-249), references at the plan's abscissae and the velocity-reference clamp (:261-292), the
 //                     QP solve (:320), keep the old plan on failure (:322-332), discard the first QP solve when
 //                     `jit` (:337-342), to_base_control of column delay_step -> actuation (:395-413), telemetry (:333-336)
+//   every 10th published step -> the diagnostics array (:351-384); change_trajectory (:509-571) re-expresses the plan on
+//                     another reference line
 // What a rclcpp wrapper adds is subscriptions, publishers, the timer and the visualisation topics (no ROS 2 in this image).
 #ifndef LMPC_HOST_RACING_MPC_NODE_CORE_HPP_
 #define LMPC_HOST_RACING_MPC_NODE_CORE_HPP_
 
 #include <memory>
+#include <string>
+#include <utility>
 #include <vector>
 
 #include "racing_mpc.hpp"
@@ -45,6 +49,38 @@ struct MPCTelemetry {
   double solve_time = 0.0;                   // ms
 };
 
+// diagnostic_msgs/DiagnosticStatus as the node fills it (lmpc_utils/cycle_profiler.hpp:37-67): max / mean / min of a window
+// as strings, WARN when the window's maximum exceeds the threshold
+struct DiagnosticStatus {
+  enum Level { OK = 0, WARN = 1 };
+  int level = OK;
+  std::string name, message;
+  std::vector<std::pair<std::string, std::string>> values;  // ("max", ...), ("mean", ...), ("min", ...)
+};
+// diagnostic_msgs/DiagnosticArray: what the node publishes every `window` published steps (racing_mpc_node.cpp:370-384)
+struct DiagnosticArray {
+  double stamp = 0.0;  // the state message's time (the node stamps with its clock)
+  std::vector<DiagnosticStatus> status;
+};
+
+// lmpc::utils::CycleProfiler<double> (lmpc_utils/cycle_profiler.hpp:70-133): the last `window` samples, their max / mean / min
+class CycleWindow {
+ public:
+  explicit CycleWindow(std::size_t window) : buf_(window), n_(0), next_(0) {}
+  void add(double v) {
+    if (buf_.empty()) return;
+    buf_[next_] = v;
+    next_ = (next_ + 1) % buf_.size();
+    if (n_ < buf_.size()) ++n_;
+  }
+  std::size_t capacity() const { return buf_.size(); }
+  DiagnosticStatus status(const std::string& name, const std::string& message, double warn_threshold) const;
+
+ private:
+  std::vector<double> buf_;
+  std::size_t n_, next_;
+};
+
 class RacingMPCNodeCore {
  public:
   enum class Result { INITIAL_SOLVE, INITIAL_SOLVE_FAILED, JIT_DISCARDED, PUBLISHED };
@@ -56,6 +92,17 @@ class RacingMPCNodeCore {
 
   // one timer tick: `actuation` carries the last published actuation in and the new one out (only when PUBLISHED)
   Result step(const VehicleState& state, VehicleActuation& actuation, MPCTelemetry& telemetry);
+
+  // Diagnostics (racing_mpc_node.cpp:47-48,351-384): solve time (ms) and iteration count of every published step go into two
+  // windows of 10; after every 10th published step `diagnostics` holds a fresh array -- "Racing MPC Solve Time" (WARN above the
+  // control period dt * 1e3 ms) and "Racing MPC Iteration Count" (WARN above 50) -- and the function returns true once.
+  bool take_diagnostics(DiagnosticArray& diagnostics);
+
+  // RacingMPCNode::change_trajectory (racing_mpc_node.cpp:509-571): switch to another reference line.  The previous plan's
+  // poses go old Frenet -> global -> new Frenet (only once the QP controller has solved, as upstream), total_length and the
+  // curvature under the model step follow the new track.  The measured state needs no conversion here: step() projects the
+  // global pose of every state message itself (:181-185).  A null track is ignored (upstream: unknown index).
+  void change_trajectory(lmpc::vehicle_model::racing_trajectory::RacingTrajectory::SharedPtr new_track);
 
   void set_speed_limit(const double& speed_limit);  // racing_mpc_node.cpp:571-581
   void set_speed_scale(const double& speed_scale);  // :583-598 (out of (0, 1] resets to 0.2)
@@ -75,6 +122,10 @@ class RacingMPCNodeCore {
   double speed_limit_, speed_scale_ = 1.0;
   DM last_x_, last_u_, last_du_, last_convex_combi_;
   DMDict sol_in_;
+  CycleWindow profiler_{10}, profiler_iter_count_{10};  // racing_mpc_node.cpp:47-48
+  std::size_t profile_step_count_ = 0;
+  bool diagnostics_ready_ = false;
+  DiagnosticArray diagnostics_;
 };
 
 }  // namespace racing_mpc

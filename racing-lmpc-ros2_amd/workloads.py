@@ -83,6 +83,20 @@ def sample_states_near_laps(laps, batch: int, L: float, seed: int = 0):
     return x, np.zeros((batch, 2))
 
 
+def regression_sample_pairs(track: dict, laps, plant_step, seed: int = 7, dt: float = 0.03):
+    """Recorded data of a plant that differs from the model, as two-sample laps for `Solver.set_regression_laps`
+    (BASELINE configs[4]: "LMPC + error-dynamics residual term"): states around the stored laps, inputs drawn at random,
+    and each state's successor one `dt` later from `plant_step(xa [n, 6], ua [n, 2]) -> xb [n, 6]` -- the caller's plant
+    (bench.py and the full-size parity test use the plant kernel of a second handle with 15 % less grip)."""
+    rng = np.random.default_rng(seed)
+    n = sum(l.shape[0] for l in laps)
+    xa = np.concatenate(laps) + rng.normal(0, 1, (n, 6)) * np.array([0.0, 0.02, 0.02, 0.1, 0.03, 0.2])
+    ua = np.stack([rng.uniform(-0.005, 0.005, n), rng.uniform(-0.15, 0.15, n)], axis=1)
+    ka = np.interp(xa[:, 0], np.arange(track["M"]) * track["L"] / track["M"], track["curvature"], period=track["L"])
+    xb = np.asarray(plant_step(xa, ua))
+    return [(np.stack([xa[j], xb[j]]), np.stack([ua[j], ua[j]]), np.array([ka[j], ka[j]]), np.array([0.0, dt])) for j in range(n)]
+
+
 def track_from_file(path, M: int = 1024) -> dict:
     """Uniform periodic device tables sampled from one of the reference's 17-column track files
     (racing_trajectory.py: same interpolants as RacingTrajectory upstream)."""

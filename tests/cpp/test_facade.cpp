@@ -55,6 +55,21 @@ int main(int argc, char** argv) {
     try { mpc.solve(in, out, stats); } catch (const std::runtime_error&) { refused = true; }
     if (!refused || mpc.solved()) { std::puts("FAIL: a first call without warm start keys must throw"); return 1; }
   }
+  {  // a FAILED first solve leaves no previous solution behind either (upstream: error_on_fail = true, solve_limited() throws
+     // before sol_ is assigned, racing_mpc.cpp:86-103,343-345): the next call without the keys still throws
+    RacingMPC fresh(cfg, veh);
+    DMDict bad = in, outb;
+    bad["X_optm_ref"] = bad["X_ref"];
+    bad["U_optm_ref"] = bad["U_ref"];
+    bad["dU_optm_ref"] = DM(2, static_cast<std::size_t>(N) - 1);
+    bad["T_optm_ref"] = bad["T_ref"];
+    bad["x_ic"](3, 0) = 0.01;  // outside the state box: the QP is infeasible
+    fresh.solve(bad, outb, stats);
+    if (outb.count("X_optm") || fresh.solved()) { std::puts("FAIL: infeasible first solve reported a solution"); return 1; }
+    bool refused = false;
+    try { fresh.solve(in, outb, stats); } catch (const std::runtime_error&) { refused = true; }
+    if (!refused) { std::puts("FAIL: a failed first solve must not count as a previous solution"); return 1; }
+  }
   // the node's first call (racing_mpc_node.cpp:225-234): the reference doubles as the warm start
   in["X_optm_ref"] = in["X_ref"];
   in["U_optm_ref"] = in["U_ref"];

@@ -60,7 +60,8 @@ int main(int argc, char** argv) {
   double x[6] = {0.5, 0.02, 0.0, 1.5, 0.0, 0.0};
   VehicleActuation act;
   MPCTelemetry tel;
-  int n_published = 0, n_failed = 0, n_initial = 0, n_discarded = 0;
+  int n_published = 0, n_failed = 0, n_initial = 0, n_discarded = 0, n_diag = 0;
+  bool changed = false;
   double travelled = 0.0, worst_excess = -1e9, solve_ms = 0.0, t = 0.0;
   const int max_steps = (int)(laps_wanted * L / 1.0 / dt);  // (bounded: at least 1 m/s average)
   for (int k = 0; k < max_steps && travelled < laps_wanted * L; ++k) {
@@ -92,6 +93,41 @@ int main(int argc, char** argv) {
     if (r == RacingMPCNodeCore::Result::JIT_DISCARDED) ++n_discarded;
     if (r == RacingMPCNodeCore::Result::PUBLISHED) {
       ++n_published;
+      // racing_mpc_node.cpp:370-384: a diagnostics array after every 10th published step, and only then
+      DiagnosticArray da;
+      const bool got = node.take_diagnostics(da);
+      if (got != (n_published % 10 == 0)) { std::puts("FAIL: diagnostics cadence"); return 1; }
+      if (got) {
+        ++n_diag;
+        const bool shape = da.status.size() == 2 && da.status[0].name == "Racing MPC Solve Time" && da.status[0].message == "(ms)" &&
+                           da.status[1].name == "Racing MPC Iteration Count" && da.status[0].values.size() == 3 &&
+                           da.status[0].values[0].first == "max" && da.status[0].values[1].first == "mean" && da.status[0].values[2].first == "min";
+        if (!shape) { std::puts("FAIL: diagnostics content"); return 1; }
+        const double mx = std::atof(da.status[0].values[0].second.c_str()), mean = std::atof(da.status[0].values[1].second.c_str()),
+                     mn = std::atof(da.status[0].values[2].second.c_str()), it_max = std::atof(da.status[1].values[0].second.c_str());
+        if (!(mn <= mean && mean <= mx && mx > 0.0) || (da.status[0].level == DiagnosticStatus::WARN) != (mx > dt * 1e3) ||
+            (da.status[1].level == DiagnosticStatus::WARN) != (it_max > 50) || it_max < 1) { std::puts("FAIL: diagnostics levels"); return 1; }
+        if (node.take_diagnostics(da)) { std::puts("FAIL: diagnostics handed out twice"); return 1; }
+      }
+      // racing_mpc_node.cpp:509-571, once, mid-run: the same race line loaded again is another reference-line object -- the plan
+      // goes old Frenet -> global -> new Frenet and must come back where it was (abscissa modulo the lap), and the run goes on
+      if (n_published == 57 && !df) {
+        const lmpc::DM before = node.last_x();
+        auto again = std::make_shared<rt::RacingTrajectory>(std::string(argv[1]));
+        node.change_trajectory(again);
+        node.change_trajectory(nullptr);  // ignored
+        const lmpc::DM& after = node.last_x();
+        double worst = 0.0;
+        for (std::size_t i = 0; i < before.cols; ++i) {
+          double ds = std::fabs(after(0, i) - before(0, i));
+          ds = std::fmin(ds, std::fabs(ds - L));
+          worst = std::fmax(worst, std::fmax(ds, std::fmax(std::fabs(after(1, i) - before(1, i)), std::fabs(after(2, i) - before(2, i)))));
+          for (int q = 3; q < 6; ++q) if (after(q, i) != before(q, i)) worst = 1.0;
+        }
+        std::printf("change_trajectory: plan moved by %.2e\n", worst);
+        if (!(worst < 1e-6)) { std::puts("FAIL: change_trajectory round trip"); return 1; }
+        changed = true;
+      }
       n_failed += tel.solved ? 0 : 1;
       solve_ms += tel.solve_time;
       if ((int)tel.state.size() != 6 * N || (int)tel.control.size() != 2 * (N - 1)) { std::puts("FAIL: telemetry sizes"); return 1; }
@@ -116,7 +152,8 @@ int main(int argc, char** argv) {
   }
   std::printf("laps %.3f time %.3f published %d failed %d initial %d discarded %d worst_excess %.4f mean_step_ms %.3f\n",
               travelled / L, t, n_published, n_failed, n_initial, n_discarded, worst_excess, solve_ms / (n_published ? n_published : 1));
-  const bool ok = travelled >= laps_wanted * L && n_initial == 1 && n_discarded == 1 && n_failed <= n_published / 100 && worst_excess < 0.02;
+  const bool ok = travelled >= laps_wanted * L && n_initial == 1 && n_discarded == 1 && n_failed <= n_published / 100 && worst_excess < 0.02 &&
+                  n_diag == n_published / 10 && (changed || df || n_published < 57);
   if (df) std::fclose(df);
   std::puts(ok ? "PASS" : "FAIL");
   return ok ? 0 : 1;

@@ -1,5 +1,5 @@
-"""Helper of tests/test_gpu_mixed_lmpc.py (run as a subprocess with LMPC_DEBUG_CLEANUP_ALL=1 in the environment, which the
-library reads once per process): the fp64 second pass of lmpc_solve_batch_mixed handed the WHOLE batch, against the direct
+"""Helper of tests/test_gpu_mixed_lmpc.py (run as a subprocess with LMPC_HIP_LIBRARY = the debug build of the library and
+LMPC_DEBUG_CLEANUP_ALL=1 in the environment, which that build reads once per process): the fp64 second pass of lmpc_solve_batch_mixed handed the WHOLE batch, against the direct
 fp64 kernel of lmpc_solve_batch -- same problems, so the same bits.  Prints one JSON line per case."""
 import json
 import sys

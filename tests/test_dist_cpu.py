@@ -28,7 +28,8 @@ def _worker(rank, world, port, N, B, q):
     idx = torch.arange(lo, hi, dtype=torch.float64)
     out = {"X_optm": idx[None, None, :] + torch.arange(6 * N, dtype=torch.float64).reshape(6, N, 1) * 1e-3,
            "U_optm": -idx[None, None, :] + torch.arange(2 * (N - 1), dtype=torch.float64).reshape(2, N - 1, 1) * 1e-3,
-           "dU_optm": 2 * idx[None, None, :] + torch.zeros(2, N - 1, 1, dtype=torch.float64)}
+           "dU_optm": 2 * idx[None, None, :] + torch.zeros(2, N - 1, 1, dtype=torch.float64),
+           "status": (torch.arange(lo, hi) % 3).to(torch.int32), "iters": (7 + torch.arange(lo, hi)).to(torch.int32)}
     flat = torch.empty(bench.packed_numel(N, B), dtype=torch.float64)
     gbuf = torch.empty(world * flat.numel(), dtype=torch.float64)
     bench.pack_results(out, flat)
@@ -59,6 +60,9 @@ def test_shard_and_gather_world2():
     assert np.allclose(full["X_optm"][5, N - 1], gi + (6 * N - 1) * 1e-3)
     assert np.array_equal(full["U_optm"][0, 0], -gi)
     assert np.array_equal(full["dU_optm"][1, N - 2], 2 * gi)
+    # status and iteration counts travel with the results: rank 0 knows which problems of which rank failed
+    assert full["status"].dtype == np.int32 and np.array_equal(full["status"], np.arange(world * B) % 3)
+    assert np.array_equal(full["iters"], 7 + np.arange(world * B))
 
 
 def test_shard_bounds_cover_everything():

@@ -182,8 +182,8 @@ def test_learning_problem_at_full_size_in_fp64(pkg):
 
 def test_second_pass_is_the_direct_fp64_kernel_bit_for_bit():
     """The fp64 second pass of the mixed solve (a persistent grid walking the list of marked problems and CALLING the
-    solve) against the direct fp64 kernel, on whole batches (LMPC_DEBUG_CLEANUP_ALL=1 hands every problem to the second
-    pass): same status, iteration count and bits for every problem, for every (KQ, KS) the second pass is built for.
+    solve) against the direct fp64 kernel, on whole batches (the debug build of the library -- the same sources with
+    -DLMPC_DEBUG_HOOKS -- reads LMPC_DEBUG_CLEANUP_ALL=1 and hands every problem to the second pass): same status, iteration count and bits for every problem, for every (KQ, KS) the second pass is built for.
     Guards a failure seen in round 3: with the solve inlined under the persistent loop one instantiation computed garbage
     while the direct kernel was right."""
     import json
@@ -192,7 +192,9 @@ def test_second_pass_is_the_direct_fp64_kernel_bit_for_bit():
     import sys
     from pathlib import Path
     here = Path(__file__).resolve().parent
-    env = dict(os.environ, LMPC_DEBUG_CLEANUP_ALL="1")
+    dbg = here.parent / "racing-lmpc-ros2_amd" / "lib" / "liblmpc_hip_dbg.so"   # the hook exists in the debug build only (make debug)
+    assert dbg.exists(), "liblmpc_hip_dbg.so not built: __graft_entry__.build()"
+    env = dict(os.environ, LMPC_DEBUG_CLEANUP_ALL="1", LMPC_HIP_LIBRARY=str(dbg))
     r = subprocess.run([sys.executable, str(here / "second_pass_check.py")], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     rows = [json.loads(line) for line in r.stdout.splitlines() if line.startswith("{")]

@@ -1056,3 +1056,37 @@ def test_aos_result_layout_holds_the_same_numbers(pkg):
     for k in ("X_optm", "U_optm", "dU_optm"):
         assert np.array_equal(aos[k].transpose(2, 1, 0), soa[k]), k
     assert np.array_equal(aos["status"], soa["status"]) and np.array_equal(aos["iters"], soa["iters"])
+
+
+def test_aos_layout_does_not_reach_the_solves_the_library_runs_for_itself(pkg):
+    """lmpc_set_output_layout applies to lmpc_solve_batch / lmpc_solve_batch_mixed as the caller invokes them (include/lmpc_hip.h).
+    The sequential-QP solve (its inner QPs feed the line search and the next linearisation), the single-problem host entry
+    (its staging buffer is unpacked as [6][N]) and the warm-start shift all work on the default layout: with AOS set they
+    return what they return without it (they returned scrambled trajectories)."""
+    import ctypes as C
+    import torch
+
+    veh, cfg, solver, tr, x, u = make(pkg, "barc20", 48, 31)
+    x[:, 3] = np.maximum(x[:, 3], 1.8)                      # starts the SQP converges from (test_full_dynamics_*)
+    inp = S.cold_start_inputs(cfg, veh, tr, x, u, 0.025)
+    ref_nl = to_np(solver.solve_full_dynamics(inp, max_sqp=6))
+    ref_qp = to_np(solver.solve(inp))
+    solver.set_output_layout("aos")
+    try:
+        nl = to_np(solver.solve_full_dynamics(inp, max_sqp=6))
+        for k in ("X_optm", "U_optm", "dU_optm", "status", "sqp_iters"):
+            assert np.array_equal(nl[k], ref_nl[k]), k
+        # one problem through the host entry (column-major 6 x N host arrays, as the facade passes them)
+        b = 5
+        lib, h = pkg.load_library(), solver._h
+        col = lambda a: np.ascontiguousarray(np.asarray(a, dtype=np.float64))  # noqa: E731
+        hx = [col(inp["x_ic"][:, b]), col(inp["u_ic"][:, b]), col(inp["X_ref"][:, :, b].T), col(inp["U_ref"][:, :, b].T), col(inp["T_ref"][:, b]),
+              col(inp["bound_left"][:, b]), col(inp["bound_right"][:, b]), col(inp["curvatures"][:, b]), col(inp["vel_ref"][:, b])]
+        X, U, dU = np.zeros((20, 6)), np.zeros((19, 2)), np.zeros((19, 2))
+        st, it = C.c_int32(-1), C.c_int32(-1)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+        rc = lib.lmpc_solve_host(h, *[p(a) for a in hx], C.c_double(tr["L"]), None, None, p(X), p(U), p(dU), None, C.byref(st), C.byref(it))
+        assert rc == 0 and st.value == ref_qp["status"][b]
+        assert np.array_equal(X.T, ref_qp["X_optm"][:, :, b]) and np.array_equal(U.T, ref_qp["U_optm"][:, :, b]) and np.array_equal(dU.T, ref_qp["dU_optm"][:, :, b])
+    finally:
+        solver.set_output_layout("soa")
