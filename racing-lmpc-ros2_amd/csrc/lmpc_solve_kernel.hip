@@ -360,7 +360,11 @@ template <> struct ipm_limits<float> {
 #define LMPC_F32_POL_FEAS 1e-5f
 #endif
 #ifndef LMPC_F32_POL_DUAL
-#define LMPC_F32_POL_DUAL 1e-3f
+// (1e-3 until round 4: at the per-GPU size of BASELINE configs[4] -- 32768 learning problems, regression on -- one answer
+//  verified with a held row's multiplier at -5e-4 sat 2.4e-3 from the fp64 answer; with 1e-4 the worst of the batch is 2.0e-4,
+//  the worst of the 8192 IAC problems 8.5e-5 (2.4e-4 before), and the second pass takes no measurable extra time:
+//  profiles/r04_f32_acceptance.md)
+#define LMPC_F32_POL_DUAL 1e-4f
 #endif
 #ifndef LMPC_F32_POL_STEP_TOL
 #define LMPC_F32_POL_STEP_TOL 1e-4f
@@ -1727,24 +1731,33 @@ __device__ __forceinline__ T* uni_ptr(T* p) {
   return reinterpret_cast<T*>(((unsigned long long)hi << 32) | lo);
 }
 
-// Where the polish is a call: the instantiations compiled for two waves per SIMD in fp64 (N <= 23 tracking: the headline).
-// The one-wave-per-SIMD instantiations keep it inline -- they spill to AGPRs, not to scratch, and a call site in the function
-// turns a part of those moves into scratch traffic inside the iteration (ISA census, round 4: N = 40 fp64 0 -> 57 reloads per
-// iteration, the fp64 learning kernel 0 -> 114) -- and so do the single-precision ones, whose iteration spills the same with
-// the polish inline, behind a call, or (nearly) compiled out: there it is the iteration's own state that does not fit.
-// (-DLMPC_POLISH_CALL=0 / 1: never / always, for A/B timing.)
+// Where the polish is a call, and where the sweeps take a fresh lane value (FRESH_LANE above) -- measured per instantiation in
+// round 4 (profiles/r04_polish_forms.md: {inline, call} x {fresh, not}, every (KQ, KS), checksums against the round-3 build):
+//   * fp64, one wave per SIMD (KQ >= 7 or the learning problem: the instantiations that live in VGPRs + AGPRs): a CALL.  The call
+//     form computes bit for bit what the round-3 kernel computed, at every horizon and for both problems; the inlined function
+//     does not: with FRESH_LANE in the factorisation AND the vector solve the <double, 7, 0> instance (N = 24 .. 40) returns
+//     different -- wrong -- answers (72 of 8192 IAC problems "infeasible"), the same wrong answers whatever the post-RA schedule
+//     or the wait counts, and the right ones again with SGPR spills sent to memory instead of VGPR lanes, or at -O2 (DESIGN.md
+//     section 4, "the register-starved instantiations").  The call costs the callee's prologue / epilogue and the spills around
+//     the call site, ~1 KB of scratch traffic per lane and call, and buys -5 .. -16 % of the kernel time from N = 60 on and for
+//     the learning problem from N = 40 on (nothing either way at N = 40 tracking).
+//   * fp64, two waves per SIMD (tracking up to N = 23: the headline): INLINED.  Same time as the call form (0.872 against 0.868 ms
+//     per 4096 at N = 20), bit for bit the round-3 answers, and 102 MB of HBM traffic per launch against 250 MB (round 3: 174 MB):
+//     at 256 VGPRs there are no AGPR copies for a call boundary to save, and the call's own spills are the larger traffic.
+//   * fp32 (single precision and the fp32 pass of the mixed entry): INLINED -- the call form is 10 % slower on the mixed learning
+//     kernel and changes single-precision roundings enough to lose four solves of 4096 at N = 80.
+//   * FRESH_LANE everywhere.
+// (-DLMPC_POLISH_CALL=0 / 1, -DLMPC_FRESH_POLICY=0 / 1: never / always, for A/B timing; scratch/r4_build_variants.sh.)
 #ifndef LMPC_POLISH_CALL
 #define LMPC_POLISH_CALL 2
 #endif
-#ifndef LMPC_FRESH_POLICY  // 0 never, 1 always, 2 per instantiation (below)
+#ifndef LMPC_FRESH_POLICY
 #define LMPC_FRESH_POLICY 2
 #endif
-constexpr bool lmpc_fresh_lane(int real_bytes, int kq, int ks) {
-  return LMPC_FRESH_POLICY == 1 || (LMPC_FRESH_POLICY == 2 && (real_bytes == 4 || (ks == 0 && (kq == 4 || kq >= 11))));
-}
 constexpr bool lmpc_polish_is_call(int real_bytes, int kq, int ks) {
-  return LMPC_POLISH_CALL == 1 || (LMPC_POLISH_CALL == 2 && real_bytes == 8 && lmpc_waves_per_simd(real_bytes, kq, ks) >= 2);
+  return LMPC_POLISH_CALL == 1 || (LMPC_POLISH_CALL == 2 && real_bytes == 8 && lmpc_waves_per_simd(real_bytes, kq, ks) < 2);
 }
+constexpr bool lmpc_fresh_lane(int real_bytes, int kq, int ks) { return LMPC_FRESH_POLICY != 0; }
 
 template <typename real, int KQ, int KS, typename io>
 __device__ __forceinline__ PolishResult<real, KS> lmpc_polish(const PolishArgs<real, KQ, KS>& a) {
@@ -3271,6 +3284,20 @@ __device__ __forceinline__ void lmpc_solve_problem(
         if (sx.on[q]) lam_out[(size_t)(lane + 64 * q) * B + b] = io(sx.lm[q]);
     }
   }
+#ifdef LMPC_DUMP_ROWS  // (scratch/r4_rowdump.py: the interior point's row state as it stands at the exit, every lane, behind the 4 B kkt values)
+  if (kkt_out) {
+    io* const dst = kkt_out + (size_t)4 * B + ((size_t)b * 64 + lane) * (6 * KQ);
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) {
+      dst[6 * q + 0] = io(s_tu[q]);
+      dst[6 * q + 1] = io(s_tl[q]);
+      dst[6 * q + 2] = io(s_lu[q]);
+      dst[6 * q + 3] = io(s_ll[q]);
+      dst[6 * q + 4] = io(s_pu[q]);
+      dst[6 * q + 5] = io(s_pl[q]);
+    }
+  }
+#endif
   if (lane == 0) {
     status_out[b] = status;
     iters_out[b] = it;
