@@ -29,9 +29,9 @@ ALGO_BYTES_PER_SOLVE = (13 * 20 + 5) * 8 + (10 * 20 - 4) * 8 + 8  # 3696 B at N 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
 
 
-def measured_traffic_bytes(pmc_file="r03_pmc.json", kernel="lmpc_solve_kernel<double, 4, 0"):
+def measured_traffic_bytes(pmc_file="r04_pmc.json", kernel="lmpc_solve_kernel<double, 4, 0"):
     """HBM bytes per launch of the QP kernel from the committed rocprofv3 PMC passes of this same command
-    (profiles/r03_pmc.json: FETCH_SIZE and WRITE_SIZE are reported in KiB, collected in separate --pmc runs).
+    (profiles/r04_pmc.json: FETCH_SIZE and WRITE_SIZE are reported in KiB, collected in separate --pmc runs).
     The gfx950 FETCH_SIZE x2 correction of MI355X_MICROARCH.md applies to wide coalesced streams only; this
     kernel's reads are 8-byte strided or L2/MALL-resident workspace lines, so the raw counter is reported."""
     try:
@@ -89,7 +89,7 @@ def live_traffic_bytes(workload_argv, kernel):
         return None
 
 
-def engine_utilisation(kernel_ms, pmc_file="r03_pmc.json", kernel="lmpc_solve_kernel<double, 4, 0"):
+def engine_utilisation(kernel_ms, pmc_file="r04_pmc.json", kernel="lmpc_solve_kernel<double, 4, 0"):
     """What actually bounds the QP kernel: busy fractions of the FP64 VALU and of the LDS pipeline from the same
     committed PMC passes (SQ_ACTIVE_INST_VALU is in 4-cycle units summed over waves, one VALU per SIMD, 4 SIMDs x
     256 CUs; SQ_LDS_IDX_ACTIVE in cycles summed over the 256 CU-local LDS pipelines), against the kernel duration of
@@ -488,6 +488,10 @@ def main():
     elapsed = time.perf_counter() - t0
     one_stream_value = None
     if world == 1 and S > 1:  # the same steps strictly one after the other, for reference
+        # (on the default stream, which has not launched these kernels yet: its first launch grows that queue's scratch
+        #  arena -- a one-off of ~20 ms at the 1.5 KB frames of the N = 60 kernels -- and belongs to initialisation like the
+        #  first launches on the other streams)
+        solve_step(0)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for k in range(args.steps):
@@ -557,7 +561,7 @@ def main():
             algo_bytes += (7 + 1) * 160 * 8  # + ss_x, ss_j in and lambda out (13 936 B at S = 160)
         achieved = algo_bytes * B / (sol_avg * 1e-3) / 1e9
         # committed PMC passes of this command: tracking, or the learning problem with 160 safe-set points
-        pmc_sel = ("r03_pmc_lmpc.json", "lmpc_solve_kernel<double, 4, 3") if lmpc else ("r03_pmc.json", "lmpc_solve_kernel<double, 4, 0")
+        pmc_sel = ("r04_pmc_lmpc.json", "lmpc_solve_kernel<double, 4, 3") if lmpc else ("r04_pmc.json", "lmpc_solve_kernel<double, 4, 0")
         pmc_shape = not (N != 20 or B != 4096 or iac or f32 or mixed)  # the shape the committed passes were taken on
         traffic, traffic_source = None, None
         if world == 1 and not args.no_pmc:

@@ -3355,8 +3355,12 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
 // return at once costs more than the solves (38 KB of LDS and 500 registers to allocate per workgroup: 1.3 ms per 8192).
 // The solve is a CALL here, not inlined into the loop: with the 3000-line body inlined under a loop the <double, 7, 3>
 // instance computed garbage (nondeterministically; the same body without the loop, or called once per workgroup, is bit
-// for bit the direct kernel -- scratch/r3_cleanup_dbg.py); behind a call boundary every instance is.  The callee names the
-// workgroup's dynamic LDS block itself, so its accesses stay in the LDS address space.
+// for bit the direct kernel -- scratch/r3_cleanup_dbg.py); behind a call boundary every instance is.  Round 4 met the same
+// family deterministically in <double, 7, 0> and bisected it ("the register-starved instantiations":
+// the answers of these 460-to-512-register functions depend on how the compiler parks spilled scalars in VGPR lanes; wait
+// counts, post-RA scheduling and the machine verifier are ruled out): the noinline works around exactly that -- a call
+// boundary is the one thing that has kept every build of this family right.  The callee names the workgroup's dynamic
+// LDS block itself, so its accesses stay in the LDS address space.
 template <typename real, int KQ, int KS, typename io>
 __device__ __attribute__((noinline)) void lmpc_solve_problem_call(
     const lmpc_params& P, const int B, const int b, const io* __restrict__ ws_lin, const io* __restrict__ x_ic,
