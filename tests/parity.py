@@ -55,5 +55,11 @@ def assert_same_iterations(a, b):
     refuses (a held row met to 0.9e-9 or 1.1e-9) costs the refusing one the three to five interior-point iterations down to
     its own tolerance; a problem crawling at the floor of fp64 (mu a few 1e-14) dips under the tolerance an iteration
     apart.  Both end at the same optimum (the value tests hold them to 1e-6 of each other)."""
-    d = np.abs(np.asarray(a).astype(int) - np.asarray(b).astype(int))
+    a, b = np.asarray(a).astype(int), np.asarray(b).astype(int)
+    d = np.abs(a - b)
     assert (d == 0).mean() >= 0.9 and (d <= 1).mean() >= 0.95 and d.max() <= 8, (float((d == 0).mean()), float((d <= 1).mean()), int(d.max()))
+    # ... and the borderline decisions fall both ways: a kernel whose polish were refused (or accepted) systematically more
+    # often than the twin's would move the MEAN count, which a handful of individual differences of up to 8 does not
+    # (ADVICE r3: the per-problem bound alone was loosened from 2 to 8 when the polish arrived)
+    if a.size >= 16:
+        assert abs(a.mean() - b.mean()) <= 0.25, (float(a.mean()), float(b.mean()))

@@ -507,6 +507,10 @@ def test_full_dynamics_sqp_reaches_kkt_points_of_the_nlp(pkg):
           x[conv, 3].min(), "largest rho converged", rho[conv].max(), "; QP status", np.bincount(nlp["status"], minlength=3))
     assert model_ok.sum() >= 60 and conv[model_ok].mean() >= 0.99, (conv[model_ok].mean(), np.bincount(nlp["status"]), np.sort(nlp["sqp_move"][model_ok])[-5:])
     assert conv.mean() > 0.78
+    # the statement the test made before the rho class was introduced, kept next to it: of the starts above
+    # 1.6 m/s -- where the 25 ms RK4 step of the tyre model is well inside its stability region -- more than 94 % converge
+    fast = x[:, 3] > 1.6
+    assert fast.sum() >= 30 and conv[fast].mean() > 0.94, (int(fast.sum()), float(conv[fast].mean()))
     assert nlp["defect"][conv].max() < 1e-7 and (nlp["sqp_iters"][conv] >= 2).all()
 
     def defect(o):
@@ -684,6 +688,7 @@ def test_lmpc_at_other_horizons_matches_the_twin(pkg, N, n_laps):
     #  the stopping rules -- and the acceptance of a polish attempt -- can fall differently on an odd problem)
     d = np.abs(o["iters"][ok] - twin["iters"][ok])
     assert d.max() <= 8 and (d <= 1).mean() >= 0.9 and (d == 0).mean() >= 0.8, d
+    assert abs(o["iters"][ok].mean() - twin["iters"][ok].mean()) <= 0.5, (o["iters"][ok].mean(), twin["iters"][ok].mean())   # (32 problems)
     e = np.abs((o["X_optm"] - twin["X_optm"]) / P.SCALE_X[:, None, None]).max(axis=(0, 1))[ok]
     # (the learning cost has no tracking terms, so the optimum is flat in more directions than the tracking problem's: until
     #  the polish kernel and twin sat up to a few 1e-6 apart on the flattest problems)
