@@ -1651,6 +1651,120 @@ __device__ __forceinline__ void riccati_solve_lean(const Lds<real>& L, ModelStre
   PT_MARK(10 + NRHS - 1)
 }
 
+// The lean vector solve with the running vector in registers (DPP row broadcasts, as riccati_solve) instead of one LDS round
+// trip per stage: at one wave per SIMD a sweep stage costs what its instruction count costs (~4.5 cycles each, nothing to
+// overlap with), and the exchange through LDS is a third of the lean stage's instructions.  Same arithmetic per output as
+// riccati_solve_lean (bit for bit); lane (s, r) = ((lane >> 4) % NRHS, lane & 7), lanes 8..15 of a row mirror 0..7.
+template <int NRHS, typename real>
+__device__ __forceinline__ void riccati_solve_lean_dpp(const Lds<real>& L, ModelStream<real>& M, int lane, Prof& pf) {
+  FRESH_LANE(lane, 5);
+  const int N = L.N;
+  const int r = lane & 7, s = (lane >> 4) & (NRHS - 1);
+  const bool own = (lane & 8) == 0 && lane < 16 * NRHS;
+  const int reg = KN_R0 + 10 * s;
+  real* T = L.tail();
+  real* const junk0 = T + TL_W + lane;
+  real* const junk1 = T + TL_W + 80 + lane;
+  const real m6 = (r >= 6) ? real(1) : real(0);
+  const int o_ha = r == 0 ? LN_HI : LN_HI + 1, o_hb = r == 0 ? LN_HI + 1 : LN_HI11;
+  // ---- backward
+  {
+    const int ch = (N - 2) / LN_CHUNK;
+    M.ensure(ch);
+    M.wait();
+    if (ch > 0) M.ensure(ch - 1);
+  }
+  real p = L.kn(N - 1)[reg + r];
+  real row[6];
+  {
+    const real* ab = M.stage(N - 2);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) row[k] = ab[6 * r + k];
+  }
+  for (int i = N - 2; i >= 0; --i) {
+    real* st = L.st(i);
+    const real* kn = L.kn(i);
+    if ((i % LN_CHUNK) == 0 && i > 0) {  // (see riccati_solve_lean)
+      M.wait();
+      if (i / LN_CHUNK >= 2) M.fetch(i / LN_CHUNK - 2);
+    }
+    const real k0r = st[2 * r], k1r = st[2 * r + 1], t = st[LN_DT];
+    const real qz = kn[reg + r], qv0 = kn[reg + 8], qv1 = kn[reg + 9];
+    const real ha = st[o_ha], hb = st[o_hb];
+    real pb[6];
+    row_bcast6(p, pb);
+    real w = m6 * p;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) w = rfma(row[k], pb[k], w);
+    real w6, w7;
+    row_bcast67(w, w6, w7);
+    {
+      const real* abn = M.stage(i > 0 ? i - 1 : 0);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) row[k] = abn[6 * r + k];
+    }
+    const real hv0 = rfma(t, w6, qv0);
+    const real hv1 = rfma(t, w7, qv1);
+    p = qz + w - (k0r * hv0 + k1r * hv1);
+    const real kff = ha * hv0 + hb * hv1;
+    *((own && r < 2) ? st + LN_KFF(s) + r : junk1) = kff;
+  }
+  wave_sync();
+  PT_MARK(8 + NRHS - 1)
+  // ---- forward
+  const int nch = (N - 2) / LN_CHUNK + 1;
+  M.ensure(0);
+  *(own ? L.kn(0) + reg + r : junk0) = 0.0;
+  M.wait();
+  if (nch > 1) M.ensure(1);
+  const int cb = r < 6 ? r : 0;
+  const int cstride = r < 6 ? 6 : 2;
+  real d = 0.0;
+  real col[8], a0, b0n, b1n;
+  auto load_stage = [&](int i) {
+    const real* ab = M.stage(i);
+    const real* st = L.st(i);
+    {
+      const real* const cbase = r < 6 ? ab + cb : st + (r - 6);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) col[k] = cbase[k * cstride];
+    }
+    a0 = st[LN_KFF(s) + (r & 1)];
+    b0n = ab[36 + cb];
+    b1n = ab[42 + cb];
+  };
+  load_stage(0);
+  wave_sync();
+  for (int i = 0; i < N - 1; ++i) {
+    const real* st = L.st(i);
+    real* kn = L.kn(i);
+    if ((i % LN_CHUNK) == LN_CHUNK - 1 && i < N - 2) {
+      M.wait();
+      if (i / LN_CHUNK + 2 < nch) M.fetch(i / LN_CHUNK + 2);
+    }
+    const real b0 = b0n, b1 = b1n, t = st[LN_DT];
+    real dz[8];
+    row_bcast8(d, dz);
+    real acc = m6 * a0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) acc = rfma(col[k], dz[k], acc);
+    const real ax = acc;
+    acc = rfma(col[6], dz[6], acc);
+    acc = rfma(col[7], dz[7], acc);
+    const real dv = -acc;
+    const real du = rfma(t, dv, d);
+    real du0, du1;
+    row_bcast67(du, du0, du1);
+    load_stage(i < N - 2 ? i + 1 : i);
+    const real nx = rfma(b1, du1, rfma(b0, du0, ax));
+    d = (r < 6) ? nx : du;
+    *(own ? kn + LMPC_KNOT_STRIDE + reg + r : junk0) = d;
+    *((own && r >= 6) ? kn + reg + 2 + r : junk1) = dv;
+  }
+  wave_sync();
+  PT_MARK(10 + NRHS - 1)
+}
+
 template <typename real>
 __device__ __forceinline__ void feedback_rollout_lean(const Lds<real>& L, ModelStream<real>& M, int lane) {
   FRESH_LANE(lane, 6);
@@ -1706,6 +1820,20 @@ __device__ __forceinline__ void feedback_rollout_lean(const Lds<real>& L, ModelS
 // (its accesses stay DS instructions).  Slacks and multipliers of the interior point are not touched; the iterate is put
 // aside in the handle's save area and comes back unless the attempt is accepted.  Wave-uniform values arrive in vector
 // registers (the calling convention has no scalar arguments) and go back to scalar registers first thing.
+// which lean vector solve: the DPP form (round 4: bit for bit the LDS-exchange form of round 3 on every long-horizon family, and
+// -8 % of the kernel at N = 60 tracking, -4 % at N = 80, -4 / -12 % for the learning problem at N = 60 / 80;
+// -DLMPC_LEAN_DPP=0 builds the LDS exchange for A/B).  Rounds 2-3 kept DPP out of the one-wave-per-SIMD kernels after a
+// non-reproducible KQ = 14 / KS = 3 build; with the polish behind a call that family has been bit-stable in every build of
+// round 4 (two repetitions of every case here, the reproducibility scripts on the final build).
+#ifndef LMPC_LEAN_DPP
+#define LMPC_LEAN_DPP 1
+#endif
+#if LMPC_LEAN_DPP
+#define LMPC_LEAN_SOLVE riccati_solve_lean_dpp
+#else
+#define LMPC_LEAN_SOLVE riccati_solve_lean
+#endif
+
 template <typename real, int KQ, int KS>
 struct PolishArgs {
   void* keep;      // this problem's block of the save area
@@ -2063,9 +2191,9 @@ __device__ __forceinline__ PolishResult<real, KS> lmpc_polish(const PolishArgs<r
       wave_sync();
       if constexpr (LEAN) {
         if (k == 0 && has_sigma)
-          riccati_solve_lean<2>(L, MS, lane, pf);
+          LMPC_LEAN_SOLVE<2>(L, MS, lane, pf);
         else
-          riccati_solve_lean<1>(L, MS, lane, pf);
+          LMPC_LEAN_SOLVE<1>(L, MS, lane, pf);
       } else if constexpr (lmpc_waves_per_simd(sizeof(real), KQ, KS) < 2) {
         if (k == 0 && has_sigma)
           riccati_solve_lds<2>(L, lane, pf);
@@ -2968,9 +3096,9 @@ __device__ __forceinline__ void lmpc_solve_problem(
       // family takes the risk.  Every instantiation as built is bitwise reproducible (scratch/r2_det_all.sh).
       if constexpr (LEAN) {
         if (pass == 0 && ipm && has_sigma)
-          riccati_solve_lean<2>(L, MS, lane, pf);
+          LMPC_LEAN_SOLVE<2>(L, MS, lane, pf);
         else
-          riccati_solve_lean<1>(L, MS, lane, pf);
+          LMPC_LEAN_SOLVE<1>(L, MS, lane, pf);
       } else if constexpr (lmpc_waves_per_simd(sizeof(real), KQ, KS) < 2) {
         if (pass == 0 && ipm && has_sigma)
           riccati_solve_lds<2>(L, lane, pf);

@@ -1,0 +1,6 @@
+#!/bin/bash
+mkdir -p gpurun_out
+python scratch/phase_timing.py 60 4096 > gpurun_out/r4h_phase_n60.txt 2>&1
+python scratch/phase_timing.py 20 4096 > gpurun_out/r4h_phase_n20.txt 2>&1
+python scratch/phase_timing.py 80 4096 > gpurun_out/r4h_phase_n80.txt 2>&1
+head -22 gpurun_out/r4h_phase_n60.txt; head -22 gpurun_out/r4h_phase_n20.txt
