@@ -1820,6 +1820,13 @@ __device__ __forceinline__ void feedback_rollout_lean(const Lds<real>& L, ModelS
 // (its accesses stay DS instructions).  Slacks and multipliers of the interior point are not touched; the iterate is put
 // aside in the handle's save area and comes back unless the attempt is accepted.  Wave-uniform values arrive in vector
 // registers (the calling convention has no scalar arguments) and go back to scalar registers first thing.
+// the fat-layout kernels that run one wave per SIMD (fp64, N = 24 .. 40, and the fp64 learning kernels): the DPP form of the vector
+// solve that the two-wave kernels use (round 4: bit for bit the LDS-exchange form, -3 % at N = 40 tracking / IAC, -2 % on the
+// learning kernel at N = 20, nothing at N = 40 learning; -DLMPC_FAT_DPP=0 builds the LDS exchange of rounds 2-3 for A/B)
+#ifndef LMPC_FAT_DPP
+#define LMPC_FAT_DPP 1
+#endif
+constexpr bool lmpc_solve_through_lds(int real_bytes, int kq, int ks) { return !LMPC_FAT_DPP && lmpc_waves_per_simd(real_bytes, kq, ks) < 2; }
 // which lean vector solve: the DPP form (round 4: bit for bit the LDS-exchange form of round 3 on every long-horizon family, and
 // -8 % of the kernel at N = 60 tracking, -4 % at N = 80, -4 / -12 % for the learning problem at N = 60 / 80;
 // -DLMPC_LEAN_DPP=0 builds the LDS exchange for A/B).  Rounds 2-3 kept DPP out of the one-wave-per-SIMD kernels after a
@@ -2194,7 +2201,7 @@ __device__ __forceinline__ PolishResult<real, KS> lmpc_polish(const PolishArgs<r
           LMPC_LEAN_SOLVE<2>(L, MS, lane, pf);
         else
           LMPC_LEAN_SOLVE<1>(L, MS, lane, pf);
-      } else if constexpr (lmpc_waves_per_simd(sizeof(real), KQ, KS) < 2) {
+      } else if constexpr (lmpc_solve_through_lds(sizeof(real), KQ, KS)) {
         if (k == 0 && has_sigma)
           riccati_solve_lds<2>(L, lane, pf);
         else
@@ -3088,18 +3095,15 @@ __device__ __forceinline__ void lmpc_solve_problem(
       wave_sync();
       // ======== Newton step: predictor together with the Schur vector, then the corrector ========
       PT_MARK(4)
-      // The DPP form of the sweeps only in the instantiations built for two or more waves per SIMD (tracking up to N = 23
-      // in fp64, the fp32 / mixed kernels up to N = 40): they fit the architectural VGPRs.  The others -- one wave per SIMD,
-      // AGPRs as spill space, up to 1.7 KB of scratch per lane -- keep the LDS exchange: they gain little from DPP (N = 60:
-      // 11.03 against 11.05 ms; the learning kernel 3 %), and the most register-starved of them (KQ = 14, KS = 3) was NOT
-      // reproducible from run to run with it, for a reason that was not found -- so none of that
-      // family takes the risk.  Every instantiation as built is bitwise reproducible (scratch/r2_det_all.sh).
+      // Every instantiation runs the DPP form of the sweeps since round 4 (lmpc_solve_through_lds / LMPC_LEAN_DPP above).  Rounds
+      // 2-3 kept the LDS exchange in the one-wave-per-SIMD kernels after a KQ = 14 / KS = 3 build that was not reproducible from
+      // run to run with DPP; with the polish behind a call that family has been bit-stable in every build.
       if constexpr (LEAN) {
         if (pass == 0 && ipm && has_sigma)
           LMPC_LEAN_SOLVE<2>(L, MS, lane, pf);
         else
           LMPC_LEAN_SOLVE<1>(L, MS, lane, pf);
-      } else if constexpr (lmpc_waves_per_simd(sizeof(real), KQ, KS) < 2) {
+      } else if constexpr (lmpc_solve_through_lds(sizeof(real), KQ, KS)) {
         if (pass == 0 && ipm && has_sigma)
           riccati_solve_lds<2>(L, lane, pf);
         else
