@@ -355,16 +355,17 @@ template <> struct ipm_limits<float> {
 // point's own tolerance, and the stabilised factorisations of those iterations are the ones it saves -- and again at
 // convergence if refused; single precision polishes at its convergence (mu ~ 2e-6), where it turns "within sqrt(mu) of the
 // optimum" into "the optimum to the accuracy of an fp32 solve".
-// (the acceptance test of the single-precision polish: -D overrides for the tail measurements of scratch/r4_tail.py)
+// The acceptance test of the single-precision polish (-D overrides: the tail measurements behind profiles/r04_f32_acceptance.md).
+// Until round 4: rows to 1e-5, multipliers to -1e-3.  At the batch sizes one GPU runs, that let three answers of 65536 learning
+// problems through that the fp32 KKT test verified and the fp64 kernel contradicts: 2.4e-3 away with the regression on (a held
+// row's multiplier between -1e-3 and -3e-4), 1.2e-3 and 1.0e-3 without it (a multiplier at -7e-5; a row violated by 3.8e-6).
+// With rows to 3e-6 and multipliers to -3e-5 the worst of four 32768-batches is 9.0e-4 (one problem; every other below 2.5e-5)
+// and the worst IAC problem 8.5e-5; the fp64 pass gets 4 more problems of 32768 and the solve takes the same time.
 #ifndef LMPC_F32_POL_FEAS
-#define LMPC_F32_POL_FEAS 1e-5f
+#define LMPC_F32_POL_FEAS 3e-6f
 #endif
 #ifndef LMPC_F32_POL_DUAL
-// (1e-3 until round 4: at the per-GPU size of BASELINE configs[4] -- 32768 learning problems, regression on -- one answer
-//  verified with a held row's multiplier at -5e-4 sat 2.4e-3 from the fp64 answer; with 1e-4 the worst of the batch is 2.0e-4,
-//  the worst of the 8192 IAC problems 8.5e-5 (2.4e-4 before), and the second pass takes no measurable extra time:
-//  profiles/r04_f32_acceptance.md)
-#define LMPC_F32_POL_DUAL 1e-4f
+#define LMPC_F32_POL_DUAL 3e-5f
 #endif
 #ifndef LMPC_F32_POL_STEP_TOL
 #define LMPC_F32_POL_STEP_TOL 1e-4f
@@ -3549,6 +3550,9 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
 #ifdef LMPC_SINGLE_INSTANCE  // (ISA inspection: hipcc -S -DLMPC_SINGLE_INSTANCE="double, 4, 3, double")
 #define LMPC_INSTANTIATE_X(...) LMPC_INSTANTIATE(__VA_ARGS__)
 LMPC_INSTANTIATE_X(LMPC_SINGLE_INSTANCE)
+#elif defined(LMPC_MINREG_TU)  // lmpc_lib_minreg.hip: the two kernels that translation unit exists for
+LMPC_INSTANTIATE(float, 4, 2, double)
+LMPC_INSTANTIATE(float, 4, 3, double)
 #else
 LMPC_INSTANTIATE(double, 2, 0, double)
 LMPC_INSTANTIATE(double, 4, 0, double)
@@ -3574,8 +3578,14 @@ LMPC_INSTANTIATE(float, 4, 0, double)
 LMPC_INSTANTIATE(float, 7, 0, double)
 LMPC_INSTANTIATE(float, 11, 0, double)  // iac_car_tracking_mpc.param.yaml ships N = 80
 LMPC_INSTANTIATE(float, 14, 0, double)
-LMPC_INSTANTIATE(float, 4, 2, double)  // the learning problem, N <= 23 (BASELINE configs[4])
-LMPC_INSTANTIATE(float, 4, 3, double)
+// the learning problem, N <= 23 (BASELINE configs[4]): instantiated in a translation unit of their own (lmpc_lib_minreg.hip),
+// which is compiled with -mllvm -amdgpu-sched-strategy=iterative-minreg -- the most spill-bound kernel of the library is the one
+// place where the minimum-register scheduler pays (131 against 184 spilled VGPRs, 9.93 against 10.65 ms per 32768, same bits;
+// every other kernel is 3-20 % slower with it: profiles/r04_sched_strategies.md).  Here: declarations only.
+extern template __global__ void lmpc_solve_kernel<float, 4, 2, double>(lmpc_params, int, const double*, const double*, const double*, const double*,
+    const double*, const double*, const double*, const double*, const double*, double*, double*, double*, double*, int*, int*, double*);
+extern template __global__ void lmpc_solve_kernel<float, 4, 3, double>(lmpc_params, int, const double*, const double*, const double*, const double*,
+    const double*, const double*, const double*, const double*, const double*, double*, double*, double*, double*, int*, int*, double*);
 #ifdef LMPC_MIXED_LONG_LEARNING  // the learning problem at the horizons the reference ships for it (barc_lmpc N = 40, iac_car_lmpc N = 60)
 LMPC_INSTANTIATE(float, 7, 2, double)
 LMPC_INSTANTIATE(float, 7, 3, double)

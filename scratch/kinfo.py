@@ -7,10 +7,18 @@ d = tempfile.mkdtemp()
 out = os.path.join(d, "co")
 fb = os.path.join(d, "fb")
 subprocess.check_call([LL + "llvm-objcopy", "-O", "binary", "--only-section=.hip_fatbin", lib, fb])
-r = subprocess.run([LL + "clang-offload-bundler", "--unbundle", "--type=o", "--input=" + fb, "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + out], capture_output=True, text=True)
-if r.returncode != 0:
-    print(r.stderr); sys.exit(1)
-notes = subprocess.run([LL + "llvm-readelf", "--notes", out], capture_output=True, text=True).stdout
+# one offload bundle per translation unit of the library (lmpc_lib.hip, lmpc_lib_minreg.hip), back to back in the section
+blob = open(fb, "rb").read()
+magic = b"__CLANG_OFFLOAD_BUNDLE__"
+starts = [i for i in range(len(blob)) if blob.startswith(magic, i)]
+notes = ""
+for n, a in enumerate(starts):
+    part = os.path.join(d, "fb%d" % n)
+    open(part, "wb").write(blob[a:starts[n + 1] if n + 1 < len(starts) else len(blob)])
+    r = subprocess.run([LL + "clang-offload-bundler", "--unbundle", "--type=o", "--input=" + part, "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + out + str(n)], capture_output=True, text=True)
+    if r.returncode != 0:
+        print(r.stderr); sys.exit(1)
+    notes += subprocess.run([LL + "llvm-readelf", "--notes", out + str(n)], capture_output=True, text=True).stdout
 blocks = re.split(r"\n\s*- \.agpr_count:", notes)
 for b in blocks[1:]:
     g = lambda key: (re.search(r"\." + key + r":\s*(\S+)", b) or [None, "?"])[1]

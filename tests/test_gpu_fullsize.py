@@ -50,23 +50,26 @@ def _check(tag, o64, ox):
     return e
 
 
-def test_configs4_share_of_one_gpu_every_problem(pkg):
+@pytest.mark.parametrize("regression", [True, False])
+def test_configs4_share_of_one_gpu_every_problem(pkg, regression):
     """configs[4] as bench.py runs it on one GPU: learning problem, 160 points, batch 32768, regression on, mixed against
-    fp64 (the fp64 solve sees the same corrected model)."""
+    fp64 (the fp64 solve sees the same corrected model) -- and the same batch without the regression (bench.py's
+    lmpc_b32768_mixed line; round 3's "two problems at 1.0-1.2e-3" were here)."""
     B, dev = 32768, "cuda"
     tr = pkg.workloads.synthetic_track("barc")
     laps = pkg.workloads.synthetic_laps(tr, 5)
     cfgd = pkg.presets.barc_lmpc(20, 5)
     pv = dict(pkg.presets.barc_vehicle())
     pv["mu"] *= 0.85
-    plant = pkg.Solver(cfgd, pv, device=0)
-    reg_laps = pkg.workloads.regression_sample_pairs(
-        tr, laps, lambda xa, ua: plant.plant_step(tr, torch.as_tensor(xa.T.copy(), device=dev), torch.as_tensor(ua.T.copy(), device=dev),
-                                                  0.03).cpu().numpy().T)
-    plant.close()
     sv = pkg.Solver(cfgd, pkg.presets.barc_vehicle(), device=0)
     sv.set_safe_set(laps, tr["L"])
-    sv.set_regression_laps(reg_laps, dist_max=0.6)
+    if regression:
+        plant = pkg.Solver(cfgd, pv, device=0)
+        reg_laps = pkg.workloads.regression_sample_pairs(
+            tr, laps, lambda xa, ua: plant.plant_step(tr, torch.as_tensor(xa.T.copy(), device=dev), torch.as_tensor(ua.T.copy(), device=dev),
+                                                      0.03).cpu().numpy().T)
+        plant.close()
+        sv.set_regression_laps(reg_laps, dist_max=0.6)
     x, u = pkg.workloads.sample_states_near_laps(laps, B, tr["L"], seed=0)
     inp = sv.prepare(tr, x.T.copy(), 0.025)
     inp["u_ic"] = torch.as_tensor(u.T.copy(), dtype=torch.float64, device=dev)
@@ -82,7 +85,7 @@ def test_configs4_share_of_one_gpu_every_problem(pkg):
 
     o64, om = solve(False), solve(True)
     assert (o64["status"] == 0).mean() > 0.999, np.bincount(o64["status"])
-    _check("configs[4] share (learning, 160 pts, regression, mixed)", o64, om)
+    _check("configs[4] share (learning, 160 pts, %s, mixed)" % ("regression" if regression else "no regression"), o64, om)
     lam = om["convex_combi_optm"][:, om["status"] == 0]
     assert np.abs(lam.sum(0) - 1.0).max() < 1e-8 and lam.min() > -1e-9     # the simplex rows are fp64 in either pass
     sv.close()
