@@ -799,6 +799,9 @@ struct Lds {
 #define LN_DT 19
 #define LN_KFF(s) ((s) ? 22 : 20)
 constexpr bool lmpc_lean(int real_bytes, int kq) { return real_bytes == 8 && kq >= 11; }
+#ifndef LMPC_FETCH_FRESH
+#define LMPC_FETCH_FRESH 1
+#endif
 template <typename real>
 struct ModelStream {
   const real* ws;  // this problem's [N - 1][LN_REC] in the workspace (HBM / L2)
@@ -820,8 +823,15 @@ struct ModelStream {
     const int lo = ch * LN_CHUNK * LN_REC;
     const int n = min(LN_CHUNK * LN_REC, NS * LN_REC - lo);
     real* const dst = buf + (ch & 1) * LN_CHUNK * LN_REC;
-    const real* const src = ws + lo + 2 * lane;
-    const int e = 2 * lane;
+    // (the per-lane source address from a lane number the optimiser cannot see through: hoisted out of the sweeps as the loop
+    //  invariant it is, the 64-bit address was spilled, and each of the four copies below then waited -- vmcnt(0): for its own
+    //  reload AND the copy before it -- four memory round trips in a row per chunk; LMPC_FETCH_FRESH)
+    int fl = lane;
+#if LMPC_FETCH_FRESH
+    asm volatile("" : "+v"(fl));
+#endif
+    const real* const src = ws + lo + 2 * fl;
+    const int e = 2 * fl;
     static_assert(sizeof(real) == 8 && (LN_CHUNK * LN_REC + 127) / 128 == 4, "four 1 KB slices per chunk");
 #define LMPC_GLDS(J)                                                                                                   \
   if (e + 128 * J < n)                                                                                                 \
@@ -2445,6 +2455,35 @@ __device__ __attribute__((noinline)) PolishResult<real, KS> lmpc_polish_call(con
 // precision, <float, float> the single-precision path, <float, double> the mixed path (fp64 linearisation, regression,
 // safe-set centring and results around an fp32 interior-point iteration).
 // One problem, solved by the calling wavefront in the LDS block it is given (the body of both kernels below).
+// Row-phase policies, per instantiation by measurement (profiles/r04_row_phases.md):
+//   slots per chunk -- the long-horizon fp64 tracking kernels take their 11 / 14 slots half at a time (load, compute, store);
+//   opaque slot tables (SlotRef below) -- the long-horizon fp64 kernels and every learning kernel.
+// (fp32 at KQ >= 11 has no spills to begin with and loses 2-3 % to either; KQ <= 7 tracking loses 1-3 % to the opaque tables;
+//  the learning kernels at KQ >= 11 lose 15 % to the chunks.)
+#ifndef LMPC_ROW_CHUNK
+#define LMPC_ROW_CHUNK(kq) (((kq) + 1) / 2)
+#endif
+#ifndef LMPC_ROW_CHUNK_MIN_KQ
+#define LMPC_ROW_CHUNK_MIN_KQ 11
+#endif
+#ifndef LMPC_ROW_CHUNK_LEARNING
+#define LMPC_ROW_CHUNK_LEARNING 0
+#endif
+#ifndef LMPC_OPAQUE_MIN_KQ
+#define LMPC_OPAQUE_MIN_KQ 11
+#endif
+#ifndef LMPC_OPAQUE_LEARNING
+#define LMPC_OPAQUE_LEARNING 1
+#endif
+__host__ __device__ constexpr int lmpc_row_chunk(int real_bytes, int kq, int ks) {
+  return (real_bytes == 8 && kq >= LMPC_ROW_CHUNK_MIN_KQ && (ks == 0 || LMPC_ROW_CHUNK_LEARNING) && LMPC_ROW_CHUNK(kq) > 0 && LMPC_ROW_CHUNK(kq) < kq)
+             ? LMPC_ROW_CHUNK(kq)
+             : kq;
+}
+__host__ __device__ constexpr bool lmpc_opaque_slots(int real_bytes, int kq, int ks) {
+  return (real_bytes == 8 && kq >= LMPC_OPAQUE_MIN_KQ) || (ks > 0 && LMPC_OPAQUE_LEARNING);
+}
+
 template <typename real, int KQ, int KS, typename io>
 __device__ __forceinline__ void lmpc_solve_problem(
     const lmpc_params& P, const int B, const int b, unsigned char* lds_raw, const io* __restrict__ ws_lin,
@@ -2463,6 +2502,10 @@ __device__ __forceinline__ void lmpc_solve_problem(
   // single precision carries the abscissa relative to x_ic[0] (the QP is invariant to the shift: A(:, s) = e_s)
   const io s_shift = sizeof(real) == 4 ? x_ic[b] : io(0);
   constexpr bool LEAN = lmpc_lean(sizeof(real), KQ);
+  // slots a row phase loads, computes and stores in one go: all of them where the registers hold the temporaries of all KQ at
+  // once; LMPC_ROW_CHUNK at a time in the long-horizon kernels (KQ >= 11: 11-14 slots x 7 operands on top of 12 doubles of row
+  // state per slot do not fit 512 registers, and what the allocator spills is the row state)
+  constexpr int QC = lmpc_row_chunk(sizeof(real), KQ, KS);
   Lds<real> L{lds, N, LEAN ? LMPC_LEAN_STAGE_STRIDE : LMPC_STAGE_STRIDE, lmpc_fresh_lane(sizeof(real), KQ, KS)};
   real* T = L.tail();
   real* ct = T + TL_CT;
@@ -2595,6 +2638,21 @@ __device__ __forceinline__ void lmpc_solve_problem(
   auto o_w = [&](int q) { return o_val[q] + ((flags(q) & F_EY) ? KN_EY - 1 : KN_R0); };
   auto o_csig = [&](int q) { return (flags(q) & F_EY) ? o_val[q] + (KN_CSIG - 1) : JB + KN_CSIG; };
   auto bounds = [&](int q) { return *reinterpret_cast<const real2*>(&lds[o_hl[q]]); };
+  // The slot's three table entries as the row phases of the iteration read them.  Where lmpc_opaque_slots says so they pass
+  // through an empty asm first: every LDS address of a slot is loop-invariant, so the optimiser hoists all of them out of the
+  // iteration -- eight addresses per slot where the tables hold three integers --, the allocator spills them, and each use then
+  // waits on its own scratch reload (`scratch_load_dword; s_waitcnt vmcnt(0); ds_read`: a gradient evaluation at KQ = 11 was ~60 of
+  // those in a row).  Behind the asm the addresses are recomputed from the tables with a handful of integer instructions.
+  struct SlotRef { int ov, oh, gf; };
+  auto slot = [&](int q) {
+    SlotRef r{o_val[q], o_hl[q], s_gf[q]};
+    if constexpr (lmpc_opaque_slots(sizeof(real), KQ, KS)) asm volatile("" : "+v"(r.ov), "+v"(r.oh), "+v"(r.gf));
+    return r;
+  };
+  auto r_flags = [](const SlotRef& r) { return r.gf >> 20; };
+  auto r_w = [&](const SlotRef& r) { return r.ov + ((r_flags(r) & F_EY) ? KN_EY - 1 : KN_R0); };
+  auto r_csig = [&](const SlotRef& r) { return (r_flags(r) & F_EY) ? r.ov + (KN_CSIG - 1) : JB + KN_CSIG; };
+  auto r_bounds = [&](const SlotRef& r) { return *reinterpret_cast<const real2*>(&lds[r.oh]); };
   // ---------------- LMPC: simplex rows lambda_j >= 0, one safe-set point per lane and k < KS ----------------
   // (racing_mpc.cpp:484-504).  The points are centred on the first one (valid because 1'lambda = 1):
   // all sums below then run over O(1) offsets instead of absolute abscissae.
@@ -2807,26 +2865,34 @@ __device__ __forceinline__ void lmpc_solve_problem(
     // ======== rows: complementarity, residual, barrier weights ========
     if (ipm) {
       real musum = 0.0, rdl = 0.0, eysum = 0.0;
-      {
-        real val[KQ];
-        real2 hl[KQ];
 #pragma unroll
-        for (int q = 0; q < KQ; ++q) {
-          val[q] = lds[o_val[q]];
-          hl[q] = bounds(q);
+      for (int q0 = 0; q0 < KQ; q0 += QC) {  // (QC slots at a time: the whole row in one go where the registers allow it)
+        real val[QC];
+        real2 hl[QC];
+        SlotRef sr[QC];
+#pragma unroll
+        for (int qq = 0; qq < QC; ++qq) {
+          const int q = q0 + qq;
+          if (q >= KQ) continue;
+          sr[qq] = slot(q);
+          val[qq] = lds[sr[qq].ov];
+          hl[qq] = r_bounds(sr[qq]);
         }
 #pragma unroll
-        for (int q = 0; q < KQ; ++q) {
-          const int f = flags(q);
+        for (int qq = 0; qq < QC; ++qq) {
+          const int q = q0 + qq;
+          if (q >= KQ) continue;
+          const int f = r_flags(sr[qq]);
           const real sg = (f & F_SIG) ? sigma : 0.0;
           const real thu = s_lu[q] * frcp(s_tu[q]), thd = s_ll[q] * frcp(s_tl[q]);
           musum += s_lu[q] * s_tu[q] + s_ll[q] * s_tl[q];
-          rdl = fmax(rdl, (f & F_UP) ? fabs(val[q] - sg + s_tu[q] - hl[q].x) : real(0));
-          rdl = fmax(rdl, (f & F_LO) ? fabs(-val[q] - sg + s_tl[q] + hl[q].y) : real(0));
-          lds[o_w(q)] = thu + thd;
-          lds[o_csig(q)] = (f & F_SIG) ? (thd - thu) : 0.0;
+          rdl = fmax(rdl, (f & F_UP) ? fabs(val[qq] - sg + s_tu[q] - hl[qq].x) : real(0));
+          rdl = fmax(rdl, (f & F_LO) ? fabs(-val[qq] - sg + s_tl[q] + hl[qq].y) : real(0));
+          lds[r_w(sr[qq])] = thu + thd;
+          lds[r_csig(sr[qq])] = (f & F_SIG) ? (thd - thu) : 0.0;
           eysum += (f & F_SIG) ? (thu + thd) : real(0);
         }
+        if constexpr (QC < KQ) ISSUE_ORDER();
       }
       if constexpr (KS > 0) {
         PT_MARK(2)
@@ -3054,33 +3120,41 @@ __device__ __forceinline__ void lmpc_solve_problem(
           PT_MARK(15)
         }
       }
-      {
-        real val[KQ], par[KQ], ca[KQ], cb[KQ], ql[KQ];
-        real2 hl[KQ];
 #pragma unroll
-        for (int q = 0; q < KQ; ++q) {
-          const int gr = s_gf[q];
-          val[q] = lds[o_val[q]];
-          hl[q] = bounds(q);
-          par[q] = lds[o_val[q] + ((gr >> 16) & 3) - 1];
-          ca[q] = lds[CTB + (gr & 0xff)];
-          cb[q] = lds[CTB + ((gr >> 8) & 0xff)];
-          ql[q] = lds[o_val[q] + (KN_QLIN - 3)];
+      for (int q0 = 0; q0 < KQ; q0 += QC) {
+        real val[QC], par[QC], ca[QC], cb[QC], ql[QC];
+        real2 hl[QC];
+        SlotRef sr[QC];
+#pragma unroll
+        for (int qq = 0; qq < QC; ++qq) {
+          const int q = q0 + qq;
+          if (q >= KQ) continue;
+          sr[qq] = slot(q);
+          const int gr = sr[qq].gf, ov = sr[qq].ov;
+          val[qq] = lds[ov];
+          hl[qq] = r_bounds(sr[qq]);
+          par[qq] = lds[ov + ((gr >> 16) & 3) - 1];
+          ca[qq] = lds[CTB + (gr & 0xff)];
+          cb[qq] = lds[CTB + ((gr >> 8) & 0xff)];
+          ql[qq] = lds[ov + (KN_QLIN - 3)];
         }
 #pragma unroll
-        for (int q = 0; q < KQ; ++q) {
-          const int f = flags(q);
+        for (int qq = 0; qq < QC; ++qq) {
+          const int q = q0 + qq;
+          if (q >= KQ) continue;
+          const int f = r_flags(sr[qq]);
           const real sg = (f & F_SIG) ? sigma : 0.0;
           const real itu = frcp(s_tu[q]), itl = frcp(s_tl[q]);
-          real cu = s_lu[q] * itu * (val[q] - sg + s_tu[q] - hl[q].x) + (smu - pm * s_pu[q]) * itu;
-          real cd = s_ll[q] * itl * (-val[q] - sg + s_tl[q] + hl[q].y) + (smu - pm * s_pl[q]) * itl;
+          real cu = s_lu[q] * itu * (val[qq] - sg + s_tu[q] - hl[qq].x) + (smu - pm * s_pu[q]) * itu;
+          real cd = s_ll[q] * itl * (-val[qq] - sg + s_tl[q] + hl[qq].y) + (smu - pm * s_pl[q]) * itl;
           cu = (ipm && (f & F_UP)) ? cu : 0.0;
           cd = (ipm && (f & F_LO)) ? cd : 0.0;
-          const real g = ca[q] * val[q] + cb[q] * par[q] + ((f & F_QLIN) ? ql[q] : real(0));  // (zero coefficients on a boundary slot)
-          lds[o_w(q)] = g + cu - cd;
-          if (pass == 0) lds[(f & F_EY) ? JB + KN_EY : o_w(q) + 10] = 0.0;
+          const real g = ca[qq] * val[qq] + cb[qq] * par[qq] + ((f & F_QLIN) ? ql[qq] : real(0));  // (zero coefficients on a boundary slot)
+          lds[r_w(sr[qq])] = g + cu - cd;
+          if (pass == 0) lds[(f & F_EY) ? JB + KN_EY : r_w(sr[qq]) + 10] = 0.0;
           sgsum += (f & F_SIG) ? (cu + cd) : real(0);
         }
+        if constexpr (QC < KQ) ISSUE_ORDER();
       }
       wave_sync();
       PT_MARK(12)
@@ -3117,23 +3191,27 @@ __device__ __forceinline__ void lmpc_solve_problem(
       }
       PT_MARK(5)
       // ======== step of every constrained value; boundary slack by Schur complement ========
-      real dz0[KQ], dz1[KQ], val[KQ];
-      real2 hl[KQ];
+      // (QC == KQ: the steps and values are loaded once, here, and stay in registers across the reduction; otherwise chunk-wise,
+      //  once for the Schur sums and again for the row steps)
+      real dz0[QC == KQ ? KQ : 1], dz1[QC == KQ ? KQ : 1], val[QC == KQ ? KQ : 1];
+      real2 hl[QC == KQ ? KQ : 1];
+      if constexpr (QC == KQ) {
 #pragma unroll
-      for (int q = 0; q < KQ; ++q) {
-        dz0[q] = lds[o_val[q] + 10];
-        dz1[q] = lds[o_val[q] + 20];
-        val[q] = lds[o_val[q]];
-        hl[q] = bounds(q);
+        for (int q = 0; q < KQ; ++q) {
+          dz0[q] = lds[o_val[q] + 10];
+          dz1[q] = lds[o_val[q] + 20];
+          val[q] = lds[o_val[q]];
+          hl[q] = bounds(q);
+        }
       }
       if (!ipm) {
 #pragma unroll
-        for (int q = 0; q < KQ; ++q) d_val[q] = dz0[q];
+        for (int q = 0; q < KQ; ++q) d_val[q] = QC == KQ ? dz0[QC == KQ ? q : 0] : lds[slot(q).ov + 10];
         break;
       }
       if (has_sigma) {
         real red[3] = {0.0, 0.0, sgsum};  // c'dz (this rhs), c'e (Schur vector), sum of boundary coefficients
-        {
+        if constexpr (QC == KQ) {
           real cs[KQ];
 #pragma unroll
           for (int q = 0; q < KQ; ++q) cs[q] = lds[o_csig(q)];
@@ -3142,6 +3220,30 @@ __device__ __forceinline__ void lmpc_solve_problem(
             const bool sch = (flags(q) & F_SCH) != 0;
             red[0] += sch ? cs[q] * dz0[q] : real(0);
             red[1] += sch ? cs[q] * dz1[q] : real(0);
+          }
+        } else {
+#pragma unroll
+          for (int q0 = 0; q0 < KQ; q0 += QC) {
+            real cs[QC], e0[QC], e1[QC];
+            SlotRef sr[QC];
+#pragma unroll
+            for (int qq = 0; qq < QC; ++qq) {
+              const int q = q0 + qq;
+              if (q >= KQ) continue;
+              sr[qq] = slot(q);
+              cs[qq] = lds[r_csig(sr[qq])];
+              e0[qq] = lds[sr[qq].ov + 10];
+              e1[qq] = lds[sr[qq].ov + 20];
+            }
+#pragma unroll
+            for (int qq = 0; qq < QC; ++qq) {
+              const int q = q0 + qq;
+              if (q >= KQ) continue;
+              const bool sch = (r_flags(sr[qq]) & F_SCH) != 0;
+              red[0] += sch ? cs[qq] * e0[qq] : real(0);
+              red[1] += sch ? cs[qq] * e1[qq] : real(0);
+            }
+            ISSUE_ORDER();
           }
         }
         wave_sum_n<3>(red);
@@ -3200,23 +3302,46 @@ __device__ __forceinline__ void lmpc_solve_problem(
       real rmax = 1.0;
       bool finite_step = true;
 #pragma unroll
-      for (int q = 0; q < KQ; ++q) {
-        const int f = flags(q);
-        const real dval = dz0[q] + dsigma * dz1[q];
-        d_val[q] = dval;
-        finite_step = finite_step && (fabs(dval) < inf);
-        const real sg = (f & F_SIG) ? sigma : 0.0, dsg = (f & F_SIG) ? dsigma : 0.0;
-        const real itu = frcp(s_tu[q]), itl = frcp(s_tl[q]);
-        const real a = (f & F_UP) ? -(val[q] - sg + s_tu[q] - hl[q].x) - (dval - dsg) : 0.0;
-        const real bq = (f & F_UP) ? -s_lu[q] + (smu - pm * s_pu[q]) * itu - s_lu[q] * itu * a : 0.0;
-        const real c = (f & F_LO) ? -(-val[q] - sg + s_tl[q] + hl[q].y) - (-dval - dsg) : 0.0;
-        const real d = (f & F_LO) ? -s_ll[q] + (smu - pm * s_pl[q]) * itl - s_ll[q] * itl * c : 0.0;
-        dtu[q] = a;
-        dlu[q] = bq;
-        dtl[q] = c;
-        dll[q] = d;
-        rmax = fmax(rmax, fmax(-a * itu, -bq * frcp(fmax(s_lu[q], lim::tiny))));
-        rmax = fmax(rmax, fmax(-c * itl, -d * frcp(fmax(s_ll[q], lim::tiny))));
+      for (int q0 = 0; q0 < KQ; q0 += QC) {
+        real e0[QC], e1[QC], ev[QC];
+        real2 eh[QC];
+        SlotRef sr[QC];
+#pragma unroll
+        for (int qq = 0; qq < QC; ++qq) {
+          const int q = q0 + qq;
+          if (q >= KQ) continue;
+          sr[qq] = slot(q);
+          if constexpr (QC == KQ) {
+            e0[qq] = dz0[q], e1[qq] = dz1[q], ev[qq] = val[q], eh[qq] = hl[q];
+          } else {
+            e0[qq] = lds[sr[qq].ov + 10];
+            e1[qq] = lds[sr[qq].ov + 20];
+            ev[qq] = lds[sr[qq].ov];
+            eh[qq] = r_bounds(sr[qq]);
+          }
+        }
+#pragma unroll
+        for (int qq = 0; qq < QC; ++qq) {
+          const int q = q0 + qq;
+          if (q >= KQ) continue;
+          const int f = r_flags(sr[qq]);
+          const real dval = e0[qq] + dsigma * e1[qq];
+          d_val[q] = dval;
+          finite_step = finite_step && (fabs(dval) < inf);
+          const real sg = (f & F_SIG) ? sigma : 0.0, dsg = (f & F_SIG) ? dsigma : 0.0;
+          const real itu = frcp(s_tu[q]), itl = frcp(s_tl[q]);
+          const real a = (f & F_UP) ? -(ev[qq] - sg + s_tu[q] - eh[qq].x) - (dval - dsg) : 0.0;
+          const real bq = (f & F_UP) ? -s_lu[q] + (smu - pm * s_pu[q]) * itu - s_lu[q] * itu * a : 0.0;
+          const real c = (f & F_LO) ? -(-ev[qq] - sg + s_tl[q] + eh[qq].y) - (-dval - dsg) : 0.0;
+          const real d = (f & F_LO) ? -s_ll[q] + (smu - pm * s_pl[q]) * itl - s_ll[q] * itl * c : 0.0;
+          dtu[q] = a;
+          dlu[q] = bq;
+          dtl[q] = c;
+          dll[q] = d;
+          rmax = fmax(rmax, fmax(-a * itu, -bq * frcp(fmax(s_lu[q], lim::tiny))));
+          rmax = fmax(rmax, fmax(-c * itl, -d * frcp(fmax(s_ll[q], lim::tiny))));
+        }
+        if constexpr (QC < KQ) ISSUE_ORDER();
       }
       if constexpr (KS > 0) {
 #pragma unroll
@@ -3334,9 +3459,10 @@ __device__ __forceinline__ void lmpc_solve_problem(
     real stepmax = 0.0;
 #pragma unroll
     for (int q = 0; q < KQ; ++q) {
-      const bool mv = (flags(q) & F_MOVE) != 0;
+      const SlotRef sr = slot(q);
+      const bool mv = (r_flags(sr) & F_MOVE) != 0;
       const real dz = mv ? alpha * d_val[q] : 0.0;
-      lds[mv ? o_val[q] : JB + q] += dz;
+      lds[mv ? sr.ov : JB + q] += dz;
       stepmax = fmax(stepmax, fabs(dz));
     }
     wave_sync();
@@ -3347,21 +3473,24 @@ __device__ __forceinline__ void lmpc_solve_problem(
       // ---- slacks and multipliers at the start point: t = max(slack, 0.5 range), lam = mu0 / t ----
       real val[KQ];
       real2 hl[KQ];
+      int fl[KQ];
 #pragma unroll
       for (int q = 0; q < KQ; ++q) {
-        val[q] = lds[o_val[q]];
-        hl[q] = bounds(q);
+        const SlotRef sr = slot(q);
+        val[q] = lds[sr.ov];
+        hl[q] = r_bounds(sr);
+        fl[q] = r_flags(sr);
       }
 #pragma unroll
       for (int q = 0; q < KQ; ++q) {
-        real range = ((flags(q) & (F_UP | F_LO)) == (F_UP | F_LO)) ? (hl[q].x - hl[q].y) : 1.0;
+        real range = ((fl[q] & (F_UP | F_LO)) == (F_UP | F_LO)) ? (hl[q].x - hl[q].y) : 1.0;
         if (!(range > real(1e-3))) range = real(1e-3);
         const real thr = thr_frac * range;
-        if (flags(q) & F_UP) {
+        if (fl[q] & F_UP) {
           s_tu[q] = fmax(hl[q].x - val[q], thr);
           s_lu[q] = mu0 / s_tu[q];
         }
-        if (flags(q) & F_LO) {
+        if (fl[q] & F_LO) {
           s_tl[q] = fmax(val[q] - hl[q].y, thr);
           s_ll[q] = mu0 / s_tl[q];
         }

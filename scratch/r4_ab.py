@@ -132,8 +132,8 @@ CASES = {
     "lmpc": lambda: case("lmpc", 20, 4096, ("f64", "mixed")),
     "lmpc32k": lambda: case("lmpc", 20, 32768, ("f64", "mixed")),
     "lmpc32kreg": lambda: case("lmpc", 20, 32768, ("f64", "mixed"), regression=True),
-    "lmpc40": lambda: case("lmpc", 40, 4096, ("f64", "mixed")),
-    "lmpc60": lambda: case("lmpc", 60, 4096, ("f64", "mixed")),
+    "lmpc40": lambda: case("lmpc", 40, 4096, ("f64",)),
+    "lmpc60": lambda: case("lmpc", 60, 4096, ("f64",)),
     "iac": lambda: case("iac", 40, 8192, ("f64", "mixed", "f32")),
     "iac60": lambda: case("iac", 60, 4096, ("f64", "mixed", "f32")),
     "iac80": lambda: case("iac", 80, 4096, ("f64", "mixed", "f32")),
