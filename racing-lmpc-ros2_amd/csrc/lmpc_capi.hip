@@ -30,10 +30,10 @@ __global__ void lmpc_ss_query_kernel(int, int, int, int, const int*, const int*,
                                      double*, double*, int*, double*);
 __global__ void lmpc_reg_residual_kernel(lmpc_vehicle, int, int, const int*, const double*, const double*, const double*,
                                          const double*, double*);
-__global__ void lmpc_reg_pack_kernel(lmpc_regression_spec, int, int, const int*, const double*, const double*, const double*, double*);
+__global__ void lmpc_reg_pack_kernel(lmpc_regression_spec, int, int, const int*, const double*, const double*, const double*, double*, double*);
 template <int NF, int NOUT, bool WS_LAYOUT>
-__global__ void lmpc_regress_kernel(int, int, lmpc_regression_spec, int, const double*, const double*, const double*, double*,
-                                    double*, double*);
+__global__ void lmpc_regress_kernel(int, int, lmpc_regression_spec, int, const double*, const double*, const double*, const double*,
+                                    double*, double*, double*);
 __global__ void lmpc_launch_order_kernel(int, const int*, int*);
 __global__ void lmpc_collect_unverified_kernel(int, const int*, int*);
 template <typename real, int KQ, int KS, typename io>
@@ -74,7 +74,8 @@ struct lmpc_handle {
   double* reg_x = nullptr;  // [total][6]
   double* reg_u = nullptr;  // [total][2]
   double* reg_y = nullptr;  // [total][6]
-  double* reg_tab = nullptr;  // [reg_npad][NF + NOUT]: features and regressed residuals of the samples that have a successor
+  double* reg_tab = nullptr;  // [reg_npad][NF + NOUT]: features and regressed residuals of the samples that have a successor,
+                              // and behind them [reg_npad]: the features' squared norms
   int reg_npad = 0;           // their number, padded to a multiple of four with unreachable rows
   lmpc_regression_spec reg_spec{};
   // staging for the single-problem host entry points (lmpc_solve_host, lmpc_ss_query_host): device buffers and PINNED
@@ -278,12 +279,13 @@ int launch_regress(lmpc_handle* h, int batch, const double* X_ref, const double*
   const int nf = h->reg_spec.n_in_state + h->reg_spec.n_in_ctrl;
   const long long queries = (long long)batch * (h->P.N - 1);
   const dim3 grid((unsigned)((queries + 63) / 64)), block(64);
+  const double* zz = h->reg_tab + (size_t)h->reg_npad * (size_t)(nf + h->reg_spec.n_out);
   if (nf == 5 && h->reg_spec.n_out == 3)
     hipLaunchKernelGGL((lmpc_regress_kernel<5, 3, WS>), grid, block, 0, h->stream, h->P.N, batch, h->reg_spec, h->reg_npad,
-                       h->reg_tab, X_ref, U_ref, A, Bm, g);
+                       h->reg_tab, zz, X_ref, U_ref, A, Bm, g);
   else
     hipLaunchKernelGGL((lmpc_regress_kernel<8, 6, WS>), grid, block, 0, h->stream, h->P.N, batch, h->reg_spec, h->reg_npad,
-                       h->reg_tab, X_ref, U_ref, A, Bm, g);
+                       h->reg_tab, zz, X_ref, U_ref, A, Bm, g);
   HIP_TRY(h, hipGetLastError());
   return LMPC_OK;
 }
@@ -1098,10 +1100,10 @@ int lmpc_set_regression_laps(lmpc_handle* h, int32_t n_laps, const int32_t* n_pt
     const int nvalid = (int)valid.size(), npad = (nvalid + 3) / 4 * 4;
     HIP_TRY(h, hipMalloc(&tv.p, (size_t)nvalid * sizeof(int)));
     int* dvalid = static_cast<int*>(tv.p);
-    HIP_TRY(h, hipMalloc(&h->reg_tab, (size_t)npad * (size_t)(nf + spec->n_out) * sizeof(double)));
+    HIP_TRY(h, hipMalloc(&h->reg_tab, (size_t)npad * (size_t)(nf + spec->n_out + 1) * sizeof(double)));
     HIP_TRY(h, hipMemcpy(dvalid, valid.data(), (size_t)nvalid * sizeof(int), hipMemcpyHostToDevice));
     hipLaunchKernelGGL(lmpc_reg_pack_kernel, dim3((unsigned)((npad + 255) / 256)), dim3(256), 0, h->stream, *spec, nvalid, npad, dvalid,
-                       h->reg_x, h->reg_u, h->reg_y, h->reg_tab);
+                       h->reg_x, h->reg_u, h->reg_y, h->reg_tab, h->reg_tab + (size_t)npad * (size_t)(nf + spec->n_out));
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->reg_npad = npad;

@@ -25,7 +25,12 @@
 // tests its own distance and, when any lane of the wave is within the bandwidth, adds w m m' and w y m' to its own
 // 21 + 6 NOUT sums as FMAs with scalar operands.  No cross-lane reduction, no per-lane gather; each lane then factors
 // its own (NF+1)^2 system.  The accumulation is the product W Phi (queries x samples times samples x 39) and would map
-// onto v_mfma_f64_16x16x4 -- whose rate on gfx950 equals the vector FMA rate, with 39 columns padded to 48: no gain.
+// onto v_mfma_f64_16x16x4 -- measured on the MI355X (scratch/mfma_f64_rate.hip): 47 TFLOP/s with two waves per SIMD and twelve
+// independent accumulator tiles (105 cycles per instruction), 39 with five fp64 FMAs between MFMAs; the 64 M MFMAs of the
+// 32768 x 19 x 2200 workload with 39 columns padded to 48 would take 2.8-3.3 ms, the vector kernel takes 2.5: not built.
+// Per pair the vector loop spends 54 instructions: d^2 = (|q|^2 + |z|^2) - 2 z.q (one add + NF FMAs, |z|^2 from the table's
+// tail), K / c0 = max(1 - d^2/h^2, 0)^2 (the bandwidth test is the max), NF products w z, 21 + 6 NOUT FMAs; c0 once at the end
+// (round 4: 62 -> 54 instructions, 2.86 -> 2.52 ms).
 // (The first version ran one wavefront per query with the lanes striding the samples: three dependent gathers per
 // iteration behind two branches and a 39-value shuffle reduction -- latency-bound at 13 ms per 32768 x 19 queries over
 // 2200 samples; this one is FP64-issue-bound.)
@@ -55,28 +60,34 @@ __global__ void lmpc_reg_residual_kernel(lmpc_vehicle veh, int total, int as_wri
 }
 
 // tab[v][NF + NOUT] for the valid samples (valid[v] = index of a sample that is not the last of its lap), v < nvalid;
-// rows nvalid .. npad-1: features 1e30 (out of every bandwidth), residuals 0
+// rows nvalid .. npad-1: features and residuals 0, |z|^2 = 1e30 (out of every bandwidth); zz[v] = |z_v|^2
 __global__ void lmpc_reg_pack_kernel(lmpc_regression_spec spec, int nvalid, int npad, const int* __restrict__ valid,
                                      const double* __restrict__ x, const double* __restrict__ u, const double* __restrict__ y,
-                                     double* __restrict__ tab) {
+                                     double* __restrict__ tab, double* __restrict__ zz) {
   const int v = blockIdx.x * blockDim.x + threadIdx.x;
   if (v >= npad) return;
   const int ns = spec.n_in_state, nf = ns + spec.n_in_ctrl, nrow = nf + spec.n_out;
   double* row = tab + (size_t)v * nrow;
-  if (v >= nvalid) {
-    for (int f = 0; f < nf; ++f) row[f] = 1e30;
+  if (v >= nvalid) {  // (features 0 with |z|^2 = 1e30: d^2 = 1e30 for every query, and no 0 * inf in the sums)
+    for (int f = 0; f < nf; ++f) row[f] = 0.0;
     for (int o = 0; o < spec.n_out; ++o) row[nf + o] = 0.0;
+    zz[v] = 1e30;
     return;
   }
   const int j = valid[v];
-  for (int f = 0; f < nf; ++f) row[f] = f < ns ? x[(size_t)j * 6 + spec.in_state[f]] : u[(size_t)j * 2 + spec.in_ctrl[f - ns]];
+  double s = 0.0;
+  for (int f = 0; f < nf; ++f) {
+    row[f] = f < ns ? x[(size_t)j * 6 + spec.in_state[f]] : u[(size_t)j * 2 + spec.in_ctrl[f - ns]];
+    s = __builtin_fma(row[f], row[f], s);
+  }
+  zz[v] = s;
   for (int o = 0; o < spec.n_out; ++o) row[nf + o] = y[(size_t)j * 6 + spec.out[o]];
 }
 
 // WS_LAYOUT: update the handle's linearisation workspace [B][N-1][54]; otherwise the A/B/g arrays of lmpc_linearize_batch.
 template <int NF, int NOUT, bool WS_LAYOUT>
 __global__ __launch_bounds__(64) void lmpc_regress_kernel(int N, int B, lmpc_regression_spec spec, int npad,
-                                                          const double* __restrict__ tab, const double* __restrict__ X_ref,
+                                                          const double* __restrict__ tab, const double* __restrict__ zz, const double* __restrict__ X_ref,
                                                           const double* __restrict__ U_ref, double* __restrict__ outA,
                                                           double* __restrict__ outB, double* __restrict__ outg) {
   constexpr int NM = NF + 1;
@@ -93,32 +104,38 @@ __global__ __launch_bounds__(64) void lmpc_regress_kernel(int N, int B, lmpc_reg
 #pragma unroll
   for (int f = 0; f < NF; ++f)
     q[f] = f < ns ? X_ref[((size_t)spec.in_state[f] * N + i) * B + b] : U_ref[((size_t)spec.in_ctrl[f - ns] * NS + i) * B + b];
-  const double h = spec.dist_max, h2 = h * h, ih2 = 1.0 / h2, c0 = 0.75 / h;
+  const double h = spec.dist_max, h2 = h * h, nih2 = -1.0 / h2, c0 = 0.75 / h;
+  // d^2 = (|q|^2 + |z|^2) - 2 z.q: one add and NF FMAs per pair instead of NF subtractions and NF FMAs (|z|^2 is formed on the
+  // scalar side of the loop: it is the same for every lane).  A dead lane's query sits out of every bandwidth.
+  double qm2[NF], qq = 0.0;
+#pragma unroll
+  for (int f = 0; f < NF; ++f) {
+    if (!live) q[f] = 1e30;
+    qm2[f] = -2.0 * q[f];
+    qq = __builtin_fma(q[f], q[f], qq);
+  }
   double acc[NQ + NOUT * NM];
 #pragma unroll
   for (int a = 0; a < NQ + NOUT * NM; ++a) acc[a] = 0.0;
   for (int j0 = 0; j0 < npad; j0 += UNR) {
-    double row[UNR][NROW], d2[UNR];
+    double row[UNR][NROW], sq[UNR];
 #pragma unroll
     for (int t = 0; t < UNR; ++t)
 #pragma unroll
       for (int c = 0; c < NROW; ++c) row[t][c] = tab[(size_t)(j0 + t) * NROW + c];  // wave-uniform address: scalar loads
 #pragma unroll
     for (int t = 0; t < UNR; ++t) {
-      double s = 0.0;
+      double s = qq + zz[j0 + t];
 #pragma unroll
-      for (int f = 0; f < NF; ++f) {
-        const double e = row[t][f] - q[f];
-        s += e * e;
-      }
-      d2[t] = s;
+      for (int f = 0; f < NF; ++f) s = __builtin_fma(row[t][f], qm2[f], s);
+      // K / c0 = (1 - (d/h)^2)^2 inside the bandwidth, 0 outside (safe_set.cpp:84-87): max(1 - d^2/h^2, 0)^2; c0 = 0.75/h
+      // multiplies the sums once, after the loop
+      sq[t] = fmax(__builtin_fma(s, nih2, 1.0), 0.0);
     }
 #pragma unroll
     for (int t = 0; t < UNR; ++t) {
-      const bool hit = live && d2[t] < h2;   // K = 0.75/h (1 - (d/h)^2)^2 inside the bandwidth (safe_set.cpp:84-87)
-      if (!__any(hit)) continue;
-      const double sq = 1.0 - d2[t] * ih2;
-      const double w = hit ? c0 * sq * sq : 0.0;
+      if (!__any(sq[t] > 0.0)) continue;
+      const double w = sq[t] * sq[t];
       double wm[NM];
 #pragma unroll
       for (int r = 0; r < NF; ++r) wm[r] = w * row[t][r];
@@ -139,6 +156,8 @@ __global__ __launch_bounds__(64) void lmpc_regress_kernel(int N, int B, lmpc_reg
       }
     }
   }
+#pragma unroll
+  for (int a = 0; a < NQ + NOUT * NM; ++a) acc[a] *= c0;
   // "if there are no points left, skip the regression" (safe_set.cpp:207-210): the weight sum is M'KM's last entry
   if (!live || !(acc[NQ - 1] > 0.0)) return;
   // Cholesky of Q = M'KM + 1e-3 I, this lane's own system
@@ -209,7 +228,7 @@ __global__ __launch_bounds__(64) void lmpc_regress_kernel(int N, int B, lmpc_reg
 }
 
 #define LMPC_REG_INSTANTIATE(NF, NOUT, WS)                                                                                    \
-  template __global__ void lmpc_regress_kernel<NF, NOUT, WS>(int, int, lmpc_regression_spec, int, const double*, const double*, \
+  template __global__ void lmpc_regress_kernel<NF, NOUT, WS>(int, int, lmpc_regression_spec, int, const double*, const double*, const double*, \
                                                              const double*, double*, double*, double*);
 LMPC_REG_INSTANTIATE(5, 3, true)
 LMPC_REG_INSTANTIATE(5, 3, false)
