@@ -2460,6 +2460,11 @@ __device__ __attribute__((noinline)) PolishResult<real, KS> lmpc_polish_call(con
 //   opaque slot tables (SlotRef below) -- the long-horizon fp64 kernels and every learning kernel.
 // (fp32 at KQ >= 11 has no spills to begin with and loses 2-3 % to either; KQ <= 7 tracking loses 1-3 % to the opaque tables;
 //  the learning kernels at KQ >= 11 lose 15 % to the chunks.)
+// (bit mask of the four flag-select address sites recomputed per use in the fp64 tracking kernels with KQ <= 4: all four, -1.6..2.2 %
+//  at N = 20, bit-identical; +1 % at KQ = 7 and in fp32, which keep the hoisted form: profiles/r04_row_phases.md)
+#ifndef LMPC_OPAQUE_SITES
+#define LMPC_OPAQUE_SITES 15
+#endif
 #ifndef LMPC_ROW_CHUNK
 #define LMPC_ROW_CHUNK(kq) (((kq) + 1) / 2)
 #endif
@@ -2482,6 +2487,9 @@ __host__ __device__ constexpr int lmpc_row_chunk(int real_bytes, int kq, int ks)
 }
 __host__ __device__ constexpr bool lmpc_opaque_slots(int real_bytes, int kq, int ks) {
   return (real_bytes == 8 && kq >= LMPC_OPAQUE_MIN_KQ) || (ks > 0 && LMPC_OPAQUE_LEARNING);
+}
+__host__ __device__ constexpr int lmpc_opaque_sites(int real_bytes, int kq, int ks) {
+  return (real_bytes == 8 && kq <= 4 && ks == 0) ? LMPC_OPAQUE_SITES : 0;
 }
 
 template <typename real, int KQ, int KS, typename io>
@@ -2506,6 +2514,7 @@ __device__ __forceinline__ void lmpc_solve_problem(
   // once; LMPC_ROW_CHUNK at a time in the long-horizon kernels (KQ >= 11: 11-14 slots x 7 operands on top of 12 doubles of row
   // state per slot do not fit 512 registers, and what the allocator spills is the row state)
   constexpr int QC = lmpc_row_chunk(sizeof(real), KQ, KS);
+  constexpr int SITES = lmpc_opaque_sites(sizeof(real), KQ, KS);
   Lds<real> L{lds, N, LEAN ? LMPC_LEAN_STAGE_STRIDE : LMPC_STAGE_STRIDE, lmpc_fresh_lane(sizeof(real), KQ, KS)};
   real* T = L.tail();
   real* ct = T + TL_CT;
@@ -2647,6 +2656,18 @@ __device__ __forceinline__ void lmpc_solve_problem(
   auto slot = [&](int q) {
     SlotRef r{o_val[q], o_hl[q], s_gf[q]};
     if constexpr (lmpc_opaque_slots(sizeof(real), KQ, KS)) asm volatile("" : "+v"(r.ov), "+v"(r.oh), "+v"(r.gf));
+    return r;
+  };
+  // (the short-horizon tracking kernels keep the hoisted addresses -- the opaque tables cost them 1-3 % -- except at the sites of
+  //  lmpc_opaque_sites, where the address is a select on the slot's flags: bit 0 the coupling cell in the row phase, 1 the rhs1 cell
+  //  the gradient clears, 2 the coupling cell in the Schur sums, 3 the primal update)
+  auto slot_at = [&](int q, int site) {
+    SlotRef r{o_val[q], o_hl[q], s_gf[q]};
+    if constexpr (lmpc_opaque_slots(sizeof(real), KQ, KS)) {
+      asm volatile("" : "+v"(r.ov), "+v"(r.oh), "+v"(r.gf));
+    } else if ((SITES >> site) & 1) {
+      asm volatile("" : "+v"(r.gf));
+    }
     return r;
   };
   auto r_flags = [](const SlotRef& r) { return r.gf >> 20; };
@@ -2889,7 +2910,7 @@ __device__ __forceinline__ void lmpc_solve_problem(
           rdl = fmax(rdl, (f & F_UP) ? fabs(val[qq] - sg + s_tu[q] - hl[qq].x) : real(0));
           rdl = fmax(rdl, (f & F_LO) ? fabs(-val[qq] - sg + s_tl[q] + hl[qq].y) : real(0));
           lds[r_w(sr[qq])] = thu + thd;
-          lds[r_csig(sr[qq])] = (f & F_SIG) ? (thd - thu) : 0.0;
+          lds[r_csig(((SITES & 1) && !lmpc_opaque_slots(sizeof(real), KQ, KS)) ? slot_at(q, 0) : sr[qq])] = (f & F_SIG) ? (thd - thu) : 0.0;
           eysum += (f & F_SIG) ? (thu + thd) : real(0);
         }
         if constexpr (QC < KQ) ISSUE_ORDER();
@@ -3151,7 +3172,10 @@ __device__ __forceinline__ void lmpc_solve_problem(
           cd = (ipm && (f & F_LO)) ? cd : 0.0;
           const real g = ca[qq] * val[qq] + cb[qq] * par[qq] + ((f & F_QLIN) ? ql[qq] : real(0));  // (zero coefficients on a boundary slot)
           lds[r_w(sr[qq])] = g + cu - cd;
-          if (pass == 0) lds[(f & F_EY) ? JB + KN_EY : r_w(sr[qq]) + 10] = 0.0;
+          if (pass == 0) {
+            const SlotRef sz = ((SITES & 2) && !lmpc_opaque_slots(sizeof(real), KQ, KS)) ? slot_at(q, 1) : sr[qq];
+            lds[(r_flags(sz) & F_EY) ? JB + KN_EY : r_w(sz) + 10] = 0.0;
+          }
           sgsum += (f & F_SIG) ? (cu + cd) : real(0);
         }
         if constexpr (QC < KQ) ISSUE_ORDER();
@@ -3214,7 +3238,7 @@ __device__ __forceinline__ void lmpc_solve_problem(
         if constexpr (QC == KQ) {
           real cs[KQ];
 #pragma unroll
-          for (int q = 0; q < KQ; ++q) cs[q] = lds[o_csig(q)];
+          for (int q = 0; q < KQ; ++q) cs[q] = lds[r_csig(slot_at(q, 2))];
 #pragma unroll
           for (int q = 0; q < KQ; ++q) {
             const bool sch = (flags(q) & F_SCH) != 0;
@@ -3459,7 +3483,7 @@ __device__ __forceinline__ void lmpc_solve_problem(
     real stepmax = 0.0;
 #pragma unroll
     for (int q = 0; q < KQ; ++q) {
-      const SlotRef sr = slot(q);
+      const SlotRef sr = slot_at(q, 3);
       const bool mv = (r_flags(sr) & F_MOVE) != 0;
       const real dz = mv ? alpha * d_val[q] : 0.0;
       lds[mv ? sr.ov : JB + q] += dz;
