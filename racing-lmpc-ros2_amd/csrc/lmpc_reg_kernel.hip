@@ -30,7 +30,7 @@
 // 32768 x 19 x 2200 workload with 39 columns padded to 48 would take 2.8-3.3 ms, the vector kernel takes 2.5: not built.
 // Per pair the vector loop spends 54 instructions: d^2 = (|q|^2 + |z|^2) - 2 z.q (one add + NF FMAs, |z|^2 from the table's
 // tail), K / c0 = max(1 - d^2/h^2, 0)^2 (the bandwidth test is the max), NF products w z, 21 + 6 NOUT FMAs; c0 once at the end
-// (round 4: 62 -> 54 instructions, 2.86 -> 2.52 ms).
+// (round 4: 62 -> 54 instructions, 2.86 -> 2.52 ms; the group's scalar loads up front with one wait: 2.38 ms).
 // (The first version ran one wavefront per query with the lanes striding the samples: three dependent gathers per
 // iteration behind two branches and a 39-value shuffle reduction -- latency-bound at 13 ms per 32768 x 19 queries over
 // 2200 samples; this one is FP64-issue-bound.)
@@ -123,9 +123,24 @@ __global__ __launch_bounds__(64) void lmpc_regress_kernel(int N, int B, lmpc_reg
     for (int t = 0; t < UNR; ++t)
 #pragma unroll
       for (int c = 0; c < NROW; ++c) row[t][c] = tab[(size_t)(j0 + t) * NROW + c];  // wave-uniform address: scalar loads
+    double zn[UNR];
+#pragma unroll
+    for (int t = 0; t < UNR; ++t) zn[t] = zz[j0 + t];
+    // every row of the group is "used" here, in scalar registers: left alone, the compiler loads a sample's features, waits, tests
+    // the distance, and only inside the hit branch loads its residuals and waits again -- two exposed scalar-cache round trips per
+    // sample instead of one per group
+    // (where the group fits the scalar registers: (8, 6) would need 120 of them)
+    if constexpr (2 * (NROW + 1) * UNR <= 80) {
+#pragma unroll
+      for (int t = 0; t < UNR; ++t) {
+#pragma unroll
+        for (int c = 0; c < NROW; ++c) asm volatile("" : "+s"(row[t][c]));
+        asm volatile("" : "+s"(zn[t]));
+      }
+    }
 #pragma unroll
     for (int t = 0; t < UNR; ++t) {
-      double s = qq + zz[j0 + t];
+      double s = qq + zn[t];
 #pragma unroll
       for (int f = 0; f < NF; ++f) s = __builtin_fma(row[t][f], qm2[f], s);
       // K / c0 = (1 - (d/h)^2)^2 inside the bandwidth, 0 outside (safe_set.cpp:84-87): max(1 - d^2/h^2, 0)^2; c0 = 0.75/h
