@@ -15,7 +15,7 @@
 
 #include "lmpc_device.h"
 
-template <bool WS_LAYOUT, typename io>
+template <bool WS_LAYOUT, typename io, int W>
 __global__ void lmpc_linearize_kernel(lmpc_params, int, const io*, const io*, const io*, const io*, io*, io*, io*);
 __global__ void lmpc_prepare_kernel(lmpc_params, int, lmpc_track, const double*, const int*, double, double, double, double*,
                                     double*, double*, double*, double*, double*, double*);
@@ -529,7 +529,7 @@ int lmpc_linearize_batch(lmpc_handle* h, int32_t batch, const double* X_ref, con
   if (batch == 0) return LMPC_OK;
   HIP_TRY(h, hipSetDevice(h->device));
   dim3 grid((batch + 255) / 256, h->P.N - 1);
-  hipLaunchKernelGGL((lmpc_linearize_kernel<false, double>), grid, dim3(256), 0, h->stream, h->P, batch, X_ref, U_ref, T_ref,
+  hipLaunchKernelGGL((lmpc_linearize_kernel<false, double, 1>), grid, dim3(256), 0, h->stream, h->P, batch, X_ref, U_ref, T_ref,
                      curvatures, A, Bm, g);
   HIP_TRY(h, hipGetLastError());
   return LMPC_OK;
@@ -556,8 +556,14 @@ int solve_batch_fp64_arrays(lmpc_handle* h, bool mixed, bool aos, int32_t batch,
   const int N = h->P.N;
   if (h->timing) HIP_TRY(h, hipEventRecord(h->ev[0], h->stream));
   dim3 grid((batch + 255) / 256, N - 1);
-  hipLaunchKernelGGL((lmpc_linearize_kernel<true, double>), grid, dim3(256), 0, h->stream, h->P, batch, X_ref, U_ref, T_ref,
-                     curvatures, h->ws, (double*)nullptr, (double*)nullptr);
+  // the 256-register build of the linearisation where a wave of it can sit next to a resident wave of the QP kernel that follows
+  // (two waves per SIMD: the short-horizon tracking kernels), so that the next batch's linearisation fills this batch's residency tail
+  if (!h->P.learning && lmpc_waves_per_simd(mixed ? 4 : 8, kq_for(N), 0) >= 2)
+    hipLaunchKernelGGL((lmpc_linearize_kernel<true, double, 2>), grid, dim3(256), 0, h->stream, h->P, batch, X_ref, U_ref, T_ref,
+                       curvatures, h->ws, (double*)nullptr, (double*)nullptr);
+  else
+    hipLaunchKernelGGL((lmpc_linearize_kernel<true, double, 1>), grid, dim3(256), 0, h->stream, h->P, batch, X_ref, U_ref, T_ref,
+                       curvatures, h->ws, (double*)nullptr, (double*)nullptr);
   HIP_TRY(h, hipGetLastError());
   if (h->reg_on) {  // error-dynamics regression onto the workspace (safe_set.cpp:182-245)
     const int rc = launch_regress<true>(h, batch, X_ref, U_ref, h->ws, nullptr, nullptr);
@@ -653,8 +659,12 @@ int lmpc_solve_batch_f32(lmpc_handle* h, int32_t batch, const float* x_ic, const
   }
   if (h->timing) HIP_TRY(h, hipEventRecord(h->ev[0], h->stream));
   dim3 grid((batch + 255) / 256, N - 1);
-  hipLaunchKernelGGL((lmpc_linearize_kernel<true, float>), grid, dim3(256), 0, h->stream, h->P, batch, X_ref, U_ref, T_ref,
-                     curvatures, h->ws_f32, (float*)nullptr, (float*)nullptr);
+  if (lmpc_waves_per_simd(4, kq_for(N), 0) >= 2)
+    hipLaunchKernelGGL((lmpc_linearize_kernel<true, float, 2>), grid, dim3(256), 0, h->stream, h->P, batch, X_ref, U_ref, T_ref,
+                       curvatures, h->ws_f32, (float*)nullptr, (float*)nullptr);
+  else
+    hipLaunchKernelGGL((lmpc_linearize_kernel<true, float, 1>), grid, dim3(256), 0, h->stream, h->P, batch, X_ref, U_ref, T_ref,
+                       curvatures, h->ws_f32, (float*)nullptr, (float*)nullptr);
   HIP_TRY(h, hipGetLastError());
   if (h->timing) HIP_TRY(h, hipEventRecord(h->ev[1], h->stream));
   const size_t lds = lmpc_lds_bytes(N, 0, 0, 4);

@@ -19,8 +19,12 @@
 //                    (ABt[c][k] = [A B][k][c], i.e. columns contiguous)
 // WS_LAYOUT = false: C-ABI arrays A [6][6][N-1][B], Bm [6][2][N-1][B], g [6][N-1][B]
 // io = element type of the arrays (double, or float for the single-precision solve); the arithmetic is fp64.
-template <bool WS_LAYOUT, typename io>
-__global__ __launch_bounds__(256) void lmpc_linearize_kernel(lmpc_params P, int B, const io* __restrict__ X_ref,
+// W = waves per SIMD the registers are sized for.  W = 1: 378 VGPRs + 122 AGPRs, no scratch -- the faster kernel on its own (43 against
+// 49 us per 4096 x 19).  W = 2: 256 VGPRs and 612 B of spills, but a wave of it fits NEXT TO a resident wave of a two-waves-per-SIMD QP
+// kernel (256 VGPRs each), so the next batch's linearisation runs in the residency tail of this batch's solve instead of waiting for
+// whole SIMDs to drain: +5.5 % solves/s on the pipelined headline, +10 % on the fp32 IAC configuration; the host picks (lmpc_capi.hip).
+template <bool WS_LAYOUT, typename io, int W>
+__global__ __launch_bounds__(256, W) void lmpc_linearize_kernel(lmpc_params P, int B, const io* __restrict__ X_ref,
                                                              const io* __restrict__ U_ref, const io* __restrict__ T_ref,
                                                              const io* __restrict__ curv, io* __restrict__ outA,
                                                              io* __restrict__ outB, io* __restrict__ outg) {
@@ -98,12 +102,16 @@ __global__ __launch_bounds__(256) void lmpc_linearize_kernel(lmpc_params P, int 
   }
 }
 
-template __global__ void lmpc_linearize_kernel<true, double>(lmpc_params, int, const double*, const double*, const double*,
+template __global__ void lmpc_linearize_kernel<true, double, 1>(lmpc_params, int, const double*, const double*, const double*,
                                                              const double*, double*, double*, double*);
-template __global__ void lmpc_linearize_kernel<true, float>(lmpc_params, int, const float*, const float*, const float*, const float*,
+template __global__ void lmpc_linearize_kernel<true, float, 1>(lmpc_params, int, const float*, const float*, const float*, const float*,
                                                             float*, float*, float*);
-template __global__ void lmpc_linearize_kernel<false, double>(lmpc_params, int, const double*, const double*, const double*,
+template __global__ void lmpc_linearize_kernel<false, double, 1>(lmpc_params, int, const double*, const double*, const double*,
                                                               const double*, double*, double*, double*);
+template __global__ void lmpc_linearize_kernel<true, double, 2>(lmpc_params, int, const double*, const double*, const double*,
+                                                             const double*, double*, double*, double*);
+template __global__ void lmpc_linearize_kernel<true, float, 2>(lmpc_params, int, const float*, const float*, const float*, const float*,
+                                                            float*, float*, float*);
 
 // periodic linear interpolation on a uniform table of M samples over [0, L)
 __device__ __forceinline__ double track_lookup(const double* __restrict__ tab, int M, double L, double s) {
