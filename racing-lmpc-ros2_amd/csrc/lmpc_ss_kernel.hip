@@ -57,20 +57,49 @@ __global__ __launch_bounds__(64) void lmpc_ss_query_kernel(int B, int n_laps, in
     // seldom owns more than one of the K winners: its runner-up is promoted without touching LDS again.
     double bestd = INFINITY, secd = INFINITY;
     int besti = INT_MAX, seci = INT_MAX;  // seci: INT_MAX = the share has no further point, -1 = not known (rescan)
-    for (int c = lane; c < n3; c += 64) {
-      const int rep = c / n, j = c - rep * n;
-      const double s = xl[(size_t)j * 6] + (rep - 1) * Lt;
-      const double ds = s - qs, de = xl[(size_t)j * 6 + 1] - qe;
-      const double d = ds * ds + de * de;
-      dist[c] = d;
-      if (d < bestd) {
-        secd = bestd;
-        seci = besti;
-        bestd = d;
-        besti = c;
-      } else if (d < secd) {
-        secd = d;
-        seci = c;
+    // four points of the share per trip, their loads issued together (one point per trip left the pass waiting on a dependent
+    // L2 round trip per point, behind an integer division for (rep, j): 62 us per query wave), (rep, j) stepped, not divided
+    {
+      int j = lane, rep = 0;
+      while (j >= n) {
+        j -= n;
+        ++rep;
+      }
+      for (int c = lane; c < n3; c += 256) {
+        double sv[4], ev[4];
+        int rp[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const bool in = c + 64 * t < n3;
+          const int jj = in ? j : 0;
+          sv[t] = xl[(size_t)jj * 6];
+          ev[t] = xl[(size_t)jj * 6 + 1];
+          rp[t] = rep;
+          j += 64;
+          while (j >= n) {
+            j -= n;
+            ++rep;
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int ct = c + 64 * t;
+          if (ct < n3) {
+            const double s = sv[t] + (rp[t] - 1) * Lt;
+            const double ds = s - qs, de = ev[t] - qe;
+            const double d = ds * ds + de * de;
+            dist[ct] = d;
+            if (d < bestd) {
+              secd = bestd;
+              seci = besti;
+              bestd = d;
+              besti = ct;
+            } else if (d < secd) {
+              secd = d;
+              seci = ct;
+            }
+          }
+        }
       }
     }
     int take = K < n3 ? K : n3;
