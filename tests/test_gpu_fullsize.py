@@ -32,8 +32,9 @@ def _report(tag, e, ed, o64, ox):
              np.bincount(ox["status"], minlength=4).tolist(), ox["iters"].mean()))
 
 
-def _check(tag, o64, ox):
-    """status parity + every commonly solved problem within TOL_F32 of the fp64 answer"""
+def _check(tag, o64, ox, guard=None):
+    """status parity + every commonly solved problem within TOL_F32 of the fp64 answer (the stated contract); `guard`: four times
+    the worst distance this batch had when the test was written -- the kernels are bitwise reproducible, so a larger one is a change"""
     s64, sx = o64["status"] == 0, ox["status"] == 0
     lost = np.where(s64 & ~sx)[0]
     assert lost.size == 0, (tag, "solved in fp64, not by the reduced-precision entry", lost[:8], ox["status"][lost[:8]], ox["iters"][lost[:8]])
@@ -43,6 +44,8 @@ def _check(tag, o64, ox):
     _report(tag, e, ed, o64, ox)
     worst = np.argsort(e)[-4:]
     assert e.max() < TOL_F32, (tag, np.where(both)[0][worst], e[worst])
+    if guard is not None:
+        assert e.max() < guard, (tag, "worse than when the test was written", np.where(both)[0][worst], e[worst])
     assert np.percentile(e, 99) < 1e-4, (tag, np.percentile(e, 99))
     # the input rates are the inputs' differences over the 25 ms period (u_i = u_{i-1} + t dU_i, racing_mpc.cpp:190-196): an
     # error of the inputs shows up forty times larger in them, in the same scaled units
@@ -85,7 +88,7 @@ def test_configs4_share_of_one_gpu_every_problem(pkg, regression):
 
     o64, om = solve(False), solve(True)
     assert (o64["status"] == 0).mean() > 0.999, np.bincount(o64["status"])
-    _check("configs[4] share (learning, 160 pts, %s, mixed)" % ("regression" if regression else "no regression"), o64, om)
+    _check("configs[4] share (learning, 160 pts, %s, mixed)" % ("regression" if regression else "no regression"), o64, om, guard=1e-4)  # 2.5e-5 / 1.6e-5
     lam = om["convex_combi_optm"][:, om["status"] == 0]
     assert np.abs(lam.sum(0) - 1.0).max() < 1e-8 and lam.min() > -1e-9     # the simplex rows are fp64 in either pass
     sv.close()
@@ -108,5 +111,5 @@ def test_configs3_share_of_one_gpu_every_problem(pkg, entry):
         ox = _np(sv.solve_f32(inp32))
     else:
         ox = _np(sv.solve(inp, mixed=True))
-    _check("configs[3] share (IAC N = 40, %s)" % entry, o64, ox)
+    _check("configs[3] share (IAC N = 40, %s)" % entry, o64, ox, guard=None if entry == "f32" else 3.4e-4)  # mixed: 8.5e-5; fp32: 4.6e-4
     sv.close()
