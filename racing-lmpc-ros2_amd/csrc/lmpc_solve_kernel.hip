@@ -777,6 +777,7 @@ struct Lds {
   int N;
   int stride;  // of a stage record: LMPC_STAGE_STRIDE, or LMPC_LEAN_STAGE_STRIDE in the lean layout (below)
   bool fresh;  // FRESH_LANE in the sweeps of this instantiation (a compile-time constant where the sweeps are inlined)
+  bool chain_prio;  // CHAIN_PRIO around the serial stage chains (likewise)
   __device__ __forceinline__ real* st(int i) const { return base + i * stride; }
   __device__ __forceinline__ real* kn(int i) const { return base + (N - 1) * stride + i * LMPC_KNOT_STRIDE; }
   __device__ __forceinline__ real* tail() const { return base + (N - 1) * stride + N * LMPC_KNOT_STRIDE; }
@@ -863,6 +864,15 @@ __device__ __forceinline__ real qz_entry(const real* ct, bool terminal, int r, i
 // Pin the issue order of LDS traffic: one wave's DS instructions return in issue order, so the read a
 // serial chain waits for must be queued ahead of the operand prefetch of the following stage.
 #define ISSUE_ORDER() __builtin_amdgcn_sched_barrier(0)
+// The serial stage chains (factorisation, sweeps) at a higher issue priority than the row phases of the wave they share a SIMD
+// with (s_setprio): the chain's next instruction is the one a solve waits for, the row phases are throughput work that fills in.
+// Two-waves-per-SIMD kernels only (alone on its SIMD a wave has nobody to yield to: +0.5 %): headline kernel -1.5 %, pipelined
+// +1.4 %, one batch at a time -1.9 %, the mixed learning kernel -1.1 %; same bits (profiles/r04_row_phases.md).
+#ifndef LMPC_CHAIN_PRIO
+#define LMPC_CHAIN_PRIO 3
+#endif
+#define CHAIN_PRIO_ENTER() do { if (LMPC_CHAIN_PRIO && L.chain_prio) __builtin_amdgcn_s_setprio(LMPC_CHAIN_PRIO); } while (0)
+#define CHAIN_PRIO_LEAVE() do { if (LMPC_CHAIN_PRIO && L.chain_prio) __builtin_amdgcn_s_setprio(0); } while (0)
 // ... and the other way round: value x is complete before any later memory operation is issued (an
 // empty asm that consumes x and clobbers memory), used to keep a prefetch behind the last use of the
 // registers it overwrites.
@@ -897,6 +907,7 @@ __device__ __forceinline__ real qz_entry(const real* ct, bool terminal, int r, i
 template <bool HAS_PT, bool JOSEPH, typename real, typename ptreal>
 __device__ __forceinline__ void riccati_factor(const Lds<real>& L, int lane, const ptreal* PT) {
   FRESH_LANE(lane, 0);
+  CHAIN_PRIO_ENTER();
   const int N = L.N, r = lane >> 3, c = lane & 7;
   real* T = L.tail();
   real* MP = T + TL_P;
@@ -1066,6 +1077,7 @@ __device__ __forceinline__ void riccati_factor(const Lds<real>& L, int lane, con
     *(res_on ? st + res_off : res_junk) = res;
     wave_sync();
   }
+  CHAIN_PRIO_LEAVE();
 }
 
 // Lane K of every 16-lane row to the whole row (DPP row_newbcast, gfx90a+; v_mov_b64_dpp for doubles): a register-to-
@@ -1109,6 +1121,7 @@ __device__ __forceinline__ void row_bcast67(real v, real& a, real& b) {  // lane
 template <int NRHS, typename real>
 __device__ __forceinline__ void riccati_solve(const Lds<real>& L, int lane, Prof& pf) {
   FRESH_LANE(lane, 2);
+  CHAIN_PRIO_ENTER();
   const int N = L.N;
   const int r = lane & 7, s = (lane >> 4) & (NRHS - 1);
   const bool own = (lane & 8) == 0 && lane < 16 * NRHS;
@@ -1192,6 +1205,7 @@ __device__ __forceinline__ void riccati_solve(const Lds<real>& L, int lane, Prof
     *((own && r >= 6) ? kn + reg + 2 + r : junk1) = dv;
   }
   wave_sync();
+  CHAIN_PRIO_LEAVE();
   PT_MARK(10 + NRHS - 1)
 }
 
@@ -1915,7 +1929,8 @@ __device__ __forceinline__ PolishResult<real, KS> lmpc_polish(const PolishArgs<r
   const int lane = threadIdx.x;
   const int N = uni(a.N), NS = N - 1;
   constexpr bool LEAN = lmpc_lean(sizeof(real), KQ);
-  Lds<real> L{lds, N, LEAN ? LMPC_LEAN_STAGE_STRIDE : LMPC_STAGE_STRIDE, lmpc_fresh_lane(sizeof(real), KQ, KS)};
+  Lds<real> L{lds, N, LEAN ? LMPC_LEAN_STAGE_STRIDE : LMPC_STAGE_STRIDE, lmpc_fresh_lane(sizeof(real), KQ, KS),
+              lmpc_waves_per_simd(sizeof(real), KQ, KS) >= 2};
   real* const T = L.tail();
   treal* const TT = reinterpret_cast<treal*>(T + LMPC_TAIL_DOUBLES);
   ModelStream<real> MS{nullptr, nullptr, NS, lane, uni(a.have0), uni(a.have1)};
@@ -2492,7 +2507,9 @@ __host__ __device__ constexpr int lmpc_opaque_sites(int real_bytes, int kq, int 
   return (real_bytes == 8 && kq <= 4 && ks == 0) ? LMPC_OPAQUE_SITES : 0;
 }
 
-template <typename real, int KQ, int KS, typename io>
+// SECOND: the fp64 second pass of a mixed solve -- a handful of problems a whole batch waits for, sharing the chip with the next batch's
+// first pass: its waves run at the top issue priority throughout (and do not drop it between chains).
+template <typename real, int KQ, int KS, typename io, bool SECOND = false>
 __device__ __forceinline__ void lmpc_solve_problem(
     const lmpc_params& P, const int B, const int b, unsigned char* lds_raw, const io* __restrict__ ws_lin,
     const io* __restrict__ x_ic, const io* __restrict__ u_ic, const io* __restrict__ T_ref, const io* __restrict__ bl,
@@ -2515,7 +2532,9 @@ __device__ __forceinline__ void lmpc_solve_problem(
   // state per slot do not fit 512 registers, and what the allocator spills is the row state)
   constexpr int QC = lmpc_row_chunk(sizeof(real), KQ, KS);
   constexpr int SITES = lmpc_opaque_sites(sizeof(real), KQ, KS);
-  Lds<real> L{lds, N, LEAN ? LMPC_LEAN_STAGE_STRIDE : LMPC_STAGE_STRIDE, lmpc_fresh_lane(sizeof(real), KQ, KS)};
+  Lds<real> L{lds, N, LEAN ? LMPC_LEAN_STAGE_STRIDE : LMPC_STAGE_STRIDE, lmpc_fresh_lane(sizeof(real), KQ, KS),
+              !SECOND && lmpc_waves_per_simd(sizeof(real), KQ, KS) >= 2};
+  if constexpr (SECOND && LMPC_CHAIN_PRIO) __builtin_amdgcn_s_setprio(3);
   real* T = L.tail();
   real* ct = T + TL_CT;
   real* KN0 = L.kn(0);
@@ -3655,8 +3674,8 @@ __device__ __attribute__((noinline)) void lmpc_solve_problem_call(
     io* __restrict__ X_out, io* __restrict__ U_out, io* __restrict__ dU_out, int* __restrict__ status_out,
     int* __restrict__ iters_out, io* __restrict__ kkt_out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  lmpc_solve_problem<real, KQ, KS, io>(P, B, b, lds_raw, ws_lin, x_ic, u_ic, T_ref, bl, br, vref, ss_x, ss_j, lam_out, X_out, U_out,
-                                       dU_out, status_out, iters_out, kkt_out);
+  lmpc_solve_problem<real, KQ, KS, io, true>(P, B, b, lds_raw, ws_lin, x_ic, u_ic, T_ref, bl, br, vref, ss_x, ss_j, lam_out, X_out, U_out,
+                                             dU_out, status_out, iters_out, kkt_out);
 }
 
 template <typename real, int KQ, int KS, typename io>
