@@ -871,6 +871,9 @@ __device__ __forceinline__ real qz_entry(const real* ct, bool terminal, int r, i
 #ifndef LMPC_CHAIN_PRIO
 #define LMPC_CHAIN_PRIO 3
 #endif
+#ifndef LMPC_TERM_PRIO  // (the learning problem's terminal elimination, another serial chain: measured, see the profile)
+#define LMPC_TERM_PRIO 0
+#endif
 #define CHAIN_PRIO_ENTER() do { if (LMPC_CHAIN_PRIO && L.chain_prio) __builtin_amdgcn_s_setprio(LMPC_CHAIN_PRIO); } while (0)
 #define CHAIN_PRIO_LEAVE() do { if (LMPC_CHAIN_PRIO && L.chain_prio) __builtin_amdgcn_s_setprio(0); } while (0)
 // ... and the other way round: value x is complete before any later memory operation is issued (an
@@ -3036,7 +3039,9 @@ __device__ __forceinline__ void lmpc_solve_problem(
           }
 #pragma unroll
           for (int k = 0; k < 6; ++k) F[k * 6 + k] += 1.0 / fmax(TT[TL_E + k], treal(1e-30));  // (a zero weight: that component of eps is free)
+          if (LMPC_TERM_PRIO) CHAIN_PRIO_ENTER();
           term_factor_u(TT, lane, F, aB, av[6], m);
+          if (LMPC_TERM_PRIO) CHAIN_PRIO_LEAVE();
         }
         if (lane < 6) {
           treal e = 0.0;
@@ -3148,7 +3153,9 @@ __device__ __forceinline__ void lmpc_solve_problem(
           treal beta[6], h[6], nu;
 #pragma unroll
           for (int k = 0; k < 6; ++k) beta[k] = bs[k];
+          if (LMPC_TERM_PRIO) CHAIN_PRIO_ENTER();
           term_solve_u(TT, lane, sx.m, beta, bs[6], sx.r1, h, nu);
+          if (LMPC_TERM_PRIO) CHAIN_PRIO_LEAVE();
           PT_MARK(14)
           if (lane < 6) {  // terminal gradient onto x_T: E eps + pT, pT = -h
             treal hs = h[0];
@@ -3322,7 +3329,9 @@ __device__ __forceinline__ void lmpc_solve_problem(
         treal beta[6], h[6], nu;
 #pragma unroll
         for (int k = 0; k < 6; ++k) beta[k] = gs[k];
+        if (LMPC_TERM_PRIO) CHAIN_PRIO_ENTER();
         term_solve_u(TT, lane, sx.m, beta, gs[6], sx.r1, h, nu);
+        if (LMPC_TERM_PRIO) CHAIN_PRIO_LEAVE();
 #pragma unroll
         for (int q = 0; q < KS; ++q) {
           treal uh = 0.0, uq[6];
