@@ -1922,7 +1922,7 @@ constexpr bool lmpc_polish_is_call(int real_bytes, int kq, int ks) {
 }
 constexpr bool lmpc_fresh_lane(int real_bytes, int kq, int ks) { return LMPC_FRESH_POLICY != 0; }
 
-template <typename real, int KQ, int KS, typename io>
+template <typename real, int KQ, int KS, typename io, bool SECOND = false>  // (SECOND: see lmpc_solve_problem)
 __device__ __forceinline__ PolishResult<real, KS> lmpc_polish(const PolishArgs<real, KQ, KS>& a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   real* const lds = reinterpret_cast<real*>(lds_raw);
@@ -1933,7 +1933,7 @@ __device__ __forceinline__ PolishResult<real, KS> lmpc_polish(const PolishArgs<r
   const int N = uni(a.N), NS = N - 1;
   constexpr bool LEAN = lmpc_lean(sizeof(real), KQ);
   Lds<real> L{lds, N, LEAN ? LMPC_LEAN_STAGE_STRIDE : LMPC_STAGE_STRIDE, lmpc_fresh_lane(sizeof(real), KQ, KS),
-              lmpc_waves_per_simd(sizeof(real), KQ, KS) >= 2};
+              !SECOND && lmpc_waves_per_simd(sizeof(real), KQ, KS) >= 2};
   real* const T = L.tail();
   treal* const TT = reinterpret_cast<treal*>(T + LMPC_TAIL_DOUBLES);
   ModelStream<real> MS{nullptr, nullptr, NS, lane, uni(a.have0), uni(a.have1)};
@@ -2464,9 +2464,9 @@ __device__ __forceinline__ PolishResult<real, KS> lmpc_polish(const PolishArgs<r
   return res;
 }
 
-template <typename real, int KQ, int KS, typename io>
+template <typename real, int KQ, int KS, typename io, bool SECOND = false>
 __device__ __attribute__((noinline)) PolishResult<real, KS> lmpc_polish_call(const PolishArgs<real, KQ, KS> a) {
-  return lmpc_polish<real, KQ, KS, io>(a);
+  return lmpc_polish<real, KQ, KS, io, SECOND>(a);
 }
 
 // `real` is the arithmetic and LDS type, `io` the type of the arrays in HBM: <double, double> is the reference's
@@ -2858,9 +2858,9 @@ __device__ __forceinline__ void lmpc_solve_problem(
     pa.sx = sx;
     PolishResult<real, KS> pr;
     if constexpr (lmpc_polish_is_call(sizeof(real), KQ, KS))
-      pr = lmpc_polish_call<real, KQ, KS, io>(pa);
+      pr = lmpc_polish_call<real, KQ, KS, io, SECOND>(pa);
     else
-      pr = lmpc_polish<real, KQ, KS, io>(pa);
+      pr = lmpc_polish<real, KQ, KS, io, SECOND>(pa);
     pol_rounds = uni(pr.pol_rounds);
     // what the interior point recomputes before it reads it again (predictor products -- multiplied by zero in the next
     // predictor pass --, the explicit-point bookkeeping, the Schur scalars) does not live across the polish
