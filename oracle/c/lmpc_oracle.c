@@ -38,6 +38,7 @@
  */
 #include <math.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -906,7 +907,8 @@ __attribute__((optimize("no-tree-vectorize"))) static int polish(prob_t* p, work
       for (int sd = 0; sd < 2; ++sd) q->held[i][sl][sd] = p->act[i][sl][sd] && p->lam[i][sl][sd] > p->t[i][sl][sd];
   for (int j = 0; j < S; ++j) q->heldl[j] = p->ll[j] > p->tl[j];
   int ok = 0;
-  for (int round = 0; round < POLISH_ROUNDS && !ok; ++round) {
+  const int exp_rounds = getenv("EXP_ROUNDS") ? atoi(getenv("EXP_ROUNDS")) : POLISH_ROUNDS, exp_steps = getenv("EXP_STEPS") ? atoi(getenv("EXP_STEPS")) : POLISH_STEPS;
+  for (int round = 0; round < exp_rounds && !ok; ++round) {
     int nfree = 0;
     for (int j = 0; j < S; ++j) nfree += !q->heldl[j];
     if (S && nfree > MA_MAX) break;
@@ -929,7 +931,7 @@ __attribute__((optimize("no-tree-vectorize"))) static int polish(prob_t* p, work
     cost_gradient(p, w);
     newton_factor(p, w, 1);
     double last_step = 0.0;
-    for (int k = 0; k < POLISH_STEPS; ++k) {
+    for (int k = 0; k < exp_steps; ++k) {
       cost_gradient(p, w);
       for (int i = 0; i < N; ++i)
         for (int sl = 0; sl < NSLOT; ++sl)
@@ -961,6 +963,7 @@ __attribute__((optimize("no-tree-vectorize"))) static int polish(prob_t* p, work
         if (i < N - 1)
           for (int r = 0; r < 2; ++r) last_step = fmax(last_step, fabs(p->dv[i][r]) * isx[6 + r]);
       }
+      if (k >= POLISH_STEPS - 1 && last_step <= POLISH_STEP_TOL) break;
     }
     /* ---- verify ---- */
     int bad = !(last_step <= POLISH_STEP_TOL), anyneg = 0, anyweak = 0, anyviol = 0; /* (a last step that still moved the
@@ -996,6 +999,19 @@ __attribute__((optimize("no-tree-vectorize"))) static int polish(prob_t* p, work
       } else if (!(-p->lmb[j] <= POLISH_FEAS)) {
         anyviol = 1;
       }
+    }
+    if (getenv("LMPC_ORACLE_POLISH_TRACE")) {
+      int nheld = 0, nbadfeas = 0, nneg = 0, nviol = 0; double worst_feas = 0.0, worst_viol = 0.0;
+      for (int i = 0; i < N; ++i)
+        for (int sl = 0; sl < NSLOT; ++sl)
+          for (int sd = 0; sd < 2; ++sd) {
+            if (!p->act[i][sl][sd]) continue;
+            const double r = row_res(p, i, sl, sd);
+            if (q->held[i][sl][sd]) { ++nheld; if (!(fabs(r) <= POLISH_FEAS)) { ++nbadfeas; fprintf(stderr, "   held row (%d,%d,%d) res %.3e y %.3e ipm lam %.3e t %.3e\n", i, sl, sd, r, q->y[i][sl][sd], p->lam[i][sl][sd], p->t[i][sl][sd]); } if (fabs(r) > worst_feas) worst_feas = fabs(r); if (q->y[i][sl][sd] < -POLISH_DUAL) { ++nneg; fprintf(stderr, "   neg mult (%d,%d,%d) y %.3e ipm lam %.3e t %.3e\n", i, sl, sd, q->y[i][sl][sd], p->lam[i][sl][sd], p->t[i][sl][sd]); } }
+            else if (!(r <= POLISH_FEAS)) { ++nviol; if (r > worst_viol) worst_viol = r; fprintf(stderr, "   violated (%d,%d,%d) res %.3e ipm lam %.3e t %.3e\n", i, sl, sd, r, p->lam[i][sl][sd], p->t[i][sl][sd]); }
+          }
+      fprintf(stderr, "polish round %d: held %d last_step %.3e bad %d (held rows off %d, worst %.3e) neg %d (weak %d, ymin %.3e) viol %d (worst %.3e)\n",
+              round, nheld, last_step, bad, nbadfeas, worst_feas, nneg, anyweak, ymin, nviol, worst_viol);
     }
     if (!bad && !anyneg && !anyviol) {
       ok = 1;
