@@ -428,7 +428,8 @@ static inline double slot_val(double (*z)[8], double (*v)[2], int i, int sl) {
 #endif
 /* complementarity below which a step that does not lower it ends the solve (ipm_solve) */
 #define STALL_MU 1e-9
-#define MA_MAX 4
+#define MA_MAX 6 /* four until round 5: a five-lap safe set has optima that blend one point per lap, and the fifth point then went
+                  * through 1 / theta -> 1e12 (cond(F_B) with it): answers 1e-2 off, reported OPTIMAL (csrc/lmpc_solve_kernel.hip) */
 #define TAU_REL 1e-5 /* tau = TAU_REL * max_j u_j'E u_j: cond(F_B) <= ~1e5 */
 typedef struct {
   double Fi[36];       /* F^-1 over all points */
@@ -879,13 +880,21 @@ static void primal_update(prob_t* p, double alpha) {
 #define POLISH_THETA 1e8
 #define POLISH_MU 1e-8
 #define POLISH_RD 1e-6
-#define POLISH_ROUNDS 3
-#define POLISH_STEPS 2
+#define POLISH_ROUNDS 4
+#define POLISH_STEPS 4 /* at most; the loop stops after the second when that one moved the iterate by <= POLISH_STEP_OK */
+#define POLISH_STEP_OK 1e-7
 #define POLISH_FEAS 1e-9
 #define POLISH_DUAL 1e-7
 #define POLISH_STRONG 1e3
-#define POLISH_STEP_TOL 1e-5 /* the last multiplier step, in the reference's scaled units (racing_mpc.cpp:36-37): converged
-                              * steps are 1e-7 .. 1e-10, the ones this is there to catch 1e-3 .. 1e-1 */
+#define POLISH_STEP_TOL 1e-6 /* the last multiplier step, in the reference's scaled units (racing_mpc.cpp:36-37): converged
+                              * steps are 1e-7 .. 1e-10, the ones this is there to catch 1e-3 .. 1e-1.  Round 5: until then exactly
+                              * two steps and 1e-5.  A set repaired with rows that start from a zero multiplier, or two sigma-coupled
+                              * boundary rows, converges like 0.1 per step: the second step was still 1.5e-5 .. 1.7e-4 and the
+                              * attempt was refused -- at N = 80 / learning N = 60 that left the interior point's own answer, 9e-6 /
+                              * 2e-5 from the dense optimum (profiles/r04_fullsize_parity.txt, 1.1e-6 / 1.7e-5 kernel against twin) --
+                              * while an attempt accepted at 1e-5 with that rate is 1e-6 off.  Now: up to four steps, stop at 1e-7,
+                              * accept at 1e-6, four rounds.  On the bench distributions against the dense optimum (scratch/r5/
+                              * cmp_cache.py): worst 2e-7 at every horizon, mean iterations -0.3 %, maximum 18 -> 14 at N = 20. */
 typedef struct {
   double z[NMAX][8], v[NMAX][2], sigma, lmb[SMAX];
   rows_t y;
@@ -907,8 +916,7 @@ __attribute__((optimize("no-tree-vectorize"))) static int polish(prob_t* p, work
       for (int sd = 0; sd < 2; ++sd) q->held[i][sl][sd] = p->act[i][sl][sd] && p->lam[i][sl][sd] > p->t[i][sl][sd];
   for (int j = 0; j < S; ++j) q->heldl[j] = p->ll[j] > p->tl[j];
   int ok = 0;
-  const int exp_rounds = getenv("EXP_ROUNDS") ? atoi(getenv("EXP_ROUNDS")) : POLISH_ROUNDS, exp_steps = getenv("EXP_STEPS") ? atoi(getenv("EXP_STEPS")) : POLISH_STEPS;
-  for (int round = 0; round < exp_rounds && !ok; ++round) {
+  for (int round = 0; round < POLISH_ROUNDS && !ok; ++round) {
     int nfree = 0;
     for (int j = 0; j < S; ++j) nfree += !q->heldl[j];
     if (S && nfree > MA_MAX) break;
@@ -931,7 +939,7 @@ __attribute__((optimize("no-tree-vectorize"))) static int polish(prob_t* p, work
     cost_gradient(p, w);
     newton_factor(p, w, 1);
     double last_step = 0.0;
-    for (int k = 0; k < exp_steps; ++k) {
+    for (int k = 0; k < POLISH_STEPS; ++k) {
       cost_gradient(p, w);
       for (int i = 0; i < N; ++i)
         for (int sl = 0; sl < NSLOT; ++sl)
@@ -963,7 +971,7 @@ __attribute__((optimize("no-tree-vectorize"))) static int polish(prob_t* p, work
         if (i < N - 1)
           for (int r = 0; r < 2; ++r) last_step = fmax(last_step, fabs(p->dv[i][r]) * isx[6 + r]);
       }
-      if (k >= POLISH_STEPS - 1 && last_step <= POLISH_STEP_TOL) break;
+      if (k >= 1 && last_step <= POLISH_STEP_OK) break; /* (converged: the remaining steps would move nothing) */
     }
     /* ---- verify ---- */
     int bad = !(last_step <= POLISH_STEP_TOL), anyneg = 0, anyweak = 0, anyviol = 0; /* (a last step that still moved the

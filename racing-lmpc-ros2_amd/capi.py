@@ -356,7 +356,9 @@ class Solver:
         B, N = a[0].shape[1], self.N
         if out is None:
             kw = dict(dtype=torch.float32, device=self.device)
-            shapes = ((B, N, 6), (B, N - 1, 2)) if getattr(self, "_aos", False) else ((6, N, B), (2, N - 1, B))  # lmpc_set_output_layout
+            # (always the default layout: lmpc_set_output_layout applies to lmpc_solve_batch / _mixed only -- include/lmpc_hip.h --
+            # and until round 5 this allocated [B][N][6] under the AOS setting for a kernel that writes [6][N][B]: ADVICE r4)
+            shapes = ((6, N, B), (2, N - 1, B))
             out = {"X_optm": torch.empty(shapes[0], **kw), "U_optm": torch.empty(shapes[1], **kw),
                    "dU_optm": torch.empty(shapes[1], **kw), "kkt": torch.empty((4, B), **kw),
                    "status": torch.empty((B,), dtype=torch.int32, device=self.device),

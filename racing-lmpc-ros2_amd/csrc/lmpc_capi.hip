@@ -457,8 +457,12 @@ int lmpc_reserve(lmpc_handle* h, int32_t max_batch) {
   if (h->unverified) HIP_TRY(h, hipFree(h->unverified));
   h->unverified = nullptr;
   HIP_TRY(h, hipMalloc(&h->unverified, ((size_t)max_batch + 1) * sizeof(int)));
+  // the polish's save area first: a batch counts as reserved only when everything a solve of that size touches exists
+  // (with ws_cap set before a failed reserve_save a later solve skipped the reservation and wrote through a null save)
+  const int rc = reserve_save(h, (size_t)max_batch, sizeof(double));
+  if (rc != LMPC_OK) return rc;
   h->ws_cap = (size_t)max_batch;
-  return reserve_save(h, (size_t)max_batch, sizeof(double));
+  return LMPC_OK;
 }
 
 int lmpc_query_launch(const lmpc_handle* h, int32_t* lds_bytes_per_problem, int32_t* threads_per_problem) {

@@ -122,7 +122,13 @@ struct Prof {};
 #define TL_S11 228   // s11 = 1'M^-1 1
 #define TL_E 230     // E = 2 convex_hull_slack (exact, whatever `real` is)
 #define TL_UL 236    // the (centred) safe-set points, point-major [S][6]
-#define MA_MAX 4       // explicit points at most (the smallest theta below tau); supports of 1-3 points are what occurs
+// Explicit points at most (the smallest theta below tau).  Four until round 5 ("supports of 1-3 points are what occurs"): with a
+// FIVE-lap safe set the optimum blends one point per lap, a support of five, on ~0.1 % of the bench distribution at N = 27 .. 29
+// and on most problems at N <= 5 (tests/dispatch_sweep.py found them).  The fifth point then went through 1 / theta with theta ->
+// 1e-12: cond(F_B) 1e12, Newton steps with a stationarity residual of O(1), and an answer 1e-2 from the optimum reported OPTIMAL --
+// by the kernel and its twin alike, so kernel-against-twin tests could not see it; the dense oracle did.  Six is what the terminal
+// block can hold (C_A = Theta_A + U_A'F_B^-1 U_A has rank <= 6 as Theta_A -> 0) and what its LDS cells were laid out for.
+#define MA_MAX 6
 #define TAU_REL 1e-5   // tau = TAU_REL * max_j u_j'E u_j: cond(F_B) <= ~1e5 whatever the iteration does
 #define STALL_MU 1e-9  // complementarity below which a step that does not lower it ends the solve
 #define NBHD_GAMMA 1e-2  // once mu has risen: no complementarity product below this fraction of their mean after a step (1e-3
@@ -373,8 +379,15 @@ template <> struct ipm_limits<float> {
 template <typename real> struct polish_limits;
 template <> struct polish_limits<double> {
   static constexpr bool early = true;
-  static constexpr double theta = 1e8, feas = 1e-9, dual = 1e-7, mu_early = 1e-8, rd_early = 1e-6, step_ok = 0.0, step_tol = 1e-5;
-  static constexpr int rounds = 3, steps = 2;
+  // Round 5: up to FOUR multiplier steps (the loop stops after the second when that one moved the iterate by <= step_ok), a last
+  // step of at most 1e-6 (1e-5 until then) and four rounds (three).  A held set that a repair has extended -- the new rows start
+  // from a zero multiplier -- or two boundary rows coupled through sigma converge like 0.1 per step, not at once: the second
+  // step was still 1.5e-5 .. 1.7e-4, the attempt was refused, and what stood was the interior point's own answer, 9e-6 (tracking,
+  // N = 80) and 2e-5 (learning, N = 60) from the dense optimum; an attempt accepted at 1e-5 with that rate is itself 1e-6 off.
+  // Measured on the serial twin against the dense optimum over the bench distributions (scratch/r5/cmp_cache.py): worst 2e-7
+  // at every horizon, mean iterations -0.3 %, the slowest problem of the N = 20 batch 18 -> 14 iterations.
+  static constexpr double theta = 1e8, feas = 1e-9, dual = 1e-7, mu_early = 1e-8, rd_early = 1e-6, step_ok = 1e-7, step_tol = 1e-6;
+  static constexpr int rounds = 4, steps = 4;
 };
 template <> struct polish_limits<float> {
   // theta: 1e7 needs the stabilised factor and the fp64 2x2 pivot; with 1e5 chains of held input rows (u_i = u_{i-1} + t v_i,
@@ -559,9 +572,9 @@ __device__ __forceinline__ void term_factor_u(real* T, int lane, const real (&F)
     if (lane < 6 * MA_MAX) T[TL_WA + lane] = v;
   }
   wave_fence();
-  {  // C_A = Theta_A + U_A'W_A, staged through the factor's cells: lane 4a + b
-    static_assert(MA_MAX == 4, "lane mapping of C_A");
-    const int l = lane & 15, a = l >> 2, bq = l & 3;
+  {  // C_A = Theta_A + U_A'W_A, staged through the factor's cells: lane 6a + b
+    static_assert(MA_MAX == 6, "lane mapping of C_A, stride of the factor's cells");
+    const int l = lane < 36 ? lane : 0, a = (l * 43) >> 8, bq = l - 6 * a;
     real ua[6], wb[6];
 #pragma unroll
     for (int r = 0; r < 6; ++r) {
@@ -571,7 +584,7 @@ __device__ __forceinline__ void term_factor_u(real* T, int lane, const real (&F)
     real v = (a == bq) ? T[TL_THA + a] : real(0);
 #pragma unroll
     for (int r = 0; r < 6; ++r) v += ua[r] * wb[r];
-    if (lane < 16) T[TL_LC + a * 6 + bq] = v;
+    if (lane < 36) T[TL_LC + a * 6 + bq] = v;
   }
   wave_fence();
   // its Cholesky factor, reciprocal pivots on the diagonal; a jitter for identical points (the padding repeats the last
@@ -602,7 +615,7 @@ __device__ __forceinline__ void term_factor_u(real* T, int lane, const real (&F)
   // vectors from one product to the next through v_readlane
   real s11 = sB;
   {
-    const int la = lane & 3, lr = lane < 6 ? lane : 0;
+    const int la = lane < MA_MAX ? lane : 0, lr = lane < 6 ? lane : 0;
     real wa[6], fb[6], ua[MA_MAX];
 #pragma unroll
     for (int r = 0; r < 6; ++r) {
@@ -685,7 +698,7 @@ __device__ __forceinline__ void term_factor_u(real* T, int lane, const real (&F)
 template <typename real>
 __device__ __forceinline__ void term_solve_u(real* T, int lane, int m, const real (&beta)[6], real sig, real r1, real (&h)[6],
                                              real& nu) {
-  const int la = lane & 3, lr = lane < 6 ? lane : 0;
+  const int la = lane < MA_MAX ? lane : 0, lr = lane < 6 ? lane : 0;
   real wa[6], fb[6], ua[MA_MAX], Lc[36], ab[6], gg[6], x1[MA_MAX];
 #pragma unroll
   for (int r = 0; r < 6; ++r) {

@@ -25,6 +25,7 @@ double scalar(const DM& m, const char* what) {
   return m.data[0];
 }
 constexpr double kNewtonPerUnit = 1000.0;  // single_track_planar_model.cpp:215-216: u_lon is in kN
+constexpr double kRateRegularisation = 0.1;
 }  // namespace
 
 RacingLMPC::RacingLMPC(RacingLMPCConfig::SharedPtr mpc_config, VehicleModel::SharedPtr model, int device)
@@ -70,7 +71,13 @@ RacingLMPC::RacingLMPC(RacingLMPCConfig::SharedPtr mpc_config, VehicleModel::Sha
       c.u_min[a] = cf.u_min.data[a];
     }
   }
-  c.R_d[0] = c.R_d[3] = 1e-6;  // the reference has no rate cost; the solver needs a positive definite one (racing_lmpc.hpp)
+  // The reference has no rate cost; the solver needs a positive definite one, and the sequential-QP loop needs it for more than
+  // that: its QPs carry the cost's Hessian only, so with a vanishing weight on the input increments successive QPs zig-zag
+  // (measured with the dense SQP of oracle/nlp.py on tests/cpp/test_racing_lmpc.cpp's first solve: R_d = 1e-6 -> no convergence
+  // in 60 QPs, 1e-4 -> 30, 1e-3 -> 9).  One tenth of the input weight, per component.
+  c.R_d[0] = kRateRegularisation * c.R[0];
+  c.R_d[3] = kRateRegularisation * c.R[3];
+  if (!(c.R_d[0] > 0.0) || !(c.R_d[3] > 0.0)) throw std::invalid_argument("RacingLMPC: R must have a positive diagonal");
   for (int k = 0; k < 6; ++k) {
     c.x_max[k] = cf.x_max.data[k];
     c.x_min[k] = cf.x_min.data[k];

@@ -14,8 +14,10 @@
 // therefore FORWARDS to the nonlinear-dynamics path of the batched solver -- lmpc_solve_full_dynamics_host, the sequential-QP
 // loop that stands in for IPOPT behind RacingMPC(full_dynamics = true) -- with a configuration that restates this class's
 // problem as closely as that path can.  The differences, all in the problem and none in the surface:
-//   * input rates are VARIABLES there (dU, u_i = u_{i-1} + t_i dU_i) with a cost weight that must be positive definite: the
-//     facade sets R_d = 1e-6 I (the reference has no rate cost; at the sample weights the term is < 1e-6 of the objective);
+//   * input rates are VARIABLES there (dU, u_i = u_{i-1} + t_i dU_i) with a cost weight R_d the reference's problem does not
+//     have: the facade sets R_d = 0.1 diag(R).  It is what makes the sequential-QP loop converge -- its QPs carry the cost's
+//     Hessian only, and with a vanishing rate weight they zig-zag (racing_lmpc.cpp has the measurement) -- and it makes the plan
+//     smoother in the inputs than the reference's optimum;
 //   * ONE boundary slack shared by all knots (racing_mpc.cpp:533) instead of one per knot (racing_lmpc.cpp:83-90): identical
 //     while at most one knot is outside the tightened boundary, cheaper than the reference's when several are (the shared
 //     slack is charged once, q_boundary sigma^2, not once per violating knot);

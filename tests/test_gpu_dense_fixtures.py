@@ -1,0 +1,65 @@
+"""GPU: the KERNEL against the committed dense optima, every problem -- the strong link of the parity chain on
+>= 512 problems per BASELINE config (N = 20 BARC, N = 40 IAC, the learning problem with 160 and 96 safe-set points) and on 64 - 128
+problems at every shipped horizon, instead of the 24 + 8 + 8 + 16 golden problems of test_gpu_path.py.  Inputs: rebuilt on the CPU
+from the seeds (tests/dense_cases.py), checked against the fixture's digest, handed to lmpc_solve_batch as they are."""
+import numpy as np
+import pytest
+import torch
+
+import dense_cases as DC
+from parity import per_problem_err
+from tolerances import TOL_DU, TOL_F32, TOL_MEDIAN, TOL_XU
+
+pytestmark = pytest.mark.gpu
+GOLD = DC.__file__.rsplit("/", 1)[0] + "/golden"
+
+
+def _presets(pkg, name):
+    family, N = DC.CASES[name][0], DC.CASES[name][1]
+    if family == "trk":
+        return pkg.presets.barc_tracking_mpc(N), pkg.presets.barc_vehicle()
+    if family == "iac":
+        return pkg.presets.iac_tracking_mpc(N), pkg.presets.iac_vehicle()
+    return pkg.presets.barc_lmpc(N, 5 if family == "lrn" else 3), pkg.presets.barc_vehicle()
+
+
+def _solve(pkg, name, **kw):
+    d = np.load(f"{GOLD}/dense_{name}.npz")
+    fx = {k: d[k] for k in d.files}
+    cfg, veh, inp, ss_x, ss_j = DC.build(pkg, name)
+    np.testing.assert_allclose(DC.digest(inp, ss_x, ss_j), fx["digest"], rtol=1e-11, atol=0)
+    pc, pv = _presets(pkg, name)
+    sv = pkg.Solver(pc, pv, device=0)
+    B = fx["status"].size
+    if ss_x is None:
+        out = sv.solve(inp, **kw)
+    else:
+        o = sv.alloc_outputs(B)
+        o["convex_combi_optm"] = torch.zeros((cfg.num_ss_pts, B), dtype=torch.float64, device="cuda")
+        out = sv.solve(inp, o, ss_x=torch.as_tensor(ss_x, device="cuda"), ss_j=torch.as_tensor(ss_j, device="cuda"), **kw)
+    res = {k: v.cpu().numpy() for k, v in out.items() if hasattr(v, "cpu")}
+    sv.close()
+    return fx, res
+
+
+@pytest.mark.parametrize("name", list(DC.CASES))
+def test_kernel_against_dense_fixture_every_problem(pkg, name):
+    fx, o = _solve(pkg, name)
+    assert (o["status"] == 0).all(), (name, np.nonzero(o["status"])[0], o["status"][o["status"] != 0])
+    exu, ed = per_problem_err(o, fx)
+    worst = np.argsort(np.maximum(exu, ed))[-3:]
+    print("%s: %d problems, kernel vs dense X/U max %.1e median %.1e, dU max %.1e; iterations mean %.2f max %d"
+          % (name, exu.size, exu.max(), np.median(exu), ed.max(), o["iters"].mean(), o["iters"].max()))
+    assert exu.max() < TOL_XU and ed.max() < TOL_DU, (name, worst, exu[worst], ed[worst], fx["margin"][worst])
+    assert np.median(exu) < TOL_MEDIAN
+
+
+@pytest.mark.parametrize("name", ["iac_tracking_n40", "barc_lmpc_n20_s160", "iac_tracking_n80"])
+def test_mixed_precision_against_dense_fixture_every_problem(pkg, name):
+    """lmpc_solve_batch_mixed (configs[3] / configs[4] as quoted) against the DENSE optimum, not against the fp64 kernel: the stated
+    1e-3 (tests/tolerances.py TOL_F32), every problem."""
+    fx, o = _solve(pkg, name, mixed=True)
+    assert (o["status"] == 0).all(), (name, np.nonzero(o["status"])[0])
+    exu, ed = per_problem_err(o, fx)
+    print("%s mixed: X/U max %.1e 99 %% %.1e median %.1e, dU max %.1e" % (name, exu.max(), np.percentile(exu, 99), np.median(exu), ed.max()))
+    assert exu.max() < TOL_F32 and np.percentile(exu, 99) < 1e-4 and ed.max() < TOL_F32 / 0.025, (name, exu.max(), ed.max())

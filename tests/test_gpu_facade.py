@@ -76,6 +76,43 @@ def test_c_abi_from_plain_cpp_without_python_buffers():
     assert solved > 0.99 and rate > 1e6, r.stdout
 
 
+def test_racing_lmpc_facade_like_the_reference_test():
+    """tests/cpp/test_racing_lmpc.cpp: the reference's own test of its second plugin class (src/controllers/racing_lmpc/test/
+    test_racing_lmpc.cpp:63-160 -- ten teleporting solves, warm-start keys dropped once solved()), on the RacingLMPC facade in
+    both control layouts, with what the class promises checked instead of SUCCEED()."""
+    exe = LIB / "test_racing_lmpc"
+    assert exe.exists(), "run __graft_entry__.build() first"
+    track = ROOT / "tests" / "golden" / "barc_track" / "15_barc_optm.txt"
+    r = subprocess.run([str(exe), str(track)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("PASS"), (r.stdout[-3000:], r.stderr[-2000:])
+
+
+@pytest.mark.parametrize("shards,gather", [(1, "copy"), (2, "copy"), (2, "none"), (4, "copy")])
+def test_sharded_solver_from_plain_cpp(shards, gather):
+    """host/sharded_solver.{hpp,cpp} through bench_cabi --gpus N: N handles, N host threads, N streams, contiguous slices, results
+    gathered; on this one-GPU box every shard sits on device 0 (--same-device; the RCCL gather needs distinct devices and is
+    covered by construction + the 8-GPU driver run).  The program itself compares every problem with ONE handle solving the
+    whole batch, bit for bit, and the gathered records with each shard's own."""
+    exe = LIB / "bench_cabi"
+    assert exe.exists(), "run __graft_entry__.build() first"
+    track = ROOT / "tests" / "golden" / "barc_track" / "15_barc_optm.txt"
+    r = subprocess.run([str(exe), str(track), "2048", "10", "--gpus", str(shards), "--same-device", "--gather", gather],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout, r.stderr)
+    f = r.stdout.split()
+    assert int(f[f.index("differ_from_unsharded") + 1]) == 0 and int(f[f.index("gather_mismatch") + 1]) == 0, r.stdout
+    assert float(f[f.index("solved") + 1]) > 0.99 and int(f[f.index("shards") + 1]) == shards, r.stdout
+    print(r.stdout.strip())
+
+
+def test_sharded_solver_rccl_needs_distinct_devices():
+    exe = LIB / "bench_cabi"
+    track = ROOT / "tests" / "golden" / "barc_track" / "15_barc_optm.txt"
+    r = subprocess.run([str(exe), str(track), "256", "2", "--gpus", "2", "--same-device", "--gather", "rccl"], capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 1 and "distinct device" in r.stderr, (r.stdout, r.stderr)
+
+
 @pytest.mark.parametrize("N,mode", [(20, "continuous"), (20, "step"), (60, "continuous")])
 def test_node_core_drives_two_laps_of_the_reference_barc_track(N, mode):
     """RacingMPCNodeCore::step = RacingMPCNode::on_step_timer without ROS 2 (racing_mpc_node.cpp:150-477): global pose in,

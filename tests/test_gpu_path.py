@@ -1093,5 +1093,12 @@ def test_aos_layout_does_not_reach_the_solves_the_library_runs_for_itself(pkg):
         rc = lib.lmpc_solve_host(h, *[p(a) for a in hx], C.c_double(tr["L"]), None, None, p(X), p(U), p(dU), None, C.byref(st), C.byref(it))
         assert rc == 0 and st.value == ref_qp["status"][b]
         assert np.array_equal(X.T, ref_qp["X_optm"][:, :, b]) and np.array_equal(U.T, ref_qp["U_optm"][:, :, b]) and np.array_equal(dU.T, ref_qp["dU_optm"][:, :, b])
+        # lmpc_solve_batch_f32 writes the default layout whatever the setting; Solver.solve_f32 must allocate that shape
+        # (it allocated [B][N][6] under AOS and returned an SOA buffer viewed as AOS)
+        f32 = to_np(solver.solve_f32(inp))
+        assert f32["X_optm"].shape == (6, 20, 48) and f32["U_optm"].shape == (2, 19, 48)
     finally:
         solver.set_output_layout("soa")
+    f32_soa = to_np(solver.solve_f32(inp))
+    for k in ("X_optm", "U_optm", "dU_optm", "status"):
+        assert np.array_equal(f32[k], f32_soa[k]), k
