@@ -439,6 +439,7 @@ typedef struct {
   int m, idx[MA_MAX];  /* the explicit points */
   double W[6][MA_MAX]; /* W_A = F_B^-1 U_A */
   double Lc[MA_MAX][MA_MAX]; /* Cholesky factor of C_A */
+  double Ci[MA_MAX][MA_MAX]; /* C_A^-1 */
   double x1[MA_MAX];
   unsigned char inA[SMAX];
 } term_t;
@@ -480,19 +481,17 @@ static void mv6(const double* M, const double* x, double* y) {
   }
 }
 
-/* x <- C_A^-1 x through the Cholesky factor */
+/* x <- C_A^-1 x with the explicit inverse (term_factor forms it column by column from the Cholesky factor, as the kernel does:
+ * there one lane per row applies it, which is why it is not a pair of substitutions) */
 static void solve_CA(const term_t* tm, double* x) {
   const int m = tm->m;
-  for (int i = 0; i < m; ++i) {
-    double s = x[i];
-    for (int k = 0; k < i; ++k) s -= tm->Lc[i][k] * x[k];
-    x[i] = s / tm->Lc[i][i];
+  double y[MA_MAX];
+  for (int a = 0; a < m; ++a) {
+    double s = 0.0;
+    for (int b = 0; b < m; ++b) s += tm->Ci[a][b] * x[b];
+    y[a] = s;
   }
-  for (int i = m - 1; i >= 0; --i) {
-    double s = x[i];
-    for (int k = i + 1; k < m; ++k) s -= tm->Lc[k][i] * x[k];
-    x[i] = s / tm->Lc[i][i];
-  }
+  for (int a = 0; a < m; ++a) x[a] = y[a];
 }
 
 static void term_factor(prob_t* p, term_t* tm, const double* thl, double* PT) {
@@ -547,6 +546,20 @@ static void term_factor(prob_t* p, term_t* tm, const double* thl, double* PT) {
       for (int k = 0; k < b; ++k) s -= tm->Lc[a][k] * tm->Lc[b][k];
       tm->Lc[a][b] = (a == b) ? sqrt(s) : s / tm->Lc[b][b];
     }
+  }
+  for (int c = 0; c < m; ++c) { /* C_A^-1, column c: L L' x = e_c */
+    double y[MA_MAX], x[MA_MAX];
+    for (int i = 0; i < m; ++i) {
+      double t = (i == c) ? 1.0 : 0.0;
+      for (int k = 0; k < i; ++k) t -= tm->Lc[i][k] * y[k];
+      y[i] = t / tm->Lc[i][i];
+    }
+    for (int i = m - 1; i >= 0; --i) {
+      double t = y[i];
+      for (int k = i + 1; k < m; ++k) t -= tm->Lc[k][i] * x[k];
+      x[i] = t / tm->Lc[i][i];
+    }
+    for (int i = 0; i < m; ++i) tm->Ci[i][c] = x[i];
   }
   /* F^-1 = F_B^-1 - W C^-1 W' (column by column) */
   for (int c = 0; c < 6; ++c) {
@@ -901,6 +914,7 @@ typedef struct {
   double yl[SMAX], resl[SMAX];
   rows_t res;
   unsigned char held[NMAX][NSLOT][2], heldl[SMAX];
+  int noise;
 } polish_t;
 
 /* (no auto-vectorisation: gcc 11 at -O3 -march=x86-64-v3 miscompiles the mixed int / double classification loop) */
@@ -916,6 +930,7 @@ __attribute__((optimize("no-tree-vectorize"))) static int polish(prob_t* p, work
       for (int sd = 0; sd < 2; ++sd) q->held[i][sl][sd] = p->act[i][sl][sd] && p->lam[i][sl][sd] > p->t[i][sl][sd];
   for (int j = 0; j < S; ++j) q->heldl[j] = p->ll[j] > p->tl[j];
   int ok = 0;
+  q->noise = 0;
   for (int round = 0; round < POLISH_ROUNDS && !ok; ++round) {
     int nfree = 0;
     for (int j = 0; j < S; ++j) nfree += !q->heldl[j];
@@ -971,6 +986,7 @@ __attribute__((optimize("no-tree-vectorize"))) static int polish(prob_t* p, work
         if (i < N - 1)
           for (int r = 0; r < 2; ++r) last_step = fmax(last_step, fabs(p->dv[i][r]) * isx[6 + r]);
       }
+      if (getenv("LMPC_ORACLE_POLISH_TRACE")) fprintf(stderr, "      step %d: %.3e\n", k, last_step);
       if (k >= 1 && last_step <= POLISH_STEP_OK) break; /* (converged: the remaining steps would move nothing) */
     }
     /* ---- verify ---- */
@@ -1026,6 +1042,7 @@ __attribute__((optimize("no-tree-vectorize"))) static int polish(prob_t* p, work
       *mu_out = comp / m_rows;
       break;
     }
+    q->noise = bad && !anyneg && !anyviol; /* a consistent held set whose multiplier steps did not converge (see ipm_solve's exit) */
     /* ---- repair the working set ---- */
     int changed = 0;
     for (int i = 0; i < N; ++i)
@@ -1335,7 +1352,12 @@ static int ipm_solve(prob_t* p, work_t* w, polish_t* pq, int* iters_out, double*
   }
 
   /* the interior point has converged (or stopped at its floor with status OPTIMAL): polish what it reached */
-  if (pq && status == LMPC_SOLVE_OPTIMAL && !pol_done) pol_done = polish(p, w, pq, m, &pol_rounds, &mu);
+  if (pq && status == LMPC_SOLVE_OPTIMAL && !pol_done) {
+    pol_done = polish(p, w, pq, m, &pol_rounds, &mu);
+    /* refused, by a consistent held set whose multiplier steps did not settle: the sweeps are noisier than the contract on
+     * this problem, and the interior point's iterate came from the same sweeps (csrc/lmpc_solve_kernel.hip, same place) */
+    if (!pol_done && pq->noise) status = LMPC_SOLVE_MAX_ITER;
+  }
   /* ---- exit: report the reduced-gradient stationarity for the multipliers reached ---- */
   double rg = 0.0, viol = rdmax;
   if (status != LMPC_SOLVE_INFEASIBLE) {

@@ -47,7 +47,7 @@ struct lmpc_params {
 #define LMPC_TAIL_DOUBLES 320
 // learning: the terminal region behind the records -- always fp64 cells, whatever the records' type: the terminal-block
 // scratch (lmpc_solve_kernel.hip TL_*) and the (centred) safe-set points [6][64 KS], KS = 2 up to 128 points, 3 up to 192
-#define LMPC_TERM_CELLS 236
+#define LMPC_TERM_CELLS 272
 #define LMPC_SS_STRIDE(S) ((S) + 1)  // safe-set points kept behind the terminal cells, 6 cells each: S of them + one zero point
 #define LMPC_LIN_RECORD 54  // per stage in the linearisation workspace: ABt[8][6] | g[6]
 

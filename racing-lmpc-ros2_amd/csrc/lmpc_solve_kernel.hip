@@ -112,7 +112,7 @@ struct Prof {};
 #define TL_FB 48     // F_B^-1 [6][6], F_B = E^-1 + U_B Th_B^-1 U_B' (the points eliminated through 1/theta)
 #define TL_WA 84     // W_A = F_B^-1 U_A, column a at +6a
 #define TL_UA 120    // u of the explicit points, point a at +6a
-#define TL_LC 156    // Cholesky factor of C_A = Theta_A + U_A'F_B^-1 U_A, [i][k] (k < i); the RECIPROCAL pivots on the diagonal
+#define TL_LC 156    // C_A^-1 [6][6] (full, symmetric), C_A = Theta_A + U_A'F_B^-1 U_A; C_A itself while it is being formed
 #define TL_X1 192    // C_A^-1 (1_A - W_A'a_B)
 #define TL_G 198     // g = E U M^-1 1
 #define TL_AB 204    // a_B = U_B Th_B^-1 1
@@ -121,7 +121,8 @@ struct Prof {};
 #define TL_XA 222    // their step d lambda_A (read back by the owner lanes)
 #define TL_S11 228   // s11 = 1'M^-1 1
 #define TL_E 230     // E = 2 convex_hull_slack (exact, whatever `real` is)
-#define TL_UL 236    // the (centred) safe-set points, point-major [S][6]
+#define TL_Z 236     // Z = C_A^-1 W_A' [6][6] (a product of term_factor_u)
+#define TL_UL 272    // the (centred) safe-set points, point-major [S][6]
 // Explicit points at most (the smallest theta below tau).  Four until round 5 ("supports of 1-3 points are what occurs"): with a
 // FIVE-lap safe set the optimum blends one point per lap, a support of five, on ~0.1 % of the bench distribution at N = 27 .. 29
 // and on most problems at N <= 5 (tests/dispatch_sweep.py found them).  The fifth point then went through 1 / theta with theta ->
@@ -376,6 +377,9 @@ template <> struct ipm_limits<float> {
 #ifndef LMPC_F32_POL_STEP_TOL
 #define LMPC_F32_POL_STEP_TOL 1e-4f
 #endif
+#ifndef LMPC_F32_POL_STEPS
+#define LMPC_F32_POL_STEPS 3
+#endif
 template <typename real> struct polish_limits;
 template <> struct polish_limits<double> {
   static constexpr bool early = true;
@@ -396,7 +400,7 @@ template <> struct polish_limits<float> {
   static constexpr bool early = false;  // (an early attempt at mu ~ 1e-4 was measured on the serial twin: the iterations it saves are fewer than the rounds it adds)
   static constexpr float theta = 1e7f, feas = LMPC_F32_POL_FEAS, dual = LMPC_F32_POL_DUAL, mu_early = 0.0f, rd_early = 0.0f, step_ok = 3e-6f,
                          step_tol = LMPC_F32_POL_STEP_TOL;
-  static constexpr int rounds = 4, steps = 3;
+  static constexpr int rounds = 4, steps = LMPC_F32_POL_STEPS;
 };
 // 1 / scale of the quantity a slot constrains: the reference's scale vectors (racing_mpc.cpp:36-37, hard-coded there for every
 // vehicle) -- used only to measure a polish step
@@ -488,31 +492,25 @@ __device__ __forceinline__ real simplex_bl_polish(real lm, real y, bool held, re
 // divided by a small theta, and cond(F_B) stays below ~1/TAU_REL.  Everything here is wave-uniform arithmetic on values
 // every lane holds; results go to the LDS tail (lane 0 writes), the per-right-hand-side solves read them back as
 // broadcast reads.  Unused explicit slots (a >= m) hold u = 0, theta = 1, so they drop out without a branch.
+// x <- C_A^-1 x.  Lane `la` (< MA_MAX) brings component la of x in `v` and holds row la of C_A^-1 in `ci`; every lane gets all
+// of the result.  (Until round 5 every lane carried the whole Cholesky factor and ran both substitutions itself: with six
+// explicit points that is 21 live values and two dependent chains of 21 operations per right-hand side.)
 template <typename real>
-__device__ __forceinline__ void chol_solve6(const real* Lc, real (&x)[MA_MAX]) {  // x <- C_A^-1 x
+__device__ __forceinline__ void cinv_apply(const real (&ci)[MA_MAX], real v, real (&x)[MA_MAX]) {
+  real s = 0.0;
 #pragma unroll
-  for (int i = 0; i < MA_MAX; ++i) {
-    real v = x[i];
+  for (int b = 0; b < MA_MAX; ++b) s += ci[b] * lane_bcast(v, b);
 #pragma unroll
-    for (int k = 0; k < i; ++k) v -= Lc[i * 6 + k] * x[k];
-    x[i] = v * Lc[i * 6 + i];
-  }
-#pragma unroll
-  for (int i = MA_MAX - 1; i >= 0; --i) {
-    real v = x[i];
-#pragma unroll
-    for (int k = i + 1; k < MA_MAX; ++k) v -= Lc[k * 6 + i] * x[k];
-    x[i] = v * Lc[i * 6 + i];
-  }
+  for (int a = 0; a < MA_MAX; ++a) x[a] = lane_bcast(s, a);
 }
 
 // F = E^-1 + T_B (full 6x6), a_B, s_B, m explicit points (their u, theta already in T[TL_UA], T[TL_THA]).
-// Writes F_B^-1, W_A, the factor of C_A, x1, g, a_B, s11 and PT = F^-1 + g g'/s11 to the LDS tail.
+// Writes F_B^-1, W_A, C_A^-1, x1, g, a_B, s11 and PT = F^-1 + g g'/s11 to the LDS tail.
 // The two Cholesky factors are wave-uniform arithmetic in registers (every lane holds the sums they start from); the
-// products in between run one OUTPUT per lane -- a column of F_B^-1, an element of W_A, C_A, PT -- on operands fetched
-// from LDS in one batch per stage, results to LDS (each cell has one writer), a fence, next stage.  An earlier form
+// products in between run one OUTPUT per lane -- a column of F_B^-1 or C_A^-1, an element of W_A, C_A, Z, PT -- on operands
+// fetched from LDS in one batch per stage, results to LDS (each cell has one writer), a fence, next stage.  An earlier form
 // computed everything in every lane with lane 0 storing: ~300 dependent LDS round trips per call, 26 k cycles per
-// iteration at one wave per SIMD.  Per output the operations and their order are the same: bit-identical results.
+// iteration at one wave per SIMD.
 template <typename real>
 __device__ __forceinline__ void term_factor_u(real* T, int lane, const real (&F)[36], const real (&aB)[6], real sB, int m) {
   {  // F_B^-1 by Cholesky: lane c < 6 solves for column c
@@ -572,8 +570,8 @@ __device__ __forceinline__ void term_factor_u(real* T, int lane, const real (&F)
     if (lane < 6 * MA_MAX) T[TL_WA + lane] = v;
   }
   wave_fence();
-  {  // C_A = Theta_A + U_A'W_A, staged through the factor's cells: lane 6a + b
-    static_assert(MA_MAX == 6, "lane mapping of C_A, stride of the factor's cells");
+  {  // C_A = Theta_A + U_A'W_A, staged through the cells of its inverse: lane 6a + b
+    static_assert(MA_MAX == 6, "lane mapping of C_A, stride of its cells");
     const int l = lane < 36 ? lane : 0, a = (l * 43) >> 8, bq = l - 6 * a;
     real ua[6], wb[6];
 #pragma unroll
@@ -587,10 +585,10 @@ __device__ __forceinline__ void term_factor_u(real* T, int lane, const real (&F)
     if (lane < 36) T[TL_LC + a * 6 + bq] = v;
   }
   wave_fence();
-  // its Cholesky factor, reciprocal pivots on the diagonal; a jitter for identical points (the padding repeats the last
-  // point of the set: C_A is then singular as theta -> 0)
-  real Lc[36];
-  {
+  {  // C_A^-1 by Cholesky, like F_B^-1: the factor in registers (wave-uniform), lane c < MA_MAX solves for column c.  A jitter for
+     // identical points (the padding repeats the last point of the set: C_A is then singular as theta -> 0).  An unused slot
+     // (a >= m) has u = 0, theta = 1: its row and column of C_A are those of the identity, and so are its inverse's.
+    real Lc[36];
     real jit = 0.0;
 #pragma unroll
     for (int a = 0; a < MA_MAX; ++a) {
@@ -609,6 +607,27 @@ __device__ __forceinline__ void term_factor_u(real* T, int lane, const real (&F)
         Lc[a * 6 + bq] = (a == bq) ? frsqrt(v) : v * Lc[bq * 6 + bq];
       }
     }
+    const int c = lane < MA_MAX ? lane : 0;
+    real y[MA_MAX], x[MA_MAX];
+#pragma unroll
+    for (int i = 0; i < MA_MAX; ++i) {
+      real t = (i == c) ? real(1) : real(0);
+#pragma unroll
+      for (int k = 0; k < i; ++k) t -= Lc[i * 6 + k] * y[k];
+      y[i] = t * Lc[i * 6 + i];
+    }
+#pragma unroll
+    for (int i = MA_MAX - 1; i >= 0; --i) {
+      real t = y[i];
+#pragma unroll
+      for (int k = i + 1; k < MA_MAX; ++k) t -= Lc[k * 6 + i] * x[k];
+      x[i] = t * Lc[i * 6 + i];
+    }
+    wave_fence();  // (every lane has read C_A before its cells take the inverse)
+    if (lane < MA_MAX) {
+#pragma unroll
+      for (int i = 0; i < MA_MAX; ++i) T[TL_LC + i * 6 + lane] = x[i];
+    }
   }
   wave_fence();
   // x1 = C_A^-1 (1_A - W_A'a_B), z1 = a_B + U_A x1, g = F_B^-1 z1, s11 = 1_A'x1 + s_B - a_B'g: a row per lane, the
@@ -616,23 +635,24 @@ __device__ __forceinline__ void term_factor_u(real* T, int lane, const real (&F)
   real s11 = sB;
   {
     const int la = lane < MA_MAX ? lane : 0, lr = lane < 6 ? lane : 0;
-    real wa[6], fb[6], ua[MA_MAX];
+    real wa[6], fb[6], ua[MA_MAX], ci[MA_MAX];
 #pragma unroll
     for (int r = 0; r < 6; ++r) {
       wa[r] = T[TL_WA + la * 6 + r];
       fb[r] = T[TL_FB + lr * 6 + r];
     }
 #pragma unroll
-    for (int a = 0; a < MA_MAX; ++a) ua[a] = T[TL_UA + a * 6 + lr];
+    for (int a = 0; a < MA_MAX; ++a) {
+      ua[a] = T[TL_UA + a * 6 + lr];
+      ci[a] = T[TL_LC + la * 6 + a];
+    }
     real x1[MA_MAX], g[6];
     {
       real v = la < m ? real(1) : real(0);
 #pragma unroll
       for (int r = 0; r < 6; ++r) v -= wa[r] * aB[r];
-#pragma unroll
-      for (int a = 0; a < MA_MAX; ++a) x1[a] = lane_bcast(v, a);
+      cinv_apply(ci, v, x1);
     }
-    chol_solve6(Lc, x1);
     real z1u[6];
     {
       real z = aB[0];
@@ -660,29 +680,24 @@ __device__ __forceinline__ void term_factor_u(real* T, int lane, const real (&F)
 #pragma unroll
       for (int k = 0; k < 6; ++k) T[TL_G + k] = g[k];
 #pragma unroll
-      for (int a = 0; a < MA_MAX; ++a) {
-        T[TL_X1 + a] = x1[a];
-#pragma unroll
-        for (int bq = 0; bq <= a; ++bq) T[TL_LC + a * 6 + bq] = Lc[a * 6 + bq];
-      }
+      for (int a = 0; a < MA_MAX; ++a) T[TL_X1 + a] = x1[a];
       T[TL_S11] = s11;
     }
+  }
+  {  // Z = C_A^-1 W_A': lane 6a + c
+    const int l = lane < 36 ? lane : 0, a = (l * 43) >> 8, c = l - 6 * a;
+    real v = 0.0;
+#pragma unroll
+    for (int bq = 0; bq < MA_MAX; ++bq) v += T[TL_LC + a * 6 + bq] * T[TL_WA + bq * 6 + c];
+    if (lane < 36) T[TL_Z + a * 6 + c] = v;
   }
   wave_fence();
   {  // PT = F_B^-1 - W_A C_A^-1 W_A' + g g'/s11: lane 6r + c
     const real is11 = frcp(s11);
     const int l = lane < 36 ? lane : 0, r = (l * 43) >> 8, c = l - 6 * r;
-    real t[MA_MAX], wr[MA_MAX];
+    real v = T[TL_FB + r * 6 + c] + T[TL_G + r] * T[TL_G + c] * is11;
 #pragma unroll
-    for (int a = 0; a < MA_MAX; ++a) {
-      t[a] = T[TL_WA + a * 6 + c];
-      wr[a] = T[TL_WA + a * 6 + r];
-    }
-    const real gc = T[TL_G + c], gr = T[TL_G + r], fbrc = T[TL_FB + r * 6 + c];
-    chol_solve6(Lc, t);
-    real v = fbrc + gr * gc * is11;
-#pragma unroll
-    for (int a = 0; a < MA_MAX; ++a) v -= wr[a] * t[a];
+    for (int a = 0; a < MA_MAX; ++a) v -= T[TL_WA + a * 6 + r] * T[TL_Z + a * 6 + c];
     if (lane < 36) T[TL_PT + lane] = v;
   }
   wave_fence();
@@ -690,16 +705,16 @@ __device__ __forceinline__ void term_factor_u(real* T, int lane, const real (&F)
 
 // One right-hand side: beta = U_B Th_B^-1 r_B, sig = 1'Th_B^-1 r_B (wave sums over B), r_A in T[TL_RA], simplex
 // residual r1.  Returns h = E U dlambda and nu; writes the explicit points' step to T[TL_XA] (lane 0).
-// The operands (rows of W_A, U_A, F_B^-1, the factor of C_A, a_B, g) do not depend on the right-hand side: every lane
+// The operands (rows of W_A, U_A, F_B^-1, C_A^-1, a_B, g) do not depend on the right-hand side: every lane
 // fetches the row it works on in ONE batch of LDS reads, the four short products run one output per lane, and what the
 // next product needs of the previous one travels through v_readlane (scalar registers), not through LDS -- at one wave
 // per SIMD every dependent LDS round trip is ~100 idle cycles, and the all-lanes-compute-everything form of this
-// routine had ~100 of them.  Same operations in the same order per output: results are bit-identical to that form.
+// routine had ~100 of them.
 template <typename real>
 __device__ __forceinline__ void term_solve_u(real* T, int lane, int m, const real (&beta)[6], real sig, real r1, real (&h)[6],
                                              real& nu) {
   const int la = lane < MA_MAX ? lane : 0, lr = lane < 6 ? lane : 0;
-  real wa[6], fb[6], ua[MA_MAX], Lc[36], ab[6], gg[6], x1[MA_MAX];
+  real wa[6], fb[6], ua[MA_MAX], ci[MA_MAX], ab[6], gg[6], x1[MA_MAX];
 #pragma unroll
   for (int r = 0; r < 6; ++r) {
     wa[r] = T[TL_WA + la * 6 + r];
@@ -712,18 +727,15 @@ __device__ __forceinline__ void term_solve_u(real* T, int lane, int m, const rea
   for (int a = 0; a < MA_MAX; ++a) {
     ua[a] = T[TL_UA + a * 6 + lr];
     x1[a] = T[TL_X1 + a];
-#pragma unroll
-    for (int k = 0; k <= a; ++k) Lc[a * 6 + k] = T[TL_LC + a * 6 + k];
+    ci[a] = T[TL_LC + la * 6 + a];
   }
   real xa[MA_MAX];
   {
     real v = ra;
 #pragma unroll
     for (int r = 0; r < 6; ++r) v -= wa[r] * beta[r];
-#pragma unroll
-    for (int a = 0; a < MA_MAX; ++a) xa[a] = lane_bcast(v, a);
+    cinv_apply(ci, v, xa);
   }
-  chol_solve6(Lc, xa);
   real num = sig - r1;
   real zu[6];
   {
@@ -1895,6 +1907,7 @@ struct PolishArgs {
 template <typename real, int KS>
 struct PolishResult {
   int accepted, pol_rounds, have0, have1;
+  int noise;  // refused, and the last round failed on nothing but the multiplier steps / the held rows' residual (see the exit of lmpc_solve_problem)
   real sigma, mu, rdmax, last_step;
   double lm[KS > 0 ? KS : 1];  // the simplex weights of an accepted polish
 };
@@ -2020,7 +2033,7 @@ __device__ __forceinline__ PolishResult<real, KS> lmpc_polish(const PolishArgs<r
   }
   const real sigma_keep = sigma;
   put_keep();
-  bool accepted = false;
+  bool accepted = false, noise = false;
   for (int round = 0; round < pol::rounds; ++round) {
     if (round > 0) {  // every round starts from the interior point's iterate
       wave_sync();
@@ -2423,6 +2436,7 @@ __device__ __forceinline__ PolishResult<real, KS> lmpc_polish(const PolishArgs<r
       accepted = true;
       break;
     }
+    noise = anybad && !anyneg && !anyviol;  // a consistent held set whose multiplier steps did not converge
     // repair: release rows with a negative multiplier -- those the interior point did not hold firmly if there are such,
     // otherwise the most negative ones (a wrong row drags its neighbours' multipliers below zero) -- and only when no
     // multiplier is negative, hold the rows the new point violates
@@ -2463,6 +2477,7 @@ __device__ __forceinline__ PolishResult<real, KS> lmpc_polish(const PolishArgs<r
   }
   PolishResult<real, KS> res;
   res.accepted = accepted ? 1 : 0;
+  res.noise = (!accepted && noise) ? 1 : 0;
   res.pol_rounds = pol_rounds;
   res.have0 = MS.have0;
   res.have1 = MS.have1;
@@ -2845,6 +2860,7 @@ __device__ __forceinline__ void lmpc_solve_problem(
   // The active-set polish is a call (lmpc_polish_call above): the interior point's row state goes in by value, an accepted
   // attempt returns the wave-wide scalars and the simplex weights of the polished point (the point itself is in LDS), a
   // refused one has put everything back.
+  bool pol_noise = false;
   auto polish_attempt = [&]() -> bool {
     PolishArgs<real, KQ, KS> pa;
     pa.keep = reinterpret_cast<io*>(P.save) + (size_t)b * (10 * N - 4);
@@ -2896,6 +2912,7 @@ __device__ __forceinline__ void lmpc_solve_problem(
       MS.have1 = uni(pr.have1);
     }
     const bool accepted = uni(pr.accepted) != 0;
+    pol_noise = uni(pr.noise) != 0;
     if (accepted) {
       sigma = uni(pr.sigma);
       mu = uni(pr.mu);
@@ -3577,6 +3594,15 @@ __device__ __forceinline__ void lmpc_solve_problem(
   if (hand_over == 3) break;  // refused after the last iteration: out of iterations it is
   if (hand_over == 2 || !pol::early) {  // refused at the exit: the interior point's own answer stands
     status = LMPC_SOLVE_OPTIMAL;
+    // ... unless the refusal itself says that answer cannot be trusted to the contract (fp64, round 5).  A held set that is
+    // CONSISTENT -- no negative multiplier, no violated row -- whose multiplier steps nevertheless do not settle (last step
+    // above step_tol, or a held row not met to `feas`, after four steps) is a problem whose linear algebra is noisier than
+    // 1e-6: seen at vx < 0.6 m/s with N >= 36, where the RK4 step map's spectral radius is ~25 per stage (DESIGN.md section
+    // 3, "where it has to converge") and the steps bounce at 1e-4.  The interior point's iterate, computed with the same
+    // sweeps, was then 1e-6 .. 2e-3 from the dense optimum with status OPTIMAL (tests/dispatch_sweep.py, one problem of
+    // 1024 at eighteen horizons).  It now says LMPC_SOLVE_MAX_ITER: stopped short of the stated accuracy.  No problem of
+    // the bench distributions takes this branch (twin, 4096 / 1024 problems per family).
+    if (sizeof(real) == 8 && pol_noise) status = LMPC_SOLVE_MAX_ITER;
     break;
   }
   reentry = true;  // refused early: the interior point goes on from the same iterate (same `it`; the rows phase puts its

@@ -25,4 +25,16 @@ TOL_DU = 1e-6
 TOL_MEDIAN = 1e-8
 TOL_TWIN = 1e-6
 TOL_F32 = 1e-3
+# tests/dispatch_sweep.py, the reduced-precision entries away from the BASELINE configurations (every N from 3 to 81, 96 and 160
+# safe-set points, 1024 problems each).  Two measured effects put single problems just past 1e-3 there and nowhere on the
+# BASELINE shapes (N = 40 IAC: worst 8.5e-5 mixed / 4.6e-4 fp32; N = 20 with 160 points: 2.5e-5 -- tests/test_gpu_fullsize.py
+# holds those to TOL_F32 on every problem of the full batch):
+#   * lmpc_solve_batch_f32 has no fp64 pass behind it (its arrays are float): where its polish is refused the interior point's
+#     single-precision answer stands, and that degrades with the horizon -- 1.25e-3 at N = 78, 1.15e-3 at N = 65 (one problem each);
+#   * the fp32 pass of lmpc_solve_batch_mixed VERIFIES an active set to its own tolerances (multipliers >= -3e-5).  With 96 points
+#     at N = 11 .. 18 some problems offer two safe-set points whose multipliers differ by 3e-6 .. 1e-5 -- exchangeable at a cost
+#     difference of 1e-9 -- and the verified answer blends the other one: 1.0 - 1.3e-3 from the fp64 answer on 1 - 2 problems of
+#     1024 (gpurun_out -> profiles/r05_mixed_tail.txt; simplex supports [0 31] against [2 31]).  Tightening the fp32 test to
+#     catch a 3e-6 multiplier would send everything to the fp64 pass.
+TOL_F32_SWEEP = 2e-3
 TOL_LINEARIZE_REL = 1e-11
