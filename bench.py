@@ -42,11 +42,16 @@ def measured_traffic_bytes(pmc_file="r04_pmc.json", kernel="lmpc_solve_kernel<do
         return None
 
 
-def live_traffic_bytes(workload_argv, kernel):
-    """HBM bytes per launch of the QP kernel measured NOW: two rocprofv3 --pmc passes of this same script (FETCH_SIZE and
-    WRITE_SIZE do not fit one pass, MI355X_MICROARCH.md; counters only, no trace domains), --steps 5, one stream, summed
-    from the per-dispatch records of the kernel.  Units and corrections as measured_traffic_bytes.  None when rocprofv3 is
-    missing or a pass fails (the committed passes are reported instead, and `traffic_source` says so)."""
+PMC_PASSES = (("FETCH_SIZE",), ("WRITE_SIZE",),
+              ("SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_INSTS_SALU"),
+              ("SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT"))
+
+
+def live_counters(workload_argv, kernel, passes=PMC_PASSES):
+    """Hardware counters of the QP kernel measured NOW: one rocprofv3 --pmc pass of this same script per counter group (FETCH_SIZE
+    and WRITE_SIZE do not fit one pass, MI355X_MICROARCH.md; counters only, no trace domains), --steps 5, one stream; the average
+    over the kernel's dispatches per counter.  {} when rocprofv3 is missing, this process is itself being profiled, or a pass
+    fails (a failed group is left out, the others are kept)."""
     import shutil
     import signal
     import sqlite3
@@ -54,39 +59,67 @@ def live_traffic_bytes(workload_argv, kernel):
     import tempfile
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
-        return None
+        return {}
     # this process is itself running under a profiler (the driver, or scratch/prof.sh): do not nest a second one
     if any(k in os.environ for k in ("ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB", "ROCPROFILER_LIBRARY_CTOR", "ROCPROF_OUTPUT_PATH")) or \
             "rocprof" in os.environ.get("LD_PRELOAD", ""):
-        return None
-    total = 0.0
+        return {}
+    got = {}
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     env["TMPDIR"] = "/tmp"
     try:
         with tempfile.TemporaryDirectory(dir="/tmp") as d:
-            for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-                out = os.path.join(d, counter)
-                cmd = [exe, "--pmc", counter, "-d", out, "-o", "run", "--", sys.executable, str(ROOT / "bench.py"), "--steps", "5",
-                       "--warmup", "1", "--no-cpu-baseline", "--no-batch1", "--no-others", "--streams", "1", "--no-pmc"] + workload_argv
+            for n, group in enumerate(passes):
+                out = os.path.join(d, "pass%d" % n)
+                cmd = [exe, "--pmc", *group, "-d", out, "-o", "run", "--", sys.executable, str(ROOT / "bench.py"), "--steps", "5",
+                       "--warmup", "1", "--no-cpu-baseline", "--no-batch1", "--no-others", "--no-latency", "--streams", "1", "--no-pmc"] + workload_argv
                 proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
                 try:
                     proc.wait(timeout=90)
                 except subprocess.TimeoutExpired:
                     os.killpg(proc.pid, signal.SIGKILL)  # the exact process group started above
-                    return None
+                    continue
                 dbs = [os.path.join(r, f) for r, _, fs in os.walk(out) for f in fs if f.endswith("_results.db")]
                 if proc.returncode != 0 or not dbs:
-                    return None
+                    continue
                 con = sqlite3.connect(dbs[0])
-                row = con.execute("select avg(value), count(*) from counters_collection where counter_name = ? and kernel_name like ?",
-                                  (counter, "%" + kernel + "%")).fetchone()
+                for counter in group:
+                    row = con.execute("select avg(value), count(*) from counters_collection where counter_name = ? and kernel_name like ?",
+                                      (counter, "%" + kernel + "%")).fetchone()
+                    if row and row[1]:
+                        got[counter] = float(row[0])
                 con.close()
-                if not row or not row[1]:
-                    return None
-                total += float(row[0]) * 1024.0
-        return total
     except Exception:
+        pass
+    return got
+
+
+def live_traffic_bytes(counters):
+    """HBM bytes per launch from FETCH_SIZE + WRITE_SIZE (KiB each; units and corrections as measured_traffic_bytes)."""
+    if "FETCH_SIZE" not in counters or "WRITE_SIZE" not in counters:
         return None
+    return (counters["FETCH_SIZE"] + counters["WRITE_SIZE"]) * 1024.0
+
+
+ENGINE_CLOCK_GHZ = 2.4  # MI355X peak engine clock (MI355X_MICROARCH.md); the busy fractions below are against THAT clock
+
+
+def live_engines(counters, kernel_ms):
+    """What actually bounds the QP kernel, from the counter passes of THIS run (until round 5 the line carried
+    constants read from a committed profile): busy fractions of the VALU (SQ_ACTIVE_INST_VALU is in 4-cycle units summed over
+    waves; one VALU per SIMD, 4 SIMDs x 256 CUs) and of the LDS pipeline (SQ_LDS_IDX_ACTIVE: cycles summed over the 256 CU-local
+    pipelines) over the kernel's duration as measured in this run, instructions per solve (= per wave), and the share of LDS cycles
+    lost to bank conflicts."""
+    need = ("SQ_ACTIVE_INST_VALU", "SQ_LDS_IDX_ACTIVE", "SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_WAVES")
+    if not all(k in counters for k in need) or not counters["SQ_WAVES"]:
+        return None
+    cyc = kernel_ms * 1e-3 * ENGINE_CLOCK_GHZ * 1e9
+    e = {"valu_busy_frac": counters["SQ_ACTIVE_INST_VALU"] * 4.0 / (cyc * 256 * 4), "lds_busy_frac": counters["SQ_LDS_IDX_ACTIVE"] / (cyc * 256),
+         "valu_insts_per_solve": counters["SQ_INSTS_VALU"] / counters["SQ_WAVES"], "lds_insts_per_solve": counters["SQ_INSTS_LDS"] / counters["SQ_WAVES"],
+         "source": "rocprofv3 --pmc passes of this command in this run, against the kernel's %.3f ms at %.1f GHz" % (kernel_ms, ENGINE_CLOCK_GHZ)}
+    if "SQ_LDS_BANK_CONFLICT" in counters and counters["SQ_LDS_IDX_ACTIVE"]:
+        e["lds_bank_conflict_frac"] = counters["SQ_LDS_BANK_CONFLICT"] / counters["SQ_LDS_IDX_ACTIVE"]
+    return e
 
 
 def engine_utilisation(kernel_ms, pmc_file="r04_pmc.json", kernel="lmpc_solve_kernel<double, 4, 0"):
@@ -231,14 +264,18 @@ def other_configs(steps, warmup):
     import subprocess
     legs = [("configs[2]", ["--workload", "lmpc", "--batch", "4096", "--horizon", "20"]),
             ("configs[3], share of one GPU (8192 of 65536)", ["--workload", "iac", "--horizon", "40", "--batch", "8192", "--precision", "f32"]),
-            ("configs[4], share of one GPU (32768 of 262144)", ["--workload", "lmpc", "--batch", "32768", "--horizon", "20", "--precision", "mixed", "--regression"])]
-    keep = ("metric", "value", "unit", "ms_per_step", "ms_per_step_one_stream", "value_one_stream", "dtype", "config", "kernels_ms",
+            ("configs[4], share of one GPU (32768 of 262144)", ["--workload", "lmpc", "--batch", "32768", "--horizon", "20", "--precision", "mixed", "--regression"]),
+            # the friendlier learning workload of rounds 1 - 4 (analytic laps, states near the last lap), reported separately
+            ("configs[2] on the rounds-1-4 workload (states near the laps; not SURVEY 8d's)", ["--workload", "lmpc", "--batch", "4096", "--horizon", "20", "--lmpc-data", "near"]),
+            ("configs[4] share on the rounds-1-4 workload (states near the laps; not SURVEY 8d's)",
+             ["--workload", "lmpc", "--batch", "32768", "--horizon", "20", "--precision", "mixed", "--regression", "--lmpc-data", "near"])]
+    keep = ("metric", "value", "unit", "ms_per_step", "ms_per_step_one_stream", "value_one_stream", "timed_steps", "timed_window_s", "dtype", "config", "kernels_ms",
             "solved_fraction", "mean_ipm_iters", "p50_solve_ms", "p99_solve_ms", "ss_query_kernel")
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     out = []
     for name, argv in legs:
         cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", "1", "--steps", str(max(5, min(steps, 20))), "--warmup", str(max(1, min(warmup, 3))),
-               "--no-cpu-baseline", "--no-pmc", "--no-batch1", "--no-others"] + argv
+               "--no-cpu-baseline", "--no-pmc", "--no-batch1", "--no-others", "--min-window", "0.3"] + argv
         try:
             r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
             line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
@@ -278,6 +315,12 @@ def main():
     ap.add_argument("--regression", action="store_true", help="--workload lmpc only: switch the error-dynamics regression on "
                     "(safe_set.cpp:182-245; BASELINE configs[4]: 'LMPC + error-dynamics residual term') -- 2200 recorded sample pairs "
                     "from a plant with 15 %% less grip, every stage of every problem regressed before its QP")
+    ap.add_argument("--lmpc-data", choices=["spec", "near"], default="spec",
+                    help="--workload lmpc: spec (default) = SURVEY.md 8d config 3 as written: the five laps are produced by the tracking "
+                         "loop at speed scales 0.80 .. 1.0 (closed_loop.record_laps) and the 4096 queries are config 2's random x0; "
+                         "near = the friendlier workload of rounds 1 - 4 (analytic laps, states drawn near the last lap), kept for continuity")
+    ap.add_argument("--min-window", type=float, default=0.5, help="the timed region repeats the --steps block until it spans at least this "
+                    "many seconds AND at least 200 steps (VERDICT r4 item 9a: 20 steps of 0.7 ms are a 15 ms window); 0 = exactly --steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="do not run the two rocprofv3 --pmc passes that measure the QP kernel's HBM "
                     "traffic (N = 1 only, ~30 s); roofline.traffic then comes from the committed passes in profiles/")
@@ -347,7 +390,13 @@ def main():
     tr = pkg.workloads.synthetic_track("putnam" if iac else "barc")
     if lmpc:
         cfgd = pkg.presets.barc_lmpc(N, 5)  # 5 laps stored, 32 per lap -> 160 points
-        laps = pkg.workloads.synthetic_laps(tr, 5)
+        if args.lmpc_data == "spec":
+            # "produced by running config 1's tracking loop for 5 laps with seed-indexed speed scales {0.80 .. 1.0}", 0.03 s samples
+            trk_sv = pkg.Solver(pkg.presets.barc_tracking_mpc(20), pkg.presets.barc_vehicle(), device=local)
+            laps = pkg.closed_loop.record_laps(trk_sv, tr)
+            trk_sv.close()
+        else:
+            laps = pkg.workloads.synthetic_laps(tr, 5)
 
         reg_laps = []
         if args.regression:
@@ -368,7 +417,10 @@ def main():
                 sv.set_regression_laps(reg_laps, dist_max=0.6)
             return sv
         solver = make_solver()
-        x, u = pkg.workloads.sample_states_near_laps(laps, B, tr["L"], seed=rank)
+        if args.lmpc_data == "spec":   # "batch=4096 queries as config 2": config 2's random x0 (vx inside this controller's box)
+            x, u = pkg.workloads.sample_initial_states("barc", B, tr["L"], [-0.01, -0.314159], [0.01, 0.314159], seed=rank)
+        else:
+            x, u = pkg.workloads.sample_states_near_laps(laps, B, tr["L"], seed=rank)
     elif iac:
         def make_solver():
             return pkg.Solver(pkg.presets.iac_tracking_mpc(N), pkg.presets.iac_vehicle(), device=local)
@@ -475,11 +527,26 @@ def main():
     for k in range(args.warmup):
         step(k)
     drain()
+    # How many times the --steps block is repeated inside the timed region: at least 200 steps and --min-window seconds, from a
+    # short untimed probe of the pipeline's pace (rank 0 decides for everybody: the steps are collectives when gathering)
+    repeats = 1
+    if args.min_window > 0:
+        tp = time.perf_counter()
+        for k in range(max(S, 4)):
+            step(k)
+        drain()
+        est = (time.perf_counter() - tp) / max(S, 4)
+        repeats = max(1, -(-max(200, int(args.min_window / max(est, 1e-6)) + 1) // args.steps))
+        if world > 1:
+            box = [repeats]
+            dist.broadcast_object_list(box, src=0)
+            repeats = int(box[0])
+    timed_steps = args.steps * repeats
     if world > 1:
         dist.barrier()
         torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for k in range(args.steps):
+    for k in range(timed_steps):
         step(k)
     drain()
     if world > 1:
@@ -494,10 +561,10 @@ def main():
         solve_step(0)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        for k in range(args.steps):
+        for k in range(timed_steps):
             solve_step(k)
         torch.cuda.synchronize()
-        one_stream_value = B * args.steps / (time.perf_counter() - t1)
+        one_stream_value = B * timed_steps / (time.perf_counter() - t1)
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if shared_gpu else dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -508,7 +575,7 @@ def main():
     if rank == 0:
         solver.enable_timing(True)
         # p99 over >= 1000 timed calls (bounded to ~3 s of GPU time for the big batches)
-        n_lat = 20 if args.no_latency else int(max(100, min(1000, 3.0 / max(elapsed / args.steps, 1e-4))))
+        n_lat = 20 if args.no_latency else int(max(100, min(1000, 3.0 / max(elapsed / timed_steps, 1e-4))))
         for k in range(n_lat):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -550,11 +617,11 @@ def main():
 
     gathered = None
     if gather and rank == 0:  # what rank 0 holds after the last gather: every rank's results and statuses
-        full = unpack_results(gbuf[(args.steps - 1) % S], world, N, B)
+        full = unpack_results(gbuf[(timed_steps - 1) % S], world, N, B)
         gathered = {"problems": int(full["status"].numel()), "solved_fraction": float((full["status"] == 0).float().mean()),
                     "mean_iters": float(full["iters"].float().mean())}
     if rank == 0:
-        value = world * B * args.steps / elapsed
+        value = world * B * timed_steps / elapsed
         sol_avg = float(np.mean(sol_ms))
         algo_bytes = ((13 * N + 5) + (10 * N - 4)) * (4 if f32 else 8) + 8
         if lmpc:
@@ -563,22 +630,32 @@ def main():
         # committed PMC passes of this command: tracking, or the learning problem with 160 safe-set points
         pmc_sel = ("r04_pmc_lmpc.json", "lmpc_solve_kernel<double, 4, 3") if lmpc else ("r04_pmc.json", "lmpc_solve_kernel<double, 4, 0")
         pmc_shape = not (N != 20 or B != 4096 or iac or f32 or mixed)  # the shape the committed passes were taken on
-        traffic, traffic_source = None, None
+        traffic, traffic_source, counters = None, None, {}
         if world == 1 and not args.no_pmc:
-            wl_argv = ["--batch", str(B), "--horizon", str(N), "--workload", args.workload, "--precision", args.precision]
+            wl_argv = ["--batch", str(B), "--horizon", str(N), "--workload", args.workload, "--precision", args.precision, "--lmpc-data", args.lmpc_data]
+            if args.regression:
+                wl_argv.append("--regression")
             kname = "lmpc_solve_kernel<%s, " % ("float" if (f32 or mixed) else "double")
-            traffic = live_traffic_bytes(wl_argv, kname)
+            counters = live_counters(wl_argv, kname)
+            traffic = live_traffic_bytes(counters)
             traffic_source = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, two passes of this command at --steps 5, measured in this run"
         if traffic is None and pmc_shape:
             traffic = measured_traffic_bytes(*pmc_sel)
             traffic_source = "profiles/%s (committed rocprofv3 --pmc passes of this command)" % pmc_sel[0]
+        engines = live_engines(counters, sol_avg)
+        if engines is None and pmc_shape:
+            engines = engine_utilisation(sol_avg, *pmc_sel)
         res = {
             "metric": "QP solves/sec (nx=6,nu=2,N=%d)" % N, "value": value, "unit": "solves/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / timed_steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            # the timed region: `steps` x `timed_repeats` steps back to back (>= 200 steps and >= --min-window seconds)
+            "timed_steps": timed_steps, "timed_repeats": repeats, "timed_window_s": elapsed,
             "vs_baseline": None, "dtype": "f32" if f32 else ("f32 iteration, f64 arrays" if mixed else "f64"), "data": "synthetic",
             "config": {"workload": ("BARC LMPC with 5-lap safe set (160 points), batch=%d per GPU, N=%d, fp64: safe-set kNN kernel + "
-                                    "QP kernel per step (BASELINE configs[2])" if lmpc else
+                                    "QP kernel per step (BASELINE configs[2])" + (": laps from the tracking loop at speed scales 0.80 .. 1.0, queries = "
+                                    "configs[1]'s random x0 (SURVEY.md 8d config 3)" if args.lmpc_data == "spec" else ": analytic laps, states drawn near the last "
+                                    "lap (the workload of rounds 1 - 4; NOT SURVEY.md 8d's)") if lmpc else
                                     ("IAC Putnam tracking MPC, batch=%d per GPU, N=%d, fp32 (BASELINE configs[3])" if f32 else
                                      "IAC Putnam tracking MPC, batch=%d per GPU, N=%d, fp64 (problem of BASELINE configs[3])") if iac else
                                     "BARC tracking MPC, batch=%d random x0 per GPU, N=%d, fp64 (BASELINE configs[1])") % (B, N)
@@ -593,7 +670,7 @@ def main():
             "latency_samples": len(lat), "value_one_stream": one_stream_value,
             # one batch at a time: the figure that reconciles with kernels_ms and the rocprofv3 summaries (the headline
             # ms_per_step overlaps consecutive batches on `streams` HIP streams, so it can sit below one kernel's duration)
-            "ms_per_step_one_stream": (B / one_stream_value * 1e3) if one_stream_value else elapsed / args.steps * 1e3,
+            "ms_per_step_one_stream": (B / one_stream_value * 1e3) if one_stream_value else elapsed / timed_steps * 1e3,
             "batch1_solve_ms": {"p50": float(np.percentile(lat1, 50)), "p99": float(np.percentile(lat1, 99)), "control_period_ms": 25.0} if lat1 else None,
             "solved_fraction": float((st == 0).mean()), "mean_ipm_iters": float(iters.mean()),  # (interior-point iterations + polish rounds)
             "kernels_ms": {"linearize": float(np.mean(lin_ms)), "qp_solve": sol_avg,
@@ -602,10 +679,13 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_source,
+                         # counter bytes against algorithmic bytes per launch: what the kernel moves beyond what the problem needs
+                         # (spill traffic, the linearisation workspace read back) -- VERDICT r4 item 7
+                         "traffic_over_algorithmic": (traffic / (algo_bytes * B)) if traffic else None,
                          "algorithmic_bytes_per_solve": algo_bytes,
                          "note": "algorithmic bytes x batch / lmpc_solve_kernel time; the kernel is "
                                  "FP64-VALU issue / LDS-pipeline bound (DESIGN.md), HBM fraction is reported as required",
-                         "engines": engine_utilisation(sol_avg, *pmc_sel) if pmc_shape else None},
+                         "engines": engines},
         }
         if ss_ms:
             # safe-set query kernel: per query 2 doubles in, 7 S doubles out (ss_x [6][S], ss_j [S]); the lap store

@@ -96,6 +96,34 @@ def run(solver, track: dict, x0, u0, steps: int, dt: float = 0.025, n_sub: int =
     return {"x": x, "distance": dist, "worst_excess": worst_excess, "n_fail": n_fail, "trace": trace}
 
 
+def record_laps(solver, track: dict, speed_scales=(0.80, 0.85, 0.90, 0.95, 1.0), dt: float = 0.03, n_sub: int = 3):
+    """The laps SURVEY.md 8d config 3 stores in the safe set: "running config 1's tracking loop for 5 laps with seed-indexed speed
+    scales {0.80, 0.85, 0.90, 0.95, 1.0}", one sample per 0.03 s (the recorder's period upstream, racing_mpc_node.cpp:66).  One
+    car per scale from the start line at the profile's speed, driven by `solver` (a tracking handle) until it has covered one lap;
+    the samples of that lap are returned as host arrays [n][6], oldest (slowest) first -- what SafeSetRecorder would have written."""
+    import numpy as np
+    import torch
+
+    L, M = float(track["L"]), int(track["M"])
+    laps = []
+    for sc in speed_scales:
+        v0 = max(float(np.asarray(track["vel"])[0]) * sc, 0.5)
+        x0 = torch.tensor([[0.0], [0.0], [0.0], [v0], [0.0], [0.0]], dtype=torch.float64, device=solver.device)
+        u0 = torch.zeros((2, 1), dtype=torch.float64, device=solver.device)
+        v_min = max(float(np.asarray(track["vel"]).min()) * sc * 0.8, 0.4)
+        steps = int(1.25 * L / (v_min * dt)) + 8
+        r = run(solver, track, x0, u0, steps=steps, dt=dt, n_sub=n_sub, speed_scale=sc, record_every=1)
+        xs = np.stack([x0.cpu().numpy()[:, 0]] + [t.cpu().numpy()[:, 0] for t in r["trace"]])     # [steps + 1][6], abscissa wrapped
+        ds = np.diff(xs[:, 0])
+        ds = np.where(ds < -L / 2, ds + L, ds)
+        travelled = np.concatenate([[0.0], np.cumsum(ds)])
+        n = int(np.searchsorted(travelled, L))       # first sample past the line: the lap is samples 0 .. n-1
+        if n >= xs.shape[0]:
+            raise RuntimeError("record_laps: the car at speed scale %.2f did not complete a lap in %d periods" % (sc, steps))
+        laps.append(xs[:n].copy())
+    return laps
+
+
 def run_lmpc(tracker, learner, track: dict, x0, u0, warm_laps: int = 2, learn_laps: int = 4, dt: float = 0.025,
              n_sub: int = 2, warm_speed_scale: float = 0.7, max_steps: int = 20000, debug: bool = False):
     """The LMPC experiment of the reference (sim_barc_lmpc): `warm_laps` laps under the tracking MPC fill the safe

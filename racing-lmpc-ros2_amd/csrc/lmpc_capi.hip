@@ -169,13 +169,9 @@ const void* pick_mixed_fn(int kq, int ks) {
   // fp32 kernel at one wave per SIMD) it ran 0.80 M solves/s against 0.70 M in fp64 with 13 % of the batch going to the
   // second pass, and one problem of 4096 passed its single-precision KKT test 3.6e-3 away from the fp64 answer -- outside
   // the 1e-3 this entry states, for a 1.14x gain
-#ifdef LMPC_MIXED_LONG_LEARNING
-  if (ks == 2) return kq <= 4 ? solve_fn<4, 2, float>() : kq == 7 ? solve_fn<7, 2, float>() : kq == 11 ? solve_fn<11, 2, float>() : nullptr;
-  if (ks == 3) return kq <= 4 ? solve_fn<4, 3, float>() : kq == 7 ? solve_fn<7, 3, float>() : kq == 11 ? solve_fn<11, 3, float>() : nullptr;
-#else
+  // (the N = 40 / 60 instantiations of that experiment, -DLMPC_MIXED_LONG_LEARNING until round 5: scratch/r5/experiment_switches.patch)
   if (ks == 2) return kq <= 4 ? solve_fn<4, 2, float>() : nullptr;
   if (ks == 3) return kq <= 4 ? solve_fn<4, 3, float>() : nullptr;
-#endif
   switch (kq) {
     case 2:
     case 4: return solve_fn<4, 0, float>();
@@ -200,12 +196,6 @@ const void* pick_f32_fn(int kq) {
 
 // the fp64 second pass of a mixed solve, for the (KQ, KS) the mixed kernels exist for
 const void* pick_cleanup_fn(int kq, int ks) {
-#ifdef LMPC_MIXED_LONG_LEARNING
-  if (ks == 2 && kq == 7) return reinterpret_cast<const void*>(&lmpc_cleanup_kernel<double, 7, 2, double>);
-  if (ks == 3 && kq == 7) return reinterpret_cast<const void*>(&lmpc_cleanup_kernel<double, 7, 3, double>);
-  if (ks == 2 && kq == 11) return reinterpret_cast<const void*>(&lmpc_cleanup_kernel<double, 11, 2, double>);
-  if (ks == 3 && kq == 11) return reinterpret_cast<const void*>(&lmpc_cleanup_kernel<double, 11, 3, double>);
-#endif
   if (ks == 2) return kq <= 4 ? reinterpret_cast<const void*>(&lmpc_cleanup_kernel<double, 4, 2, double>) : nullptr;
   if (ks == 3) return kq <= 4 ? reinterpret_cast<const void*>(&lmpc_cleanup_kernel<double, 4, 3, double>) : nullptr;
   switch (kq) {
@@ -226,7 +216,6 @@ int launch_cleanup(lmpc_handle* h, const void* fn, const solve_args& a) {
   P.launch_order = nullptr;
   P.flag_unverified = 0;
   P.out_aos = a.aos ? 1 : 0;
-  P.dbg_lds_bytes = (int)a.lds_bytes;
   int B = a.B;
   const double* ws = h->ws;
   const int* list = h->unverified;

@@ -37,7 +37,7 @@ struct lmpc_params {
   int flag_unverified;
   int hard_hull;  // all-zero convex_hull_slack: chs2 = 2 LMPC_HARD_HULL_WEIGHT and the residual is checked at the exit
   int out_aos;  // lmpc_set_output_layout: results [batch][knot][component] instead of [component][knot][batch]
-  int dbg_lds_bytes;  // (measurement builds: the workgroup's dynamic LDS size, for the LDS-clearing variant of the second pass)
+  int reserved_;  // (keeps the block's layout)
   lmpc_vehicle veh;
 };
 

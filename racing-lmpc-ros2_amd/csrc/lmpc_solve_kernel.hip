@@ -42,9 +42,6 @@
 #define OCCF 3
 #endif
 #define NSLOT 11
-#ifndef LMPC_POLISH_BUILD  // (0: the polish compiled out -- A/B timing of what its presence costs the interior point's loop)
-#define LMPC_POLISH_BUILD 1
-#endif
 // resident waves per SIMD the register allocation is sized for: the fp64 tracking kernels up to N = 23 and every fp32
 // kernel up to N = 40 run two (three for fp32, N <= 23); the fp64 LMPC and long-horizon kernels need the full file
 constexpr int lmpc_waves_per_simd(int real_bytes, int kq, int ks) {
@@ -158,11 +155,7 @@ __device__ __forceinline__ void wave_fence() {
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-#ifdef LMPC_PLAIN_SYNC  // (A/B timing only: the unfenced exchange point of rounds 1-2)
-__device__ __forceinline__ void wave_sync() { __builtin_amdgcn_wave_barrier(); }
-#else
 __device__ __forceinline__ void wave_sync() { wave_fence(); }
-#endif
 
 // A value that is the same in every lane, moved to scalar registers (v_readfirstlane): the solver's
 // wave-wide scalars (mu, step lengths, sigma, ...) then cost no vector registers while they are carried
@@ -825,9 +818,6 @@ struct Lds {
 #define LN_DT 19
 #define LN_KFF(s) ((s) ? 22 : 20)
 constexpr bool lmpc_lean(int real_bytes, int kq) { return real_bytes == 8 && kq >= 11; }
-#ifndef LMPC_FETCH_FRESH
-#define LMPC_FETCH_FRESH 1
-#endif
 template <typename real>
 struct ModelStream {
   const real* ws;  // this problem's [N - 1][LN_REC] in the workspace (HBM / L2)
@@ -851,11 +841,9 @@ struct ModelStream {
     real* const dst = buf + (ch & 1) * LN_CHUNK * LN_REC;
     // (the per-lane source address from a lane number the optimiser cannot see through: hoisted out of the sweeps as the loop
     //  invariant it is, the 64-bit address was spilled, and each of the four copies below then waited -- vmcnt(0): for its own
-    //  reload AND the copy before it -- four memory round trips in a row per chunk; LMPC_FETCH_FRESH)
+    //  reload AND the copy before it -- four memory round trips in a row per chunk)
     int fl = lane;
-#if LMPC_FETCH_FRESH
     asm volatile("" : "+v"(fl));
-#endif
     const real* const src = ws + lo + 2 * fl;
     const int e = 2 * fl;
     static_assert(sizeof(real) == 8 && (LN_CHUNK * LN_REC + 127) / 128 == 4, "four 1 KB slices per chunk");
@@ -893,12 +881,9 @@ __device__ __forceinline__ real qz_entry(const real* ct, bool terminal, int r, i
 // with (s_setprio): the chain's next instruction is the one a solve waits for, the row phases are throughput work that fills in.
 // Two-waves-per-SIMD kernels only (alone on its SIMD a wave has nobody to yield to: +0.5 %): headline kernel -1.5 %, pipelined
 // +1.4 %, one batch at a time -1.9 %, the mixed learning kernel -1.1 %; same bits (profiles/r04_row_phases.md).
-#ifndef LMPC_CHAIN_PRIO
 #define LMPC_CHAIN_PRIO 3
-#endif
-#ifndef LMPC_TERM_PRIO  // (the learning problem's terminal elimination, another serial chain: measured, see the profile)
-#define LMPC_TERM_PRIO 0
-#endif
+// (the learning problem's terminal elimination is another serial chain; raising its priority the same way was measured in round 4 and
+//  bought nothing: profiles/r04_row_phases.md)
 #define CHAIN_PRIO_ENTER() do { if (LMPC_CHAIN_PRIO && L.chain_prio) __builtin_amdgcn_s_setprio(LMPC_CHAIN_PRIO); } while (0)
 #define CHAIN_PRIO_LEAVE() do { if (LMPC_CHAIN_PRIO && L.chain_prio) __builtin_amdgcn_s_setprio(0); } while (0)
 // ... and the other way round: value x is complete before any later memory operation is issued (an
@@ -910,11 +895,9 @@ __device__ __forceinline__ real qz_entry(const real* ct, bool terminal, int r, i
 // of once at the top of the kernel and kept alive over the whole iteration, which at the register limit means spilled and
 // reloaded from scratch (or from VGPR lanes, for the predicates) inside the sweep's preamble, one wait per reload.  Per
 // instantiation (Lds::fresh, lmpc_fresh_lane below): what it does to the register allocation of a 3000-line kernel is not
-// monotone, and it is kept only where it was measured to pay.  (LMPC_FRESH_MASK: one bit per sweep function, for bisecting.)
-#ifndef LMPC_FRESH_MASK
-#define LMPC_FRESH_MASK 0x7f
-#endif
-#define FRESH_LANE(l, site) do { if (L.fresh && ((LMPC_FRESH_MASK >> (site)) & 1)) asm volatile("" : "+v"(l)); } while (0)
+// monotone, and it is kept only where it was measured to pay.  (`site` numbers the sweep functions: round 4 bisected a miscompute
+// with a per-site mask, profiles/r04_d70_bisect.md.)
+#define FRESH_LANE(l, site) do { if (L.fresh) asm volatile("" : "+v"(l)); } while (0)
 
 // Backward Riccati sweep for the barrier weights currently in the knots' rhs0 region
 // (Thz @ +10..17, Thv @ +18,19, boundary weight @ KN_EY).  Leaves K (columns 6,7 of M) and Hinv in
@@ -1237,121 +1220,6 @@ __device__ __forceinline__ void riccati_solve(const Lds<real>& L, int lane, Prof
   PT_MARK(10 + NRHS - 1)
 }
 
-// The same solve with the running vector exchanged through LDS (what riccati_solve did until round 2): the form the
-// one-wave-per-SIMD instantiations keep (see the call site).
-template <int NRHS, typename real>
-__device__ __forceinline__ void riccati_solve_lds(const Lds<real>& L, int lane, Prof& pf) {
-  FRESH_LANE(lane, 3);
-  const int N = L.N;
-  const int r = lane & 7, s = (lane >> 3) & (NRHS - 1);
-  const bool own = lane < 8 * NRHS;
-  const int reg = KN_R0 + 10 * s;
-  real* T = L.tail();
-  real* const junk0 = T + TL_W + lane;  // 64 + 64 dead cells: W (80) and Y (80) are contiguous
-  real* const junk1 = T + TL_W + 80 + lane;
-  real* const pvec = T + TL_PV + 8 * s;
-  real* const pdst = own ? pvec + r : junk0;
-  auto spread2 = [&](real v, real& a, real& b) {  // values of lanes (s, 6) and (s, 7) to the whole group
-    if constexpr (NRHS == 2) {
-      a = group_bcast<0x00D8>(v);
-      b = group_bcast<0x00F8>(v);
-    } else {
-      a = lane_bcast(v, 6);
-      b = lane_bcast(v, 7);
-    }
-  };
-  // ---- backward: p_i = q_i + Abar' p_{i+1} - K' (q_v + Bbar' p_{i+1});  kff_i = H^-1 (q_v + Bbar' p_{i+1})
-  real p = L.kn(N - 1)[reg + r];
-  *pdst = p;
-  real row[6];  // [A B](:, r), fetched one stage ahead
-  {
-    const real* st = L.st(N - 2);
-#pragma unroll
-    for (int k = 0; k < 6; ++k) row[k] = st[ST_ROW(r) + k];
-  }
-  wave_sync();
-  for (int i = N - 2; i >= 0; --i) {
-    real* st = L.st(i);
-    const real* kn = L.kn(i);
-    real pb[6];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) pb[k] = pvec[k];
-    ISSUE_ORDER();
-    // what the stage needs after the product, queued behind the costate
-    const real k0r = st[ST_ROW(r) + 6], k1r = st[ST_ROW(r) + 7], t = st[ST_DT];
-    const real qz = kn[reg + r], qv0 = kn[reg + 8], qv1 = kn[reg + 9];
-    const real hi00 = st[ST_HI], hi01 = st[ST_HI + 1], hi11 = st[ST_HI11];
-    ISSUE_ORDER();
-    real w = (r >= 6) ? p : 0.0;  // w = Abar' p: rows 6,7 also take p_u
-#pragma unroll
-    for (int k = 0; k < 6; ++k) w = rfma(row[k], pb[k], w);
-    AFTER_VALUE(w);
-    real w6, w7;
-    spread2(w, w6, w7);
-    ISSUE_ORDER();
-    {
-      const real* stn = L.st(i > 0 ? i - 1 : 0);
-#pragma unroll
-      for (int k = 0; k < 6; ++k) row[k] = stn[ST_ROW(r) + k];
-    }
-    ISSUE_ORDER();
-    const real hv0 = rfma(t, w6, qv0);
-    const real hv1 = rfma(t, w7, qv1);
-    p = qz + w - (k0r * hv0 + k1r * hv1);  // (not used after stage 0)
-    *pdst = p;
-    const real kff = (r == 0) ? hi00 * hv0 + hi01 * hv1 : hi01 * hv0 + hi11 * hv1;
-    *((own && r < 2) ? st + ST_KFF(s) + r : junk1) = kff;
-    wave_sync();
-  }
-  PT_MARK(8 + NRHS - 1)
-  // ---- forward: dv_i = -kff_i - K dz_i,  dz_{i+1} = Abar dz_i + Bbar dv_i
-  // lanes r < 6 take a state row, lanes 6, 7 the two rows of K: column k of M is [A B](:, k) | K(:, k)
-  *(own ? L.kn(0) + reg + r : junk0) = 0.0;
-  real col[8], a0;  // M(r, :) and the feed-forward term, fetched one stage ahead
-  {
-    const real* st = L.st(0);
-#pragma unroll
-    for (int k = 0; k < 8; ++k) col[k] = st[ST_ROW(k) + r];
-    a0 = st[ST_KFF(s) + (r & 1)];
-  }
-  wave_sync();
-  for (int i = 0; i < N - 1; ++i) {
-    const real* st = L.st(i);
-    real* kn = L.kn(i);
-    real dz[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) dz[k] = kn[reg + k];
-    ISSUE_ORDER();
-    const real b0 = st[ST_ROW(6) + r], b1 = st[ST_ROW(7) + r], t = st[ST_DT];
-    ISSUE_ORDER();
-    real acc = (r >= 6) ? a0 : 0.0;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) acc = rfma(col[k], dz[k], acc);
-    const real ax = acc;  // state rows: A dz_x
-    acc = rfma(col[6], dz[6], acc);
-    acc = rfma(col[7], dz[7], acc);
-    AFTER_VALUE(acc);
-    const real dv = -acc;  // lanes 6, 7
-    const real du = rfma(t, dv, (r == 6) ? dz[6] : dz[7]);
-    real du0, du1;
-    spread2(du, du0, du1);
-    ISSUE_ORDER();
-    {
-      const real* stn = L.st(i < N - 2 ? i + 1 : i);
-#pragma unroll
-      for (int k = 0; k < 8; ++k) col[k] = stn[ST_ROW(k) + r];
-      a0 = stn[ST_KFF(s) + (r & 1)];
-    }
-    ISSUE_ORDER();
-    const real nx = rfma(b1, du1, rfma(b0, du0, ax));
-    const real d = (r < 6) ? nx : du;
-    *(own ? kn + LMPC_KNOT_STRIDE + reg + r : junk0) = d;
-    *((own && r >= 6) ? kn + reg + 2 + r : junk1) = dv;
-    wave_sync();
-  }
-  PT_MARK(10 + NRHS - 1)
-}
-
 // Closed-loop rollout z_{i+1} = Abar z_i + Bbar v_i + gbar, v_i = -K_i z_i (absolute variables).
 // The linearised model can be open-loop unstable (|eig A| > 1 at low speed with dt = 25 ms), so
 // the start trajectory is generated under the stabilising Riccati feedback.  Same lane roles as the
@@ -1566,148 +1434,10 @@ __device__ __forceinline__ void riccati_factor_lean(const Lds<real>& L, ModelStr
   }
 }
 
-template <int NRHS, typename real>
-__device__ __forceinline__ void riccati_solve_lean(const Lds<real>& L, ModelStream<real>& M, int lane, Prof& pf) {
-  FRESH_LANE(lane, 5);
-  const int N = L.N;
-  const int r = lane & 7, s = (lane >> 3) & (NRHS - 1);
-  const bool own = lane < 8 * NRHS;
-  const int reg = KN_R0 + 10 * s;
-  real* T = L.tail();
-  real* const junk0 = T + TL_W + lane;
-  real* const junk1 = T + TL_W + 80 + lane;
-  real* const pvec = T + TL_PV + 8 * s;
-  real* const pdst = own ? pvec + r : junk0;
-  auto spread2 = [&](real v, real& a, real& b) {
-    if constexpr (NRHS == 2) {
-      a = group_bcast<0x00D8>(v);
-      b = group_bcast<0x00F8>(v);
-    } else {
-      a = lane_bcast(v, 6);
-      b = lane_bcast(v, 7);
-    }
-  };
-  // ---- backward
-  {
-    const int ch = (N - 2) / LN_CHUNK;
-    M.ensure(ch);
-    M.wait();
-    if (ch > 0) M.ensure(ch - 1);
-  }
-  real p = L.kn(N - 1)[reg + r];
-  *pdst = p;
-  real row[6];
-  {
-    const real* ab = M.stage(N - 2);
-#pragma unroll
-    for (int k = 0; k < 6; ++k) row[k] = ab[6 * r + k];
-  }
-  wave_sync();
-  for (int i = N - 2; i >= 0; --i) {
-    real* st = L.st(i);
-    const real* kn = L.kn(i);
-    // a chunk's last stage looks ahead into the next chunk: wait for it (fetched a chunk ago) and start the copy of the
-    // one after it into the buffer this stage no longer reads (its own operands are in registers since the stage before).
-    // At the TOP of the body, where the loop header is a block boundary anyway: a branch in mid-stage makes the compiler
-    // drain every LDS read in flight there, and the look-ahead loses its overlap.
-    if ((i % LN_CHUNK) == 0 && i > 0) {
-      M.wait();
-      if (i / LN_CHUNK >= 2) M.fetch(i / LN_CHUNK - 2);
-    }
-    real pb[6];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) pb[k] = pvec[k];
-    ISSUE_ORDER();
-    const real k0r = st[2 * r], k1r = st[2 * r + 1], t = st[LN_DT];
-    const real qz = kn[reg + r], qv0 = kn[reg + 8], qv1 = kn[reg + 9];
-    const real hi00 = st[LN_HI], hi01 = st[LN_HI + 1], hi11 = st[LN_HI11];
-    ISSUE_ORDER();
-    real w = (r >= 6) ? p : 0.0;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) w = rfma(row[k], pb[k], w);
-    AFTER_VALUE(w);
-    real w6, w7;
-    spread2(w, w6, w7);
-    ISSUE_ORDER();
-    {
-      const real* abn = M.stage(i > 0 ? i - 1 : 0);
-#pragma unroll
-      for (int k = 0; k < 6; ++k) row[k] = abn[6 * r + k];
-    }
-    ISSUE_ORDER();
-    const real hv0 = rfma(t, w6, qv0);
-    const real hv1 = rfma(t, w7, qv1);
-    p = qz + w - (k0r * hv0 + k1r * hv1);
-    *pdst = p;
-    const real kff = (r == 0) ? hi00 * hv0 + hi01 * hv1 : hi01 * hv0 + hi11 * hv1;
-    *((own && r < 2) ? st + LN_KFF(s) + r : junk1) = kff;
-    wave_sync();
-  }
-  PT_MARK(8 + NRHS - 1)
-  // ---- forward: lanes r < 6 take a state row of [A B] (column reads of the chunk slot, stride 6), lanes 6, 7 a row of K
-  // (chunks 0 and 1 are what the backward sweep has left in the two buffers: no fetch, no wait)
-  const int nch = (N - 2) / LN_CHUNK + 1;
-  M.ensure(0);
-  *(own ? L.kn(0) + reg + r : junk0) = 0.0;
-  M.wait();
-  if (nch > 1) M.ensure(1);
-  const int cb = r < 6 ? r : 0;  // (lanes 6, 7: the model operands are not used)
-  const int cstride = r < 6 ? 6 : 2;
-  real col[8], a0, b0n, b1n;
-  auto load_stage = [&](int i) {
-    const real* ab = M.stage(i);
-    const real* st = L.st(i);
-    {  // one base and one stride per lane (state rows: the chunk slot, stride 6; rows of K: the stage record, stride 2)
-      const real* const cbase = r < 6 ? ab + cb : st + (r - 6);
-#pragma unroll
-      for (int k = 0; k < 8; ++k) col[k] = cbase[k * cstride];
-    }
-    a0 = st[LN_KFF(s) + (r & 1)];
-    b0n = ab[36 + cb];
-    b1n = ab[42 + cb];
-  };
-  load_stage(0);
-  wave_sync();
-  for (int i = 0; i < N - 1; ++i) {
-    const real* st = L.st(i);
-    real* kn = L.kn(i);
-    if ((i % LN_CHUNK) == LN_CHUNK - 1 && i < N - 2) {  // (see the backward sweep)
-      M.wait();
-      if (i / LN_CHUNK + 2 < nch) M.fetch(i / LN_CHUNK + 2);
-    }
-    real dz[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) dz[k] = kn[reg + k];
-    ISSUE_ORDER();
-    const real b0 = b0n, b1 = b1n, t = st[LN_DT];
-    ISSUE_ORDER();
-    real acc = (r >= 6) ? a0 : 0.0;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) acc = rfma(col[k], dz[k], acc);
-    const real ax = acc;
-    acc = rfma(col[6], dz[6], acc);
-    acc = rfma(col[7], dz[7], acc);
-    AFTER_VALUE(acc);
-    const real dv = -acc;
-    const real du = rfma(t, dv, (r == 6) ? dz[6] : dz[7]);
-    real du0, du1;
-    spread2(du, du0, du1);
-    ISSUE_ORDER();
-    load_stage(i < N - 2 ? i + 1 : i);
-    ISSUE_ORDER();
-    const real nx = rfma(b1, du1, rfma(b0, du0, ax));
-    const real d = (r < 6) ? nx : du;
-    *(own ? kn + LMPC_KNOT_STRIDE + reg + r : junk0) = d;
-    *((own && r >= 6) ? kn + reg + 2 + r : junk1) = dv;
-    wave_sync();
-  }
-  PT_MARK(10 + NRHS - 1)
-}
-
 // The lean vector solve with the running vector in registers (DPP row broadcasts, as riccati_solve) instead of one LDS round
 // trip per stage: at one wave per SIMD a sweep stage costs what its instruction count costs (~4.5 cycles each, nothing to
-// overlap with), and the exchange through LDS is a third of the lean stage's instructions.  Same arithmetic per output as
-// riccati_solve_lean (bit for bit); lane (s, r) = ((lane >> 4) % NRHS, lane & 7), lanes 8..15 of a row mirror 0..7.
+// overlap with), and the exchange through LDS was a third of the lean stage's instructions (the LDS-exchange form of rounds 2-3,
+// bit for bit the same results, is scratch/r5/experiment_switches.patch); lane (s, r) = ((lane >> 4) % NRHS, lane & 7), lanes 8..15 of a row mirror 0..7.
 template <int NRHS, typename real>
 __device__ __forceinline__ void riccati_solve_lean_dpp(const Lds<real>& L, ModelStream<real>& M, int lane, Prof& pf) {
   FRESH_LANE(lane, 5);
@@ -1737,7 +1467,7 @@ __device__ __forceinline__ void riccati_solve_lean_dpp(const Lds<real>& L, Model
   for (int i = N - 2; i >= 0; --i) {
     real* st = L.st(i);
     const real* kn = L.kn(i);
-    if ((i % LN_CHUNK) == 0 && i > 0) {  // (see riccati_solve_lean)
+    if ((i % LN_CHUNK) == 0 && i > 0) {  // (chunk boundary: the next chunk must have landed)
       M.wait();
       if (i / LN_CHUNK >= 2) M.fetch(i / LN_CHUNK - 2);
     }
@@ -1873,26 +1603,11 @@ __device__ __forceinline__ void feedback_rollout_lean(const Lds<real>& L, ModelS
 // (its accesses stay DS instructions).  Slacks and multipliers of the interior point are not touched; the iterate is put
 // aside in the handle's save area and comes back unless the attempt is accepted.  Wave-uniform values arrive in vector
 // registers (the calling convention has no scalar arguments) and go back to scalar registers first thing.
-// the fat-layout kernels that run one wave per SIMD (fp64, N = 24 .. 40, and the fp64 learning kernels): the DPP form of the vector
-// solve that the two-wave kernels use (round 4: bit for bit the LDS-exchange form, -3 % at N = 40 tracking / IAC, -2 % on the
-// learning kernel at N = 20, nothing at N = 40 learning; -DLMPC_FAT_DPP=0 builds the LDS exchange of rounds 2-3 for A/B)
-#ifndef LMPC_FAT_DPP
-#define LMPC_FAT_DPP 1
-#endif
-constexpr bool lmpc_solve_through_lds(int real_bytes, int kq, int ks) { return !LMPC_FAT_DPP && lmpc_waves_per_simd(real_bytes, kq, ks) < 2; }
-// which lean vector solve: the DPP form (round 4: bit for bit the LDS-exchange form of round 3 on every long-horizon family, and
-// -8 % of the kernel at N = 60 tracking, -4 % at N = 80, -4 / -12 % for the learning problem at N = 60 / 80;
-// -DLMPC_LEAN_DPP=0 builds the LDS exchange for A/B).  Rounds 2-3 kept DPP out of the one-wave-per-SIMD kernels after a
-// non-reproducible KQ = 14 / KS = 3 build; with the polish behind a call that family has been bit-stable in every build of
-// round 4 (two repetitions of every case here, the reproducibility scripts on the final build).
-#ifndef LMPC_LEAN_DPP
-#define LMPC_LEAN_DPP 1
-#endif
-#if LMPC_LEAN_DPP
-#define LMPC_LEAN_SOLVE riccati_solve_lean_dpp
-#else
-#define LMPC_LEAN_SOLVE riccati_solve_lean
-#endif
+// Every instantiation runs the DPP form of the vector solves (riccati_solve, riccati_solve_lean_dpp) since round 4: bit for bit the
+// LDS-exchange forms of rounds 2-3, -3 % at N = 40 tracking / IAC, -8 % at N = 60, -4 % at N = 80, -4 / -12 % for the learning
+// problem at N = 60 / 80.  (Rounds 2-3 kept DPP out of the one-wave-per-SIMD kernels after a non-reproducible KQ = 14 / KS = 3
+// build; with the polish behind a call that family has been bit-stable in every build since.  The LDS-exchange functions and
+// their -D switches were removed in round 5: scratch/r5/experiment_switches.patch.)
 
 template <typename real, int KQ, int KS>
 struct PolishArgs {
@@ -1936,17 +1651,9 @@ __device__ __forceinline__ T* uni_ptr(T* p) {
 //   * fp32 (single precision and the fp32 pass of the mixed entry): INLINED -- the call form is 10 % slower on the mixed learning
 //     kernel and changes single-precision roundings enough to lose four solves of 4096 at N = 80.
 //   * FRESH_LANE everywhere.
-// (-DLMPC_POLISH_CALL=0 / 1, -DLMPC_FRESH_POLICY=0 / 1: never / always, for A/B timing; scratch/r4_build_variants.sh.)
-#ifndef LMPC_POLISH_CALL
-#define LMPC_POLISH_CALL 2
-#endif
-#ifndef LMPC_FRESH_POLICY
-#define LMPC_FRESH_POLICY 2
-#endif
-constexpr bool lmpc_polish_is_call(int real_bytes, int kq, int ks) {
-  return LMPC_POLISH_CALL == 1 || (LMPC_POLISH_CALL == 2 && real_bytes == 8 && lmpc_waves_per_simd(real_bytes, kq, ks) < 2);
-}
-constexpr bool lmpc_fresh_lane(int real_bytes, int kq, int ks) { return LMPC_FRESH_POLICY != 0; }
+// (The A/B switches behind these measurements -- never / always a call, never / always fresh -- went to scratch/r5/experiment_switches.patch.)
+constexpr bool lmpc_polish_is_call(int real_bytes, int kq, int ks) { return real_bytes == 8 && lmpc_waves_per_simd(real_bytes, kq, ks) < 2; }
+constexpr bool lmpc_fresh_lane(int real_bytes, int kq, int ks) { return true; }
 
 template <typename real, int KQ, int KS, typename io, bool SECOND = false>  // (SECOND: see lmpc_solve_problem)
 __device__ __forceinline__ PolishResult<real, KS> lmpc_polish(const PolishArgs<real, KQ, KS>& a) {
@@ -2253,14 +1960,9 @@ __device__ __forceinline__ PolishResult<real, KS> lmpc_polish(const PolishArgs<r
       wave_sync();
       if constexpr (LEAN) {
         if (k == 0 && has_sigma)
-          LMPC_LEAN_SOLVE<2>(L, MS, lane, pf);
+          riccati_solve_lean_dpp<2>(L, MS, lane, pf);
         else
-          LMPC_LEAN_SOLVE<1>(L, MS, lane, pf);
-      } else if constexpr (lmpc_solve_through_lds(sizeof(real), KQ, KS)) {
-        if (k == 0 && has_sigma)
-          riccati_solve_lds<2>(L, lane, pf);
-        else
-          riccati_solve_lds<1>(L, lane, pf);
+          riccati_solve_lean_dpp<1>(L, MS, lane, pf);
       } else {
         if (k == 0 && has_sigma)
           riccati_solve<2>(L, lane, pf);
@@ -2508,35 +2210,11 @@ __device__ __attribute__((noinline)) PolishResult<real, KS> lmpc_polish_call(con
 //  the learning kernels at KQ >= 11 lose 15 % to the chunks.)
 // (bit mask of the four flag-select address sites recomputed per use in the fp64 tracking kernels with KQ <= 4: all four, -1.6..2.2 %
 //  at N = 20, bit-identical; +1 % at KQ = 7 and in fp32, which keep the hoisted form: profiles/r04_row_phases.md)
-#ifndef LMPC_OPAQUE_SITES
-#define LMPC_OPAQUE_SITES 15
-#endif
-#ifndef LMPC_ROW_CHUNK
-#define LMPC_ROW_CHUNK(kq) (((kq) + 1) / 2)
-#endif
-#ifndef LMPC_ROW_CHUNK_MIN_KQ
-#define LMPC_ROW_CHUNK_MIN_KQ 11
-#endif
-#ifndef LMPC_ROW_CHUNK_LEARNING
-#define LMPC_ROW_CHUNK_LEARNING 0
-#endif
-#ifndef LMPC_OPAQUE_MIN_KQ
-#define LMPC_OPAQUE_MIN_KQ 11
-#endif
-#ifndef LMPC_OPAQUE_LEARNING
-#define LMPC_OPAQUE_LEARNING 1
-#endif
 __host__ __device__ constexpr int lmpc_row_chunk(int real_bytes, int kq, int ks) {
-  return (real_bytes == 8 && kq >= LMPC_ROW_CHUNK_MIN_KQ && (ks == 0 || LMPC_ROW_CHUNK_LEARNING) && LMPC_ROW_CHUNK(kq) > 0 && LMPC_ROW_CHUNK(kq) < kq)
-             ? LMPC_ROW_CHUNK(kq)
-             : kq;
+  return (real_bytes == 8 && kq >= 11 && ks == 0) ? (kq + 1) / 2 : kq;
 }
-__host__ __device__ constexpr bool lmpc_opaque_slots(int real_bytes, int kq, int ks) {
-  return (real_bytes == 8 && kq >= LMPC_OPAQUE_MIN_KQ) || (ks > 0 && LMPC_OPAQUE_LEARNING);
-}
-__host__ __device__ constexpr int lmpc_opaque_sites(int real_bytes, int kq, int ks) {
-  return (real_bytes == 8 && kq <= 4 && ks == 0) ? LMPC_OPAQUE_SITES : 0;
-}
+__host__ __device__ constexpr bool lmpc_opaque_slots(int real_bytes, int kq, int ks) { return (real_bytes == 8 && kq >= 11) || ks > 0; }
+__host__ __device__ constexpr int lmpc_opaque_sites(int real_bytes, int kq, int ks) { return (real_bytes == 8 && kq <= 4 && ks == 0) ? 15 : 0; }
 
 // SECOND: the fp64 second pass of a mixed solve -- a handful of problems a whole batch waits for, sharing the chip with the next batch's
 // first pass: its waves run at the top issue priority throughout (and do not drop it between chains).
@@ -2838,7 +2516,7 @@ __device__ __forceinline__ void lmpc_solve_problem(
   bool distress = false;
   const int max_iter = feasible ? P.max_iter : 0;
   typedef polish_limits<real> pol;
-  const bool polish_on = LMPC_POLISH_BUILD && P.polish >= 0;
+  const bool polish_on = P.polish >= 0;
   bool polished = false, pol_early_done = false, reentry = false;
   int pol_rounds = 0;
   // results: layout by strides (lmpc_set_output_layout): [component][knot][batch] by default -- what batch-parallel consumers
@@ -3069,9 +2747,7 @@ __device__ __forceinline__ void lmpc_solve_problem(
           }
 #pragma unroll
           for (int k = 0; k < 6; ++k) F[k * 6 + k] += 1.0 / fmax(TT[TL_E + k], treal(1e-30));  // (a zero weight: that component of eps is free)
-          if (LMPC_TERM_PRIO) CHAIN_PRIO_ENTER();
           term_factor_u(TT, lane, F, aB, av[6], m);
-          if (LMPC_TERM_PRIO) CHAIN_PRIO_LEAVE();
         }
         if (lane < 6) {
           treal e = 0.0;
@@ -3183,9 +2859,7 @@ __device__ __forceinline__ void lmpc_solve_problem(
           treal beta[6], h[6], nu;
 #pragma unroll
           for (int k = 0; k < 6; ++k) beta[k] = bs[k];
-          if (LMPC_TERM_PRIO) CHAIN_PRIO_ENTER();
           term_solve_u(TT, lane, sx.m, beta, bs[6], sx.r1, h, nu);
-          if (LMPC_TERM_PRIO) CHAIN_PRIO_LEAVE();
           PT_MARK(14)
           if (lane < 6) {  // terminal gradient onto x_T: E eps + pT, pT = -h
             treal hs = h[0];
@@ -3250,19 +2924,11 @@ __device__ __forceinline__ void lmpc_solve_problem(
       wave_sync();
       // ======== Newton step: predictor together with the Schur vector, then the corrector ========
       PT_MARK(4)
-      // Every instantiation runs the DPP form of the sweeps since round 4 (lmpc_solve_through_lds / LMPC_LEAN_DPP above).  Rounds
-      // 2-3 kept the LDS exchange in the one-wave-per-SIMD kernels after a KQ = 14 / KS = 3 build that was not reproducible from
-      // run to run with DPP; with the polish behind a call that family has been bit-stable in every build.
       if constexpr (LEAN) {
         if (pass == 0 && ipm && has_sigma)
-          LMPC_LEAN_SOLVE<2>(L, MS, lane, pf);
+          riccati_solve_lean_dpp<2>(L, MS, lane, pf);
         else
-          LMPC_LEAN_SOLVE<1>(L, MS, lane, pf);
-      } else if constexpr (lmpc_solve_through_lds(sizeof(real), KQ, KS)) {
-        if (pass == 0 && ipm && has_sigma)
-          riccati_solve_lds<2>(L, lane, pf);
-        else
-          riccati_solve_lds<1>(L, lane, pf);
+          riccati_solve_lean_dpp<1>(L, MS, lane, pf);
       } else {
         if (pass == 0 && ipm && has_sigma)
           riccati_solve<2>(L, lane, pf);
@@ -3359,9 +3025,7 @@ __device__ __forceinline__ void lmpc_solve_problem(
         treal beta[6], h[6], nu;
 #pragma unroll
         for (int k = 0; k < 6; ++k) beta[k] = gs[k];
-        if (LMPC_TERM_PRIO) CHAIN_PRIO_ENTER();
         term_solve_u(TT, lane, sx.m, beta, gs[6], sx.r1, h, nu);
-        if (LMPC_TERM_PRIO) CHAIN_PRIO_LEAVE();
 #pragma unroll
         for (int q = 0; q < KS; ++q) {
           treal uh = 0.0, uq[6];
@@ -3637,20 +3301,6 @@ __device__ __forceinline__ void lmpc_solve_problem(
         if (sx.on[q]) lam_out[(size_t)(lane + 64 * q) * B + b] = io(sx.lm[q]);
     }
   }
-#ifdef LMPC_DUMP_ROWS  // (scratch/r4_rowdump.py: the interior point's row state as it stands at the exit, every lane, behind the 4 B kkt values)
-  if (kkt_out) {
-    io* const dst = kkt_out + (size_t)4 * B + ((size_t)b * 64 + lane) * (6 * KQ);
-#pragma unroll
-    for (int q = 0; q < KQ; ++q) {
-      dst[6 * q + 0] = io(s_tu[q]);
-      dst[6 * q + 1] = io(s_tl[q]);
-      dst[6 * q + 2] = io(s_lu[q]);
-      dst[6 * q + 3] = io(s_ll[q]);
-      dst[6 * q + 4] = io(s_pu[q]);
-      dst[6 * q + 5] = io(s_pl[q]);
-    }
-  }
-#endif
   if (lane == 0) {
     status_out[b] = status;
     iters_out[b] = it;
@@ -3734,31 +3384,11 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
     const io* __restrict__ ss_j, io* __restrict__ lam_out, io* __restrict__ X_out,
     io* __restrict__ U_out, io* __restrict__ dU_out, int* __restrict__ status_out,
     int* __restrict__ iters_out, io* __restrict__ kkt_out) {
-#ifdef LMPC_CLEANUP_INLINE  // (scratch/r4_cleanup_rootcause.sh: the round-3 failure under test -- the solve inlined under the loop)
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-#endif
   const int n = __builtin_amdgcn_readfirstlane(*count);
   for (int w = blockIdx.x; w < n; w += gridDim.x) {
     const int b = __builtin_amdgcn_readfirstlane(list[w]);  // (wave-uniform: keep the problem index in a scalar register)
-#ifdef LMPC_CLEANUP_LOOP_WAIT  // hypothesis A: something of the previous problem is still in flight when the next one starts
-    asm volatile("s_waitcnt vmcnt(0) expcnt(0) lgkmcnt(0)" ::: "memory");
-    wave_fence();
-#endif
-#ifdef LMPC_CLEANUP_LDS_CLEAR  // hypothesis B: a read of LDS cells the problem has not written yet (stale content of the previous problem)
-    {
-      extern __shared__ __attribute__((aligned(16))) unsigned char lds_all[];
-      const int nbytes = (int)P.dbg_lds_bytes;
-      for (int e = threadIdx.x * 8; e < nbytes; e += 64 * 8) *reinterpret_cast<double*>(lds_all + e) = 0.0;
-      wave_fence();
-    }
-#endif
-#ifdef LMPC_CLEANUP_INLINE
-    lmpc_solve_problem<real, KQ, KS, io>(P, B, b, lds_raw, ws_lin, x_ic, u_ic, T_ref, bl, br, vref, ss_x, ss_j, lam_out, X_out, U_out, dU_out,
-                                         status_out, iters_out, kkt_out);
-#else
     lmpc_solve_problem_call<real, KQ, KS, io>(P, B, b, ws_lin, x_ic, u_ic, T_ref, bl, br, vref, ss_x, ss_j, lam_out, X_out, U_out, dU_out,
                                               status_out, iters_out, kkt_out);
-#endif
     wave_fence();
   }
 }
@@ -3806,12 +3436,6 @@ extern template __global__ void lmpc_solve_kernel<float, 4, 2, double>(lmpc_para
     const double*, const double*, const double*, const double*, const double*, double*, double*, double*, double*, int*, int*, double*);
 extern template __global__ void lmpc_solve_kernel<float, 4, 3, double>(lmpc_params, int, const double*, const double*, const double*, const double*,
     const double*, const double*, const double*, const double*, const double*, double*, double*, double*, double*, int*, int*, double*);
-#ifdef LMPC_MIXED_LONG_LEARNING  // the learning problem at the horizons the reference ships for it (barc_lmpc N = 40, iac_car_lmpc N = 60)
-LMPC_INSTANTIATE(float, 7, 2, double)
-LMPC_INSTANTIATE(float, 7, 3, double)
-LMPC_INSTANTIATE(float, 11, 2, double)
-LMPC_INSTANTIATE(float, 11, 3, double)
-#endif
 // the fp64 second pass behind each of the mixed kernels above
 #define LMPC_INSTANTIATE_CLEANUP(KQ, KS)                                                                                  \
   template __global__ void lmpc_cleanup_kernel<double, KQ, KS, double>(lmpc_params, int, const int*, const int*,          \
@@ -3823,12 +3447,6 @@ LMPC_INSTANTIATE_CLEANUP(11, 0)
 LMPC_INSTANTIATE_CLEANUP(14, 0)
 LMPC_INSTANTIATE_CLEANUP(4, 2)
 LMPC_INSTANTIATE_CLEANUP(4, 3)
-#ifdef LMPC_MIXED_LONG_LEARNING
-LMPC_INSTANTIATE_CLEANUP(7, 2)
-LMPC_INSTANTIATE_CLEANUP(7, 3)
-LMPC_INSTANTIATE_CLEANUP(11, 2)
-LMPC_INSTANTIATE_CLEANUP(11, 3)
-#endif
 // (the learning problem at N = 40 in mixed precision was built and measured: 1.16 M solves/s against 0.70 M in fp64, but
 //  median 1.2e-3 / 99th percentile 1.5e-2 from the fp64 answers -- outside the 1e-3 the mixed entry states; not shipped)
 #endif
