@@ -319,6 +319,9 @@ def main():
                     help="--workload lmpc: spec (default) = SURVEY.md 8d config 3 as written: the five laps are produced by the tracking "
                          "loop at speed scales 0.80 .. 1.0 (closed_loop.record_laps) and the 4096 queries are config 2's random x0; "
                          "near = the friendlier workload of rounds 1 - 4 (analytic laps, states drawn near the last lap), kept for continuity")
+    ap.add_argument("--ss-mode", choices=["idx", "arrays"], default="idx",
+                    help="--workload lmpc: idx (default) = the safe set by reference (lmpc_ss_query_idx_batch + lmpc_solve_batch_ss_idx: 640 B of "
+                         "codes per query); arrays = (ss_x, ss_j) materialised per query (8960 B), the interface of rounds 1 - 4")
     ap.add_argument("--min-window", type=float, default=0.5, help="the timed region repeats the --steps block until it spans at least this "
                     "many seconds AND at least 200 steps (VERDICT r4 item 9a: 20 steps of 0.7 ms are a 15 ms window); 0 = exactly --steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -456,7 +459,9 @@ def main():
         for o in outs:
             o["convex_combi_optm"] = torch.zeros((cfgd["num_ss_pts"], B), dtype=torch.float64, device=dev)
         # query = last knot of the abscissa-aligned reference (racing_mpc.cpp:219-223,249-254)
-        ss_bufs = [solver.ss_query(inp["X_ref"][:2, -1].contiguous()) for _ in outs]   # one result buffer set per output slot
+        ss_idx_mode = args.ss_mode == "idx"
+        ss_query_fn = (lambda sv, q, out=None: sv.ss_query_idx(q, out=out)) if ss_idx_mode else (lambda sv, q, out=None: sv.ss_query(q, out=out))
+        ss_bufs = [ss_query_fn(solver, inp["X_ref"][:2, -1].contiguous()) for _ in outs]   # one result buffer set per output slot
         s_last, s0, L = inp["X_ref"][0, -1], inp["x_ic"][0], tr["L"]
         kk = (s0 - s_last).abs() + L / 2
         query = torch.stack([s_last + (kk - torch.fmod(kk, L)) * torch.sign(s0 - s_last), inp["X_ref"][1, -1]]).contiguous()
@@ -494,8 +499,12 @@ def main():
         if f32:
             sv.solve_f32(inp32, o)
         elif lmpc:
-            ss_x, ss_j, _ = sv.ss_query(query, out=ss_bufs[k % len(ss_bufs)])
-            sv.solve(inp, o, ss_x=ss_x, ss_j=ss_j, mixed=mixed)
+            if ss_idx_mode:
+                idx, _ = sv.ss_query_idx(query, out=ss_bufs[k % len(ss_bufs)])
+                sv.solve(inp, o, ss_idx=idx, mixed=mixed)
+            else:
+                ss_x, ss_j, _ = sv.ss_query(query, out=ss_bufs[k % len(ss_bufs)])
+                sv.solve(inp, o, ss_x=ss_x, ss_j=ss_j, mixed=mixed)
         else:
             sv.solve(inp, o, mixed=mixed)
         return o
@@ -536,7 +545,7 @@ def main():
             step(k)
         drain()
         est = (time.perf_counter() - tp) / max(S, 4)
-        repeats = max(1, -(-max(200, int(args.min_window / max(est, 1e-6)) + 1) // args.steps))
+        repeats = max(1, -(-max(200, int(1.3 * args.min_window / max(est, 1e-6)) + 1) // args.steps))  # (the probe is slower than the steady pipeline)
         if world > 1:
             box = [repeats]
             dist.broadcast_object_list(box, src=0)
@@ -592,7 +601,7 @@ def main():
             for k in range(60):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                solver.ss_query(query, out=ss_bufs[0])
+                ss_query_fn(solver, query, out=ss_bufs[0])
                 e1.record()
                 e1.synchronize()
                 if k >= 10:
@@ -625,14 +634,15 @@ def main():
         sol_avg = float(np.mean(sol_ms))
         algo_bytes = ((13 * N + 5) + (10 * N - 4)) * (4 if f32 else 8) + 8
         if lmpc:
-            algo_bytes += (7 + 1) * 160 * 8  # + ss_x, ss_j in and lambda out (13 936 B at S = 160)
+            algo_bytes += (7 + 1) * 160 * 8  # + ss_x, ss_j in and lambda out (13 936 B at S = 160; by reference the kernel reads
+            #                                    640 B of codes + the points from the L2-resident store instead, the figure is kept as SURVEY states it)
         achieved = algo_bytes * B / (sol_avg * 1e-3) / 1e9
         # committed PMC passes of this command: tracking, or the learning problem with 160 safe-set points
         pmc_sel = ("r04_pmc_lmpc.json", "lmpc_solve_kernel<double, 4, 3") if lmpc else ("r04_pmc.json", "lmpc_solve_kernel<double, 4, 0")
         pmc_shape = not (N != 20 or B != 4096 or iac or f32 or mixed)  # the shape the committed passes were taken on
         traffic, traffic_source, counters = None, None, {}
         if world == 1 and not args.no_pmc:
-            wl_argv = ["--batch", str(B), "--horizon", str(N), "--workload", args.workload, "--precision", args.precision, "--lmpc-data", args.lmpc_data]
+            wl_argv = ["--batch", str(B), "--horizon", str(N), "--workload", args.workload, "--precision", args.precision, "--lmpc-data", args.lmpc_data, "--ss-mode", args.ss_mode]
             if args.regression:
                 wl_argv.append("--regression")
             kname = "lmpc_solve_kernel<%s, " % ("float" if (f32 or mixed) else "double")
@@ -663,6 +673,7 @@ def main():
                                    + (" -- error-dynamics regression on: %d recorded sample pairs, every stage regressed before its QP" % len(reg_laps)
                                       if (lmpc and reg_laps) else ""),
                        "batch_per_gpu": B, "horizon": N, "streams": S, "output_layout": args.output_layout,
+                       **({"safe_set": "by reference (int32 codes)" if ss_idx_mode else "arrays (ss_x, ss_j)"} if lmpc else {}),
                        "launch_order": ("longest first by the previous solve's iteration counts of the SAME batch (perfect foresight here)"
                                         if orders else "default"), "result_gather": "rccl all_gather (async)" if gather else "none",
                        "ranks_seen": ranks_seen, "gathered": gathered},
@@ -691,7 +702,7 @@ def main():
             # safe-set query kernel: per query 2 doubles in, 7 S doubles out (ss_x [6][S], ss_j [S]); the lap store
             # (5 laps x ~1320 unrolled points x 2 coordinates) is read once per query from L2, not from HBM
             S_pts = cfgd["num_ss_pts"]
-            q_bytes = (2 + 7 * S_pts) * 8
+            q_bytes = 2 * 8 + (4 * S_pts if ss_idx_mode else 7 * S_pts * 8)
             t_ss = float(np.mean(ss_ms)) * 1e-3
             res["ss_query_kernel"] = {"ms": t_ss * 1e3, "queries_per_s": B / t_ss, "algorithmic_bytes_per_query": q_bytes,
                                       "achieved_GBps": q_bytes * B / t_ss / 1e9, "frac_of_hbm_peak": q_bytes * B / t_ss / 1e9 / HBM_PEAK_GBS,

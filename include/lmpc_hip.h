@@ -321,6 +321,23 @@ int lmpc_regress_batch(lmpc_handle* h, int32_t batch, const double* X_ref, const
 int lmpc_ss_query_batch(lmpc_handle* h, int32_t batch, const double* query, double* ss_x,
                         double* ss_j, int32_t* n_found);
 
+/* The same query BY REFERENCE (round 5; no counterpart upstream, where the query returns copies, safe_set.cpp:153-180): instead
+ * of the 7 S doubles per query of (ss_x, ss_j) the kernel leaves S int32 codes, ss_idx [S][B],
+ *     code = (row of the point in the concatenated lap store of lmpc_set_safe_set) * 4 + rep,   rep = 0 / 1 / 2: the copy of the
+ *            lap shifted by -L / 0 / +L (SSTrajectory::process_lap_data, :122-128);  -1: no point (nothing stored, NaN query)
+ * padded with the last point's code (racing_mpc.cpp:263-272), and lmpc_solve_batch_ss_idx gathers the points from the store
+ * itself: 640 B per query at S = 160 instead of 8960 B written here and read back by the QP kernel.  Same neighbours in the same
+ * order as lmpc_ss_query_batch (one kernel, two output forms); the solve on them gives bit for bit the same result. */
+int lmpc_ss_query_idx_batch(lmpc_handle* h, int32_t batch, const double* query, int32_t* ss_idx, int32_t* n_found);
+
+/* lmpc_solve_batch (precision = LMPC_PRECISION_F64) or lmpc_solve_batch_mixed (LMPC_PRECISION_MIXED) for the learning problem with
+ * the safe set by reference: ss_idx [S][B] from lmpc_ss_query_idx_batch ON THIS HANDLE, against the store lmpc_set_safe_set left
+ * on it (do not replace the store between the query and the solve).  Everything else as lmpc_solve_batch. */
+int lmpc_solve_batch_ss_idx(lmpc_handle* h, int32_t batch, int32_t precision, const double* x_ic, const double* u_ic, const double* X_ref,
+                            const double* U_ref, const double* T_ref, const double* bound_left, const double* bound_right,
+                            const double* curvatures, const double* vel_ref, double total_length, const int32_t* ss_idx, double* X_optm,
+                            double* U_optm, double* dU_optm, double* convex_combi_optm, int32_t* status, int32_t* iters, double* kkt);
+
 /* Cold-start input preparation of RacingMPCNode::on_step_timer
  * (racing_mpc_node.cpp:210-235,261-292): U_ref = 1e-9, X_ref rolled out with the RK4
  * model and the track curvature at each knot, references sampled from the track tables,

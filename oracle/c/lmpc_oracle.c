@@ -218,6 +218,7 @@ typedef struct {
   /* LMPC terminal block */
   double ssx[6][SMAX], ssj[SMAX], chs2[6]; /* safe-set points CENTRED on ss0 = first point; 2*convex_hull_slack */
   double ss0[6];
+  int S_in, ss_map[SMAX]; /* points as handed in, and which of them each kept point is (runs of identical points are one point) */
   int hard_hull; /* all-zero convex_hull_slack: the hull row is an equality, realised as the penalty limit */
   /* bounds per slot */
   double hi[NMAX][NSLOT], lo[NMAX][NSLOT];
@@ -1446,9 +1447,23 @@ static void setup_problem(prob_t* p, const lmpc_config* cfg, const lmpc_vehicle*
     for (int k = 0; k < 6; ++k) {
       p->chs2[k] = any_slack ? 2.0 * cfg->convex_hull_slack[k] : 2.0 * LMPC_HARD_HULL_WEIGHT;
       p->ss0[k] = ss_x[(size_t)(k * p->S) * B + b];
-      for (int j = 0; j < p->S; ++j) p->ssx[k][j] = ss_x[(size_t)(k * p->S + j) * B + b] - p->ss0[k];
     }
-    for (int j = 0; j < p->S; ++j) p->ssj[j] = ss_j[(size_t)j * B + b];
+    /* A point that repeats the one before it adds nothing to the hull and makes the free weights' system singular (C_A, the
+     * polish's multiplier steps): the padding of a set with fewer than S points repeats the last point S - n_found times
+     * (racing_mpc.cpp:263-272).  Runs of identical points are kept once -- X, U, dU are those of the full set, the weight of a
+     * run sits on its first point.  The kernel does the same (csrc/lmpc_solve_kernel.hip, the learning prologue). */
+    const int S_in = p->S;
+    int kept = 0;
+    for (int j = 0; j < S_in; ++j) {
+      int dup = j > 0 && ss_j[(size_t)j * B + b] == ss_j[(size_t)(j - 1) * B + b];
+      for (int k = 0; k < 6 && dup; ++k) dup = ss_x[(size_t)(k * S_in + j) * B + b] == ss_x[(size_t)(k * S_in + j - 1) * B + b];
+      if (dup) continue;
+      for (int k = 0; k < 6; ++k) p->ssx[k][kept] = ss_x[(size_t)(k * S_in + j) * B + b] - p->ss0[k];
+      p->ssj[kept] = ss_j[(size_t)j * B + b];
+      p->ss_map[kept++] = j;
+    }
+    p->S_in = S_in;
+    p->S = kept;
     double umax = 0.0; /* largest u_j' E u_j over the (centred) points */
     for (int j = 0; j < p->S; ++j) {
       double q = 0.0;
@@ -1535,8 +1550,10 @@ int lmpc_oracle_solve_range(const lmpc_config* cfg, const lmpc_vehicle* veh, int
         U_optm[(size_t)(k * (N - 1) + i) * B + b] = p->z[i + 1][6 + k];
         dU_optm[(size_t)(k * (N - 1) + i) * B + b] = p->v[i][k];
       }
-    if (lambda_out && p->S)
-      for (int j = 0; j < p->S; ++j) lambda_out[(size_t)j * B + b] = p->lmb[j];
+    if (lambda_out && p->S) {
+      for (int j = 0; j < p->S_in; ++j) lambda_out[(size_t)j * B + b] = 0.0;
+      for (int j = 0; j < p->S; ++j) lambda_out[(size_t)p->ss_map[j] * B + b] = p->lmb[j];
+    }
     status[b] = st;
     iters[b] = it;
     if (kkt)

@@ -20,7 +20,8 @@ _ABI_SYMBOLS = ("lmpc_create", "lmpc_destroy", "lmpc_last_error", "lmpc_set_stre
                 "lmpc_prepare_batch", "lmpc_reserve", "lmpc_query_launch", "lmpc_enable_timing",
                 "lmpc_last_kernel_ms", "lmpc_query_residency", "lmpc_query_launch_for", "lmpc_solve_host", "lmpc_shift_batch",
                 "lmpc_plant_step_batch", "lmpc_solve_full_dynamics_batch", "lmpc_solve_full_dynamics_host", "lmpc_set_regression_laps", "lmpc_regress_batch", "lmpc_ss_query_host", "lmpc_solve_batch_f32",
-                "lmpc_solve_batch_mixed", "lmpc_prepare_failed_batch", "lmpc_set_launch_order", "lmpc_launch_order_from_iters", "lmpc_set_output_layout")
+                "lmpc_solve_batch_mixed", "lmpc_prepare_failed_batch", "lmpc_set_launch_order", "lmpc_launch_order_from_iters", "lmpc_set_output_layout",
+                "lmpc_ss_query_idx_batch", "lmpc_solve_batch_ss_idx")
 
 
 class LmpcError(RuntimeError):
@@ -327,14 +328,23 @@ class Solver:
                 "iters": torch.empty((B,), dtype=torch.int32, device=self.device),
                 "kkt": torch.empty((4, B), **kw)}
 
-    def solve(self, inp: dict, out: dict | None = None, ss_x=None, ss_j=None, mixed: bool = False):
-        """lmpc_solve_batch, or with mixed=True lmpc_solve_batch_mixed (same fp64 arrays, fp32 interior-point iteration)."""
+    def solve(self, inp: dict, out: dict | None = None, ss_x=None, ss_j=None, mixed: bool = False, ss_idx=None):
+        """lmpc_solve_batch, or with mixed=True lmpc_solve_batch_mixed (same fp64 arrays, fp32 interior-point iteration); with
+        ss_idx (int32 [S][B] from ss_query_idx) lmpc_solve_batch_ss_idx: the safe set by reference instead of ss_x / ss_j."""
         self.use_current_stream()
         keys = ("x_ic", "u_ic", "X_ref", "U_ref", "T_ref", "bound_left", "bound_right", "curvatures", "vel_ref")
         a = [self._t(inp[k]) for k in keys]
         B = a[0].shape[1]
         if out is None:
             out = self.alloc_outputs(B)
+        if ss_idx is not None:
+            rc = self.lib.lmpc_solve_batch_ss_idx(self._h, C.c_int32(B), C.c_int32(2 if mixed else 0), *[_ptr(t) for t in a],
+                                                  C.c_double(float(inp["L"])), _ptr(ss_idx), _ptr(out["X_optm"]), _ptr(out["U_optm"]),
+                                                  _ptr(out["dU_optm"]), _ptr(out.get("convex_combi_optm")), _ptr(out["status"]),
+                                                  _ptr(out["iters"]), _ptr(out.get("kkt")))
+            self._check(rc, "lmpc_solve_batch_ss_idx")
+            out["_inputs_keepalive"] = a + [ss_idx]
+            return out
         ss_x = None if ss_x is None else self._t(ss_x)
         ss_j = None if ss_j is None else self._t(ss_j)
         fn = self.lib.lmpc_solve_batch_mixed if mixed else self.lib.lmpc_solve_batch
@@ -444,6 +454,22 @@ class Solver:
         rc = self.lib.lmpc_regress_batch(self._h, C.c_int32(X.shape[2]), _ptr(X), _ptr(U), _ptr(A), _ptr(Bm), _ptr(g))
         self._check(rc, "lmpc_regress_batch")
         return A, Bm, g
+
+    def ss_query_idx(self, query, out=None):
+        """lmpc_ss_query_idx_batch: the safe set of every query by reference -- (ss_idx int32 [S][B], n_found [B]); `out` reuses buffers."""
+        torch = self._torch
+        self.use_current_stream()
+        q = self._t(query)
+        B = q.shape[1]
+        S = int(self.config["num_ss_pts"])
+        if out is not None:
+            ss_idx, nf = out
+        else:
+            ss_idx = torch.full((S, B), -1, dtype=torch.int32, device=self.device)
+            nf = torch.zeros((B,), dtype=torch.int32, device=self.device)
+        rc = self.lib.lmpc_ss_query_idx_batch(self._h, C.c_int32(B), _ptr(q), _ptr(ss_idx), _ptr(nf))
+        self._check(rc, "lmpc_ss_query_idx_batch")
+        return ss_idx, nf
 
     def ss_query(self, query, out=None):
         """lmpc_ss_query_batch.  `out` = (ss_x [6][S][B], ss_j [S][B], n_found [B]) reuses the caller's buffers (the

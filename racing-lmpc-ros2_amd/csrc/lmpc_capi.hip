@@ -27,7 +27,7 @@ template <typename real, int KQ, int KS, typename io>
 __global__ void lmpc_solve_kernel(lmpc_params, int, const io*, const io*, const io*, const io*, const io*, const io*,
                                   const io*, const io*, const io*, io*, io*, io*, io*, int*, int*, io*);
 __global__ void lmpc_ss_query_kernel(int, int, int, int, const int*, const int*, const double*, double, const double*,
-                                     double*, double*, int*, double*);
+                                     double*, double*, int*, double*, int*);
 __global__ void lmpc_reg_residual_kernel(lmpc_vehicle, int, int, const int*, const double*, const double*, const double*,
                                          const double*, double*);
 __global__ void lmpc_reg_pack_kernel(lmpc_regression_spec, int, int, const int*, const double*, const double*, const double*, double*, double*);
@@ -132,6 +132,7 @@ struct solve_args {
   int *status, *iters;
   double* kkt;
   bool aos;  // results [batch][knot][component]
+  const int* ss_idx;  // learning: the safe set by reference (lmpc_solve_batch_ss_idx) instead of ss_x / ss_j
 };
 
 template <int KQ, int KS, typename real = double>
@@ -208,6 +209,16 @@ const void* pick_cleanup_fn(int kq, int ks) {
   return nullptr;
 }
 
+// the safe set by reference: the codes of lmpc_ss_query_idx_batch and the handle's lap store they point into
+void set_ss_reference(const lmpc_handle* h, lmpc_params& P, const solve_args& a) {
+  P.ss_idx = a.ss_idx;
+  P.ss_store = h->ss_x;
+  P.ss_npts = h->ss_npts;
+  P.ss_off = h->ss_off;
+  P.ss_laps = h->ss_laps;
+  P.ss_L = h->ss_L;
+}
+
 int launch_cleanup(lmpc_handle* h, const void* fn, const solve_args& a) {
   hipLaunchKernelGGL(lmpc_collect_unverified_kernel, dim3(1), dim3(1024), 0, h->stream, a.B, a.status, h->unverified);
   HIP_TRY(h, hipGetLastError());
@@ -216,6 +227,7 @@ int launch_cleanup(lmpc_handle* h, const void* fn, const solve_args& a) {
   P.launch_order = nullptr;
   P.flag_unverified = 0;
   P.out_aos = a.aos ? 1 : 0;
+  set_ss_reference(h, P, a);
   int B = a.B;
   const double* ws = h->ws;
   const int* list = h->unverified;
@@ -246,6 +258,7 @@ int launch_solve(lmpc_handle* h, const void* fn, const solve_args& a_in, int pas
   lmpc_params P = h->P;
   P.flag_unverified = pass == 1;
   P.out_aos = a.aos ? 1 : 0;
+  set_ss_reference(h, P, a);
   // the registered order applies to solves of exactly its own batch size; every other launch through this handle (the
   // single-problem host path, the SQP's QPs on another batch, ...) keeps the default mapping
   P.launch_order = (h->order && a.B == h->order_n) ? h->order : nullptr;
@@ -533,13 +546,16 @@ int solve_batch_fp64_arrays(lmpc_handle* h, bool mixed, bool aos, int32_t batch,
                             const double* X_ref, const double* U_ref, const double* T_ref, const double* bound_left,
                             const double* bound_right, const double* curvatures, const double* vel_ref,
                             double total_length, const double* ss_x, const double* ss_j, double* X_optm, double* U_optm,
-                            double* dU_optm, double* convex_combi_optm, int32_t* status, int32_t* iters, double* kkt) {
+                            double* dU_optm, double* convex_combi_optm, int32_t* status, int32_t* iters, double* kkt,
+                            const int32_t* ss_idx = nullptr) {
   if (!h) return LMPC_ERR_ARGUMENT;
   (void)total_length;  // abscissa alignment (racing_mpc.cpp:219-223) shifts s only; the QP is invariant to it
   if (batch < 0 || !x_ic || !u_ic || !X_ref || !U_ref || !T_ref || !bound_left || !bound_right || !curvatures ||
       !vel_ref || !X_optm || !U_optm || !dU_optm || !status || !iters)
     return fail(h, LMPC_ERR_ARGUMENT, "lmpc_solve_batch: null pointer or negative batch");
-  if (h->P.learning && (!ss_x || !ss_j)) return fail(h, LMPC_ERR_ARGUMENT, "learning=1 needs ss_x and ss_j");
+  if (h->P.learning && !ss_idx && (!ss_x || !ss_j)) return fail(h, LMPC_ERR_ARGUMENT, "learning=1 needs ss_x and ss_j");
+  if (ss_idx && (!h->P.learning || !h->ss_x || h->ss_laps < 1))
+    return fail(h, LMPC_ERR_ARGUMENT, "ss_idx needs learning=1 and a safe set stored on the handle (lmpc_set_safe_set)");
   if (batch == 0) return LMPC_OK;
   HIP_TRY(h, hipSetDevice(h->device));
   if ((size_t)batch > h->ws_cap) {
@@ -571,7 +587,8 @@ int solve_batch_fp64_arrays(lmpc_handle* h, bool mixed, bool aos, int32_t batch,
   a.B = batch;
   a.lds_bytes = lmpc_lds_bytes(N, h->P.learning, h->P.S, mixed ? 4 : 8);
   a.x_ic = x_ic; a.u_ic = u_ic; a.T_ref = T_ref; a.bl = bound_left; a.br = bound_right; a.vref = vel_ref;
-  a.ss_x = h->P.learning ? ss_x : nullptr; a.ss_j = h->P.learning ? ss_j : nullptr;
+  a.ss_x = (h->P.learning && !ss_idx) ? ss_x : nullptr; a.ss_j = (h->P.learning && !ss_idx) ? ss_j : nullptr;
+  a.ss_idx = h->P.learning ? ss_idx : nullptr;
   a.lam = h->P.learning ? convex_combi_optm : nullptr;
   a.X = X_optm; a.U = U_optm; a.dU = dU_optm; a.status = status; a.iters = iters; a.kkt = kkt;
   a.aos = aos;
@@ -621,6 +638,19 @@ int lmpc_solve_batch_mixed(lmpc_handle* h, int32_t batch, const double* x_ic, co
   return solve_batch_fp64_arrays(h, true, h && h->out_aos, batch, x_ic, u_ic, X_ref, U_ref, T_ref, bound_left, bound_right, curvatures,
                                  vel_ref, total_length, ss_x, ss_j, X_optm, U_optm, dU_optm, convex_combi_optm, status,
                                  iters, kkt);
+}
+
+int lmpc_solve_batch_ss_idx(lmpc_handle* h, int32_t batch, int32_t precision, const double* x_ic, const double* u_ic, const double* X_ref,
+                            const double* U_ref, const double* T_ref, const double* bound_left, const double* bound_right,
+                            const double* curvatures, const double* vel_ref, double total_length, const int32_t* ss_idx, double* X_optm,
+                            double* U_optm, double* dU_optm, double* convex_combi_optm, int32_t* status, int32_t* iters, double* kkt) {
+  if (!h) return LMPC_ERR_ARGUMENT;
+  if (!ss_idx) return fail(h, LMPC_ERR_ARGUMENT, "lmpc_solve_batch_ss_idx: ss_idx is null");
+  if (precision != LMPC_PRECISION_F64 && precision != LMPC_PRECISION_MIXED)
+    return fail(h, LMPC_ERR_ARGUMENT, "lmpc_solve_batch_ss_idx: precision is LMPC_PRECISION_F64 or LMPC_PRECISION_MIXED");
+  return solve_batch_fp64_arrays(h, precision == LMPC_PRECISION_MIXED, h->out_aos, batch, x_ic, u_ic, X_ref, U_ref, T_ref, bound_left, bound_right,
+                                 curvatures, vel_ref, total_length, nullptr, nullptr, X_optm, U_optm, dU_optm, convex_combi_optm, status, iters, kkt,
+                                 ss_idx);
 }
 
 int lmpc_solve_batch_f32(lmpc_handle* h, int32_t batch, const float* x_ic, const float* u_ic, const float* X_ref,
@@ -978,11 +1008,27 @@ int lmpc_set_safe_set(lmpc_handle* h, int32_t n_laps, const int32_t* n_pts, cons
   return LMPC_OK;
 }
 
+namespace {
+int ss_query_launch(lmpc_handle* h, int32_t batch, const double* query, double* ss_x, double* ss_j, int32_t* n_found, int32_t* ss_idx);
+}
+
 int lmpc_ss_query_batch(lmpc_handle* h, int32_t batch, const double* query, double* ss_x, double* ss_j,
                         int32_t* n_found) {
   if (!h) return LMPC_ERR_ARGUMENT;
   if (batch < 0 || !query || !ss_x || !ss_j || !n_found)
     return fail(h, LMPC_ERR_ARGUMENT, "lmpc_ss_query_batch: null pointer or negative batch");
+  return ss_query_launch(h, batch, query, ss_x, ss_j, n_found, nullptr);
+}
+
+int lmpc_ss_query_idx_batch(lmpc_handle* h, int32_t batch, const double* query, int32_t* ss_idx, int32_t* n_found) {
+  if (!h) return LMPC_ERR_ARGUMENT;
+  if (batch < 0 || !query || !ss_idx || !n_found)
+    return fail(h, LMPC_ERR_ARGUMENT, "lmpc_ss_query_idx_batch: null pointer or negative batch");
+  return ss_query_launch(h, batch, query, nullptr, nullptr, n_found, ss_idx);
+}
+
+namespace {
+int ss_query_launch(lmpc_handle* h, int32_t batch, const double* query, double* ss_x, double* ss_j, int32_t* n_found, int32_t* ss_idx) {
   if (h->cfg.num_ss_pts < 1 || h->cfg.num_ss_pts_per_lap < 1)
     return fail(h, LMPC_ERR_ARGUMENT, "num_ss_pts / num_ss_pts_per_lap not configured");
   if (h->cfg.num_ss_pts_per_lap > 64)
@@ -995,10 +1041,11 @@ int lmpc_ss_query_batch(lmpc_handle* h, int32_t batch, const double* query, doub
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(lmpc_ss_query_kernel, dim3(8 * ((batch + 7) / 8)), dim3(64), lds, h->stream, batch, h->ss_laps, h->cfg.num_ss_pts,
                      h->cfg.num_ss_pts_per_lap, h->ss_npts, h->ss_off, h->ss_x, h->ss_L, query, ss_x, ss_j, n_found,
-                     (double*)nullptr);
+                     (double*)nullptr, ss_idx);
   HIP_TRY(h, hipGetLastError());
   return LMPC_OK;
 }
+}  // namespace
 
 int lmpc_ss_query_host(lmpc_handle* h, const double* query, double* ss_x, double* ss_j, int32_t* n_found, double* j0) {
   if (!h) return LMPC_ERR_ARGUMENT;
@@ -1023,7 +1070,7 @@ int lmpc_ss_query_host(lmpc_handle* h, const double* query, double* ss_x, double
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&lmpc_ss_query_kernel),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(lmpc_ss_query_kernel, dim3(8), dim3(64), lds, h->stream, 1, h->ss_laps, S, h->cfg.num_ss_pts_per_lap,
-                     h->ss_npts, h->ss_off, h->ss_x, h->ss_L, d, d + 2, d + 2 + 6 * (size_t)S, di, d + 2 + 7 * (size_t)S);
+                     h->ss_npts, h->ss_off, h->ss_x, h->ss_L, d, d + 2, d + 2 + 6 * (size_t)S, di, d + 2 + 7 * (size_t)S, (int*)nullptr);
   HIP_TRY(h, hipGetLastError());
   HIP_TRY(h, hipMemcpyAsync(host, d, nd * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipMemcpyAsync(h->ssq_int_host, di, sizeof(int), hipMemcpyDeviceToHost, h->stream));

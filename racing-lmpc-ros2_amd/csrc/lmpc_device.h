@@ -38,6 +38,14 @@ struct lmpc_params {
   int hard_hull;  // all-zero convex_hull_slack: chs2 = 2 LMPC_HARD_HULL_WEIGHT and the residual is checked at the exit
   int out_aos;  // lmpc_set_output_layout: results [batch][knot][component] instead of [component][knot][batch]
   int reserved_;  // (keeps the block's layout)
+  // the safe set by reference (lmpc_solve_batch_ss_idx): S codes per problem from lmpc_ss_query_idx_batch, [S][B], and the lap
+  // store they point into (the handle's copy: lmpc_set_safe_set); ss_idx == null: the points arrive as arrays (ss_x, ss_j)
+  const int* ss_idx;
+  const double* ss_store;   // [rows][6]
+  const int* ss_npts;       // [ss_laps]
+  const int* ss_off;        // [ss_laps] first row of each lap
+  int ss_laps;
+  double ss_L;
   lmpc_vehicle veh;
 };
 

@@ -2411,31 +2411,95 @@ __device__ __forceinline__ void lmpc_solve_problem(
     treal* const UL = TT + TL_UL;
     sx.ul = UL;
     if (lane < 6) TT[TL_E + lane] = treal(P.chs2[lane]);
-    io c0[6];  // the differences are formed in the storage precision, the abscissa relative to the shift
+    // The safe set of this problem: as arrays (ss_x [6][S][B], ss_j [S][B]: lmpc_ss_query_batch wrote them), or BY REFERENCE
+    // (P.ss_idx, round 5): S codes from lmpc_ss_query_idx_batch, each naming a row of the lap store and which of its three
+    // unrolled copies; the point is read from the store (48 contiguous bytes, L2-resident: the whole store is < 0.2 MB) and its
+    // cost-to-go recomputed from the row -- the same expressions as lmpc_ss_query_kernel uses, so both routes give the same bits.
+    const bool by_ref = P.ss_idx != nullptr;
+    auto ss_point = [&](int j, io (&pt)[6], io& jv) {  // point j of this problem's safe set (storage precision) and its J (not yet relative)
+      const int code = P.ss_idx[(size_t)j * B + b];
+      if (code < 0) {
 #pragma unroll
-    for (int k = 0; k < 6; ++k) {
-      c0[k] = ss_x[((size_t)k * S) * B + b];
-      sx.ss0[k] = treal(k == 0 ? c0[k] - s_shift : c0[k]);
+        for (int k = 0; k < 6; ++k) pt[k] = io(0);
+        jv = io(0);
+        return;
+      }
+      const int row = code >> 2, rep = code & 3;
+      int l = 0;
+      for (int t = 1; t < P.ss_laps; ++t) l = (row >= P.ss_off[t]) ? t : l;
+      const int n = P.ss_npts[l], jj = row - P.ss_off[l];
+      const double* src = P.ss_store + (size_t)row * 6;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) pt[k] = io(src[k] + (k == 0 ? (rep - 1) * P.ss_L : 0.0));
+      jv = io((double)(n - 1 - jj) + (1 - rep) * (double)(n - 1));
+    };
+    io c0[6], j0v = io(0);  // the differences are formed in the storage precision, the abscissa relative to the shift
+    if (by_ref) {
+      ss_point(0, c0, j0v);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) c0[k] = ss_x[((size_t)k * S) * B + b];
     }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) sx.ss0[k] = treal(k == 0 ? c0[k] - s_shift : c0[k]);
 #pragma unroll
     for (int q = 0; q < KS; ++q) {
       const int j = lane + 64 * q;
       sx.on[q] = j < S;
       sx.uz[q] = 6 * (sx.on[q] ? j : S);
+      if (by_ref) {
+        io pt[6], jv = io(0);
+        if (sx.on[q]) {
+          ss_point(j, pt, jv);
 #pragma unroll
-      for (int k = 0; k < 6; ++k)
-        if (sx.on[q]) UL[6 * j + k] = treal(ss_x[((size_t)k * S + j) * B + b] - c0[k]);
+          for (int k = 0; k < 6; ++k) UL[6 * j + k] = treal(pt[k] - c0[k]);
+        }
+        sx.j[q] = sx.on[q] ? treal(jv - j0v) : treal(0);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+          if (sx.on[q]) UL[6 * j + k] = treal(ss_x[((size_t)k * S + j) * B + b] - c0[k]);
+        sx.j[q] = sx.on[q] ? treal(ss_j[(size_t)j * B + b]) : treal(0);
+      }
       if (q == 0 && lane < 6) UL[6 * S + lane] = treal(0);  // the zero point
-      sx.j[q] = sx.on[q] ? treal(ss_j[(size_t)j * B + b]) : treal(0);
-      sx.lm[q] = sx.on[q] ? 1.0 / S : 0.0;
-      sx.t[q] = sx.on[q] ? 1.0 / S : 1.0;
+    }
+    wave_fence();
+    // A point that repeats the one before it is dropped (round 5): it adds nothing to the hull, and two free copies of one point
+    // make the explicit points' system C_A singular -- the interior point's steps and the polish's multiplier steps then carry
+    // noise of 1e-4.  The padding of a set with fewer than S points is such a run (racing_mpc.cpp:263-272 repeats the last point
+    // S - n_found times): with 64 points found and 96 copies the answers were 5e-3 from the dense optimum, status OPTIMAL
+    // (scratch/r5/pad_check.py; the twin has the same rule).  X, U, dU are those of the full set; a run's weight sits on its first
+    // point, the copies report lambda = 0.
+    real n_on = 0.0;
+#pragma unroll
+    for (int q = 0; q < KS; ++q) {
+      const int j = lane + 64 * q;
+      bool dup = false;
+      if (sx.on[q] && j > 0) {
+        if (by_ref) {
+          dup = P.ss_idx[(size_t)j * B + b] == P.ss_idx[(size_t)(j - 1) * B + b];
+        } else {
+          dup = ss_j[(size_t)j * B + b] == ss_j[(size_t)(j - 1) * B + b];
+#pragma unroll
+          for (int k = 0; k < 6; ++k) dup = dup && UL[6 * j + k] == UL[6 * (j - 1) + k];
+        }
+      }
+      sx.on[q] = sx.on[q] && !dup;
+      sx.uz[q] = 6 * (sx.on[q] ? j : S);
+      sx.j[q] = sx.on[q] ? sx.j[q] : treal(0);
+      n_on += sx.on[q] ? real(1) : real(0);
+    }
+    const treal inv_on = treal(1) / treal(uni(wave_sum(n_on)));
+#pragma unroll
+    for (int q = 0; q < KS; ++q) {
+      sx.lm[q] = sx.on[q] ? inv_on : treal(0);
+      sx.t[q] = sx.on[q] ? inv_on : treal(1);
       sx.l[q] = 0.0;
       sx.p[q] = 0.0;
       sx.dl[q] = 0.0;
       sx.aidx[q] = -1;
       m_rows += sx.on[q] ? 1.0 : 0.0;
     }
-    wave_fence();
     treal umax = 0.0;  // largest u_j'E u_j of the (centred) points
 #pragma unroll
     for (int q = 0; q < KS; ++q) {
@@ -3298,7 +3362,7 @@ __device__ __forceinline__ void lmpc_solve_problem(
     if (lam_out) {
 #pragma unroll
       for (int q = 0; q < KS; ++q)
-        if (sx.on[q]) lam_out[(size_t)(lane + 64 * q) * B + b] = io(sx.lm[q]);
+        if (lane + 64 * q < S) lam_out[(size_t)(lane + 64 * q) * B + b] = sx.on[q] ? io(sx.lm[q]) : io(0);  // (a dropped copy: 0)
     }
   }
   if (lane == 0) {

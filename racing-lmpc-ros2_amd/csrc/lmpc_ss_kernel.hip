@@ -6,6 +6,10 @@
 // with the +-L unrolling and cost-to-go of SSTrajectory::process_lap_data (:116-137) done
 // arithmetically instead of being stored, and the pad / truncate / J - J[0] post-processing of
 // RacingMPC::solve (racing_mpc.cpp:263-280) fused in.
+// Index mode (ss_idx != NULL, round 5): instead of the 7 S doubles of (ss_x, ss_j) a query leaves S int32 codes
+//   code = ((row of the point in the concatenated lap store) << 2) | rep        (rep = 0, 1, 2: the -L, 0, +L copy; -1: no point)
+// and the learning kernel's prologue gathers the points from the L2-resident store itself (lmpc_solve_kernel.hip): 640 B per
+// query instead of 8960 B written here and read back there, and 4-byte stores that merge 16 to a line instead of 8.
 //   laps newest -> oldest while fewer than S points are collected; per lap the K points of the
 //   3n-point unrolled lap [x - L e_0, x, x + L e_0] nearest to the query in (s, e_y), nearest
 //   first (ties: lower unrolled index; CGAL's order for exact ties is unspecified); J of
@@ -36,7 +40,8 @@ __global__ __launch_bounds__(64) void lmpc_ss_query_kernel(int B, int n_laps, in
                                                            const int* __restrict__ npts, const int* __restrict__ off,
                                                            const double* __restrict__ x, double Lt,
                                                            const double* __restrict__ query, double* __restrict__ ss_x,
-                                                           double* __restrict__ ss_j, int* __restrict__ n_found, double* __restrict__ j0_out) {
+                                                           double* __restrict__ ss_j, int* __restrict__ n_found, double* __restrict__ j0_out,
+                                                           int* __restrict__ ss_idx) {
 #pragma clang fp contract(off)
   extern __shared__ __attribute__((aligned(16))) double dist[];
   // XCD-aware query assignment (as in the QP kernel): consecutive workgroups go round-robin to the 8 XCDs, so workgroup
@@ -48,6 +53,7 @@ __global__ __launch_bounds__(64) void lmpc_ss_query_kernel(int B, int n_laps, in
   int tot = 0;
   double last = 0.0;  // lane k < 6: component k of the last point written; lane 6: its J - J0
   double j0 = 0.0;
+  int last_code = -1;  // (index mode) the code of the last point taken: what the padding repeats
   for (int l = n_laps - 1; l >= 0 && tot < S; --l) {
     const int n = npts[l], n3 = 3 * n;
     const double* xl = x + (size_t)off[l] * 6;
@@ -135,10 +141,14 @@ __global__ __launch_bounds__(64) void lmpc_ss_query_kernel(int B, int n_laps, in
         const double jv = (double)(n - 1 - j) + (1 - rep) * (double)(n - 1);
         if (tot == 0) j0 = __shfl(jv, 0, 64);
         if (mine) {
+          if (ss_idx) {
+            ss_idx[(size_t)(tot + lane) * B + b] = ((off[l] + j) << 2) | rep;
+          } else {
 #pragma unroll
-          for (int k = 0; k < 6; ++k)
-            ss_x[((size_t)k * S + tot + lane) * B + b] = xl[(size_t)j * 6 + k] + (k == 0 ? (rep - 1) * Lt : 0.0);
-          ss_j[(size_t)(tot + lane) * B + b] = jv - j0;
+            for (int k = 0; k < 6; ++k)
+              ss_x[((size_t)k * S + tot + lane) * B + b] = xl[(size_t)j * 6 + k] + (k == 0 ? (rep - 1) * Lt : 0.0);
+            ss_j[(size_t)(tot + lane) * B + b] = jv - j0;
+          }
         }
         // the last point written, as the padding below wants it: component k on lane k < 6, J - J0 on lane 6
         const int il = __shfl(i, take - 1, 64);
@@ -147,6 +157,7 @@ __global__ __launch_bounds__(64) void lmpc_ss_query_kernel(int B, int n_laps, in
           last = xl[(size_t)jl * 6 + lane] + (lane == 0 ? (repl - 1) * Lt : 0.0);
         else if (lane == 6)
           last = ((double)(n - 1 - jl) + (1 - repl) * (double)(n - 1)) - j0;
+        last_code = ((off[l] + jl) << 2) | repl;
         tot += take;
         continue;
       }
@@ -170,7 +181,10 @@ __global__ __launch_bounds__(64) void lmpc_ss_query_kernel(int B, int n_laps, in
       const int rep = i / n, j = i - rep * n;
       const double jv = (double)(n - 1 - j) + (1 - rep) * (double)(n - 1);
       if (tot == 0) j0 = jv;
-      if (lane < 6) {
+      last_code = ((off[l] + j) << 2) | rep;
+      if (ss_idx) {
+        if (lane == 0) ss_idx[(size_t)tot * B + b] = last_code;
+      } else if (lane < 6) {
         last = xl[(size_t)j * 6 + lane] + (lane == 0 ? (rep - 1) * Lt : 0.0);
         ss_x[((size_t)lane * S + tot) * B + b] = last;
       } else if (lane == 6) {
@@ -211,6 +225,10 @@ __global__ __launch_bounds__(64) void lmpc_ss_query_kernel(int B, int n_laps, in
   // keeps its previous parameter values; a batch has no "previous", so the outputs are zero-filled -- defined data -- and
   // n_found = 0 tells the caller not to solve on them.
   if (tot == 0) last = 0.0;
+  if (ss_idx) {
+    for (int q = tot + lane; q < S; q += 64) ss_idx[(size_t)q * B + b] = last_code;
+    return;
+  }
   for (int q = tot; q < S; ++q) {
     if (lane < 6)
       ss_x[((size_t)lane * S + q) * B + b] = last;

@@ -670,7 +670,11 @@ def test_lmpc_at_other_horizons_matches_the_twin(pkg, N, n_laps):
 
     veh, cfg, tr, laps, inp, q = LS.make(32, 70 + N, N=N, n_laps=min(n_laps, 3))
     cfg = P.barc_lmpc(N, n_laps)
-    stored = (laps * 2)[:n_laps]                                       # up to six laps: the three recorded ones, repeated
+    # up to six laps: the three recorded ones, and the same laps driven 2 cm further left (DISTINCT points: until round 5 the
+    # recorded laps were simply repeated, which hands the solver every safe-set point twice -- two free copies of one point have no
+    # unique weights, the polish cannot verify such a set and since round 5 says so, LMPC_SOLVE_MAX_ITER, where the interior point's
+    # answer used to pass as OPTIMAL 6e-5 from the dense optimum; runs of identical points -- the padding -- are dropped by the kernel)
+    stored = (laps + [l + np.array([0.0, 0.02, 0.0, 0.0, 0.0, 0.0]) for l in laps])[:n_laps]
     # (n_laps = 1 / 6: the smallest and the largest safe set the kernel is instantiated for, 32 and 192 points)
     solver = pkg.Solver(pkg.presets.barc_lmpc(N, n_laps), pkg.presets.barc_vehicle(), device=0)
     solver.set_safe_set(stored, LS.L_BARC_SS)
