@@ -185,6 +185,21 @@ int lmpc_solve_batch(lmpc_handle* h, int32_t batch, const double* x_ic, const do
                      const double* ss_j, double* X_optm, double* U_optm, double* dU_optm,
                      double* convex_combi_optm, int32_t* status, int32_t* iters, double* kkt);
 
+/* lmpc_solve_batch with the reference's warm-start inputs USED (racing_mpc.cpp:293-305: X_optm_ref, U_optm_ref, dU_optm_ref; in
+ * the node they are the previous solution shifted by one knot, racing_mpc_node.cpp:245-254 -- the arrays lmpc_shift_batch writes).
+ * X_optm_ref [6][N][B], U_optm_ref [2][N-1][B] (dU_optm_ref is implied: u_i = u_{i-1} + t_i dU_i is a row of the QP); they may alias
+ * X_ref / U_ref, as they do in the node.  Before any interior point the kernel tries an ACTIVE-SET solve on the plan: the plan
+ * made dynamically exact about this call's linearisation, its active bounds taken as the working set, the equality-constrained
+ * QP solved and its KKT conditions verified (the polish's machinery; at most two repairs of the set).  Accepted -- 92 .. 96 % of
+ * the periods of a closed loop -- the answer is the optimum the cold solve finds (same 1e-6 contract; measured 1e-11 apart) for
+ * about two iterations' worth of work instead of seven; `iters` then counts the rounds (1 or 2).  Refused, the call IS
+ * lmpc_solve_batch (the rounds spent are added to `iters`).  A bad plan costs time, never correctness: nothing is returned that
+ * has not passed the KKT test of this problem.  fp64 tracking problem; learning handles are refused (LMPC_ERR_UNSUPPORTED). */
+int lmpc_solve_batch_warm(lmpc_handle* h, int32_t batch, const double* x_ic, const double* u_ic, const double* X_ref, const double* U_ref,
+                          const double* T_ref, const double* bound_left, const double* bound_right, const double* curvatures,
+                          const double* vel_ref, double total_length, const double* X_optm_ref, const double* U_optm_ref, double* X_optm,
+                          double* U_optm, double* dU_optm, int32_t* status, int32_t* iters, double* kkt);
+
 /* Mixed precision (BASELINE configs[4]: "mixed fp32/fp64 KKT"): same arguments, layouts and fp64 arrays as
  * lmpc_solve_batch.  In fp64: the linearisation (discrete_dynamics_jacobian), the error-dynamics regression onto it when
  * lmpc_set_regression_laps is in effect, the centring of the abscissa on x_ic[0], the 2x2 pivots of the Riccati

@@ -218,6 +218,8 @@ typedef struct {
   /* LMPC terminal block */
   double ssx[6][SMAX], ssj[SMAX], chs2[6]; /* safe-set points CENTRED on ss0 = first point; 2*convex_hull_slack */
   double ss0[6];
+  int warm;                       /* lmpc_oracle_solve_range_warm: (X_ref, U_ref) is the previous optimal plan, shifted */
+  double zw[NMAX][8], vw[NMAX][2]; /* that plan in the solver's variables */
   int S_in, ss_map[SMAX]; /* points as handed in, and which of them each kept point is (runs of identical points are one point) */
   int hard_hull; /* all-zero convex_hull_slack: the hull row is an equality, realised as the penalty limit */
   /* bounds per slot */
@@ -897,6 +899,9 @@ static void primal_update(prob_t* p, double alpha) {
 #define POLISH_ROUNDS 4
 #define POLISH_STEPS 4 /* at most; the loop stops after the second when that one moved the iterate by <= POLISH_STEP_OK */
 #define POLISH_STEP_OK 1e-7
+#define WARM_ROUNDS 2       /* repairs a warm start may spend before the cold start takes over */
+#define WARM_ACT 1e-9       /* a box row of the plan counts as active within this slack (physical units; a polished plan: ~1e-16) */
+#define WARM_ACT_EY 1e-3    /* boundary rows: their bounds move with the shift (the track half-width over one knot's travel) */
 #define POLISH_FEAS 1e-9
 #define POLISH_DUAL 1e-7
 #define POLISH_STRONG 1e3
@@ -919,8 +924,8 @@ typedef struct {
 } polish_t;
 
 /* (no auto-vectorisation: gcc 11 at -O3 -march=x86-64-v3 miscompiles the mixed int / double classification loop) */
-__attribute__((optimize("no-tree-vectorize"))) static int polish(prob_t* p, work_t* w, polish_t* q, int m_rows, int* rounds_out,
-                                                                  double* mu_out) {
+__attribute__((optimize("no-tree-vectorize"))) static int polish_rounds(prob_t* p, work_t* w, polish_t* q, int m_rows, int* rounds_out,
+                                                                         double* mu_out, int max_rounds) {
   const int N = p->N, S = p->S;
   memcpy(q->z, p->z, sizeof(q->z));
   memcpy(q->v, p->v, sizeof(q->v));
@@ -932,7 +937,7 @@ __attribute__((optimize("no-tree-vectorize"))) static int polish(prob_t* p, work
   for (int j = 0; j < S; ++j) q->heldl[j] = p->ll[j] > p->tl[j];
   int ok = 0;
   q->noise = 0;
-  for (int round = 0; round < POLISH_ROUNDS && !ok; ++round) {
+  for (int round = 0; round < max_rounds && !ok; ++round) {
     int nfree = 0;
     for (int j = 0; j < S; ++j) nfree += !q->heldl[j];
     if (S && nfree > MA_MAX) break;
@@ -1085,6 +1090,10 @@ __attribute__((optimize("no-tree-vectorize"))) static int polish(prob_t* p, work
   return ok;
 }
 
+static int polish(prob_t* p, work_t* w, polish_t* q, int m_rows, int* rounds_out, double* mu_out) {
+  return polish_rounds(p, w, q, m_rows, rounds_out, mu_out, POLISH_ROUNDS);
+}
+
 /* Solve the QP with a Mehrotra predictor-corrector interior-point method.  The iteration
  * stops when the average complementarity mu <= tol (default 3e-14) and every row residual is
  * below 1e-9.  Accuracy (DESIGN.md "numerics"): the cost-to-go is kept exactly symmetric and the last
@@ -1095,6 +1104,7 @@ __attribute__((optimize("no-tree-vectorize"))) static int polish(prob_t* p, work
 static int ipm_solve(prob_t* p, work_t* w, polish_t* pq, int* iters_out, double* kkt_out) {
   const int N = p->N, S = p->S;
   const double tau = 0.995, mu0 = 0.1, thr_frac = 0.5;
+  int warm_spent = 0;
   memset(w, 0, sizeof(work_t)); /* (the caller owns the allocation: one per range, not one mmap per solve) */
   /* ---- initial point: the minimiser of the cost over the dynamics alone (no inequality
    * rows, sigma = 0).  The linearised model can be open-loop unstable (|eig A| > 1 at low speed
@@ -1111,6 +1121,78 @@ static int ipm_solve(prob_t* p, work_t* w, polish_t* pq, int* iters_out, double*
   p->sigma = 0.0;
   w->frozen_lambda = 1;
   newton_factor(p, w, 0);
+  /* ---- warm start (lmpc_solve_batch_warm; the reference's X_optm_ref / U_optm_ref / dU_optm_ref, racing_mpc.cpp:293-305: in the
+   * node the reference IS the previous solution shifted, racing_mpc_node.cpp:245-254).  An active-set solve before any interior
+   * point: (1) the plan is made dynamically exact about the new linearisation by rolling it out under the Riccati feedback of
+   * the factorisation above, v_i = v_i^plan - K_i (z_i - z_i^plan) (the shifted plan misses the new dynamics by the
+   * linearisation's change and x_0 by the plant's step: a few 1e-3); (2) the working set is read off the PLAN -- a polished
+   * optimum sits on its active bounds to rounding, and the boxes do not move with the shift; the boundary rows' bounds do, by
+   * the track's change over one knot, so they are taken with a tolerance --; (3) the polish solves on that set, verifies the KKT
+   * conditions of THIS problem and repairs the set, WARM_ROUNDS times at most.  Accepted: the optimum, for the price of about two
+   * iterations.  Refused: the cold start below, as if nothing had happened (the attempt has cost about two more). */
+  if (p->warm && pq && !S) {
+    for (int i = 0; i < N - 1; ++i) {
+      for (int a = 0; a < 2; ++a) {
+        double acc = p->vw[i][a];
+        for (int c = 0; c < 8; ++c) acc -= p->K[i][a * 8 + c] * (p->z[i][c] - p->zw[i][c]);
+        p->v[i][a] = acc;
+      }
+      const double u0 = p->z[i][6] + p->dt[i] * p->v[i][0], u1 = p->z[i][7] + p->dt[i] * p->v[i][1];
+      for (int r = 0; r < 6; ++r) {
+        double acc = p->g[i][r] + p->B[i][r * 2] * u0 + p->B[i][r * 2 + 1] * u1;
+        for (int c = 0; c < 6; ++c) acc += p->A[i][r * 6 + c] * p->z[i][c];
+        p->z[i + 1][r] = acc;
+      }
+      p->z[i + 1][6] = u0;
+      p->z[i + 1][7] = u1;
+    }
+    /* the plan's boundary slack, then its working set */
+    double sgw = 0.0;
+    if (p->has_sigma)
+      for (int i = 0; i < N; ++i) {
+        if (p->act[i][SL_EY][0] && p->zw[i][1] - p->hi[i][SL_EY] > sgw) sgw = p->zw[i][1] - p->hi[i][SL_EY];
+        if (p->act[i][SL_EY][1] && p->lo[i][SL_EY] - p->zw[i][1] > sgw) sgw = p->lo[i][SL_EY] - p->zw[i][1];
+      }
+    p->sigma = sgw;
+    int mw = 0;
+    for (int i = 0; i < N; ++i)
+      for (int sl = 0; sl < NSLOT; ++sl) {
+        const double val = slot_val(p->zw, p->vw, i, sl), sg = (sl == SL_EY && p->has_sigma) ? sgw : 0.0;
+        const double tol = sl == SL_EY ? WARM_ACT_EY : WARM_ACT;
+        for (int sd = 0; sd < 2; ++sd) {
+          if (!p->act[i][sl][sd]) continue;
+          const double slack = sd == 0 ? (p->hi[i][sl] + sg - val) : (val + sg - p->lo[i][sl]);
+          const int held = slack <= tol;
+          p->t[i][sl][sd] = held ? 0.0 : (slack > 0.0 ? slack : 0.0);
+          p->lam[i][sl][sd] = held ? 1.0 : 0.0;
+          ++mw;
+        }
+      }
+    w->frozen_lambda = 0;
+    int wr = 0;
+    double wmu = 0.0;
+    if (polish_rounds(p, w, pq, mw, &wr, &wmu, WARM_ROUNDS)) {
+      *iters_out = wr;
+      if (kkt_out) {
+        kkt_out[0] = 0.0;
+        kkt_out[1] = 0.0;
+        kkt_out[2] = wmu;
+        kkt_out[3] = p->sigma;
+      }
+      return LMPC_SOLVE_OPTIMAL;
+    }
+    warm_spent = wr; /* the rounds a refused attempt took are counted with the solve's iterations */
+    /* refused: everything the attempt touched is set up again by the cold start */
+    memset(w->th, 0, sizeof(w->th));
+    memset(w->cf, 0, sizeof(w->cf));
+    memset(p->t, 0, sizeof(p->t));
+    memset(p->lam, 0, sizeof(p->lam));
+    for (int i = 1; i < N; ++i) memset(p->z[i], 0, sizeof(p->z[i]));
+    memset(p->v, 0, sizeof(p->v));
+    p->sigma = 0.0;
+    w->frozen_lambda = 1;
+    newton_factor(p, w, 0);
+  }
   for (int i = 0; i < N - 1; ++i) {
     for (int a = 0; a < 2; ++a) {
       double acc = 0.0;
@@ -1388,7 +1470,7 @@ static int ipm_solve(prob_t* p, work_t* w, polish_t* pq, int* iters_out, double*
     for (int k = 0; k < 6; ++k)
       if (fabs(w->eps_T[k]) * isc[k] > LMPC_HARD_HULL_RESIDUAL) status = LMPC_SOLVE_INFEASIBLE;
   }
-  *iters_out = it + pol_rounds; /* a polish round costs about what an iteration does and is counted as one */
+  *iters_out = it + pol_rounds + warm_spent; /* a polish round costs about what an iteration does and is counted as one */
   return status;
 }
 
@@ -1417,6 +1499,13 @@ static void setup_problem(prob_t* p, const lmpc_config* cfg, const lmpc_vehicle*
   }
   for (int k = 0; k < 6; ++k) p->z[0][k] = x_ic[(size_t)k * B + b];
   for (int k = 0; k < 2; ++k) p->z[0][6 + k] = u_ic[(size_t)k * B + b];
+  /* the reference as a plan in the solver's variables (used by the warm start only): z_i = [x_i; u_{i-1}], v_i = (u_i - u_{i-1}) / t_i */
+  for (int i = 0; i < N; ++i) {
+    for (int k = 0; k < 6; ++k) p->zw[i][k] = i == 0 ? p->z[0][k] : X_ref[(size_t)(k * N + i) * B + b];
+    for (int k = 0; k < 2; ++k) p->zw[i][6 + k] = i == 0 ? p->z[0][6 + k] : U_ref[(size_t)(k * (N - 1) + i - 1) * B + b];
+  }
+  for (int i = 0; i < N - 1; ++i)
+    for (int k = 0; k < 2; ++k) p->vw[i][k] = (U_ref[(size_t)(k * (N - 1) + i) * B + b] - p->zw[i][6 + k]) / p->dt[i];
   /* cost */
   const double qd[6] = {0.0, cfg->q_contour, cfg->q_heading, cfg->q_vel, cfg->q_vy, cfg->q_vyaw};
   for (int i = 0; i < N; ++i)
@@ -1510,6 +1599,14 @@ static int knot0_feasible(const prob_t* p, const lmpc_config* cfg) {
   return 1;
 }
 
+static int solve_range_impl(const lmpc_config* cfg, const lmpc_vehicle* veh, int32_t batch, int32_t b0,
+                            int32_t b1, const double* x_ic, const double* u_ic, const double* X_ref,
+                            const double* U_ref, const double* T_ref, const double* bound_left,
+                            const double* bound_right, const double* curvatures,
+                            const double* vel_ref, const double* ss_x, const double* ss_j,
+                            double* X_optm, double* U_optm, double* dU_optm, double* lambda_out,
+                            int32_t* status, int32_t* iters, double* kkt, int warm);
+
 /* Same signature family as lmpc_solve_batch (host pointers); b0..b1 is the slice solved. */
 int lmpc_oracle_solve_range(const lmpc_config* cfg, const lmpc_vehicle* veh, int32_t batch, int32_t b0,
                             int32_t b1, const double* x_ic, const double* u_ic, const double* X_ref,
@@ -1518,6 +1615,29 @@ int lmpc_oracle_solve_range(const lmpc_config* cfg, const lmpc_vehicle* veh, int
                             const double* vel_ref, const double* ss_x, const double* ss_j,
                             double* X_optm, double* U_optm, double* dU_optm, double* lambda_out,
                             int32_t* status, int32_t* iters, double* kkt) {
+  return solve_range_impl(cfg, veh, batch, b0, b1, x_ic, u_ic, X_ref, U_ref, T_ref, bound_left, bound_right, curvatures, vel_ref, ss_x, ss_j,
+                          X_optm, U_optm, dU_optm, lambda_out, status, iters, kkt, 0);
+}
+
+/* lmpc_solve_batch_warm: (X_ref, U_ref) is the previous optimal plan, shifted (see ipm_solve) */
+int lmpc_oracle_solve_range_warm(const lmpc_config* cfg, const lmpc_vehicle* veh, int32_t batch, int32_t b0,
+                                 int32_t b1, const double* x_ic, const double* u_ic, const double* X_ref,
+                                 const double* U_ref, const double* T_ref, const double* bound_left,
+                                 const double* bound_right, const double* curvatures,
+                                 const double* vel_ref, const double* ss_x, const double* ss_j,
+                                 double* X_optm, double* U_optm, double* dU_optm, double* lambda_out,
+                                 int32_t* status, int32_t* iters, double* kkt) {
+  return solve_range_impl(cfg, veh, batch, b0, b1, x_ic, u_ic, X_ref, U_ref, T_ref, bound_left, bound_right, curvatures, vel_ref, ss_x, ss_j,
+                          X_optm, U_optm, dU_optm, lambda_out, status, iters, kkt, 1);
+}
+
+static int solve_range_impl(const lmpc_config* cfg, const lmpc_vehicle* veh, int32_t batch, int32_t b0,
+                            int32_t b1, const double* x_ic, const double* u_ic, const double* X_ref,
+                            const double* U_ref, const double* T_ref, const double* bound_left,
+                            const double* bound_right, const double* curvatures,
+                            const double* vel_ref, const double* ss_x, const double* ss_j,
+                            double* X_optm, double* U_optm, double* dU_optm, double* lambda_out,
+                            int32_t* status, int32_t* iters, double* kkt, int warm) {
   const int N = cfg->N, B = batch;
   if (N < 3 || N > NMAX) return LMPC_ERR_ARGUMENT;
   if (cfg->learning && (cfg->num_ss_pts < 1 || cfg->num_ss_pts > SMAX)) return LMPC_ERR_ARGUMENT;
@@ -1533,6 +1653,7 @@ int lmpc_oracle_solve_range(const lmpc_config* cfg, const lmpc_vehicle* veh, int
   for (int b = b0; b < b1; ++b) {
     setup_problem(p, cfg, veh, B, b, x_ic, u_ic, X_ref, U_ref, T_ref, bound_left, bound_right,
                   curvatures, vel_ref, ss_x, ss_j);
+    p->warm = warm;
     int it = 0, st;
     double kk[4] = {0, 0, 0, 0};
     if (!knot0_feasible(p, cfg)) {

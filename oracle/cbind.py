@@ -82,7 +82,7 @@ def _c(a):
 
 
 def solve_batch(cfg: MPCConfig, veh: Vehicle, inp: dict, ss_x=None, ss_j=None, b0=0, b1=None,
-                max_iter: int = 0, tol: float = 0.0, polish: int = 0) -> dict:
+                max_iter: int = 0, tol: float = 0.0, polish: int = 0, warm: bool = False) -> dict:
     """inp as produced by oracle.scenario.cold_start_inputs (batch axis last)."""
     N = cfg.N
     B = inp["x_ic"].shape[-1]
@@ -98,7 +98,8 @@ def solve_batch(cfg: MPCConfig, veh: Vehicle, inp: dict, ss_x=None, ss_j=None, b
     iters = np.zeros(B, dtype=np.int32)
     kkt = np.zeros((4, B))
     cc, cv = c_config(cfg, max_iter, tol, polish), c_vehicle(veh)
-    rc = lib().lmpc_oracle_solve_range(C.byref(cc), C.byref(cv), C.c_int32(B), C.c_int32(b0), C.c_int32(b1),
+    fn = lib().lmpc_oracle_solve_range_warm if warm else lib().lmpc_oracle_solve_range
+    rc = fn(C.byref(cc), C.byref(cv), C.c_int32(B), C.c_int32(b0), C.c_int32(b1),
                                        *[_p(a) for a in arrs], _p(ss_x), _p(ss_j), _p(X), _p(U), _p(dU),
                                        _p(lam), _p(status), _p(iters), _p(kkt))
     if rc != 0:

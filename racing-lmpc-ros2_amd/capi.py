@@ -21,7 +21,7 @@ _ABI_SYMBOLS = ("lmpc_create", "lmpc_destroy", "lmpc_last_error", "lmpc_set_stre
                 "lmpc_last_kernel_ms", "lmpc_query_residency", "lmpc_query_launch_for", "lmpc_solve_host", "lmpc_shift_batch",
                 "lmpc_plant_step_batch", "lmpc_solve_full_dynamics_batch", "lmpc_solve_full_dynamics_host", "lmpc_set_regression_laps", "lmpc_regress_batch", "lmpc_ss_query_host", "lmpc_solve_batch_f32",
                 "lmpc_solve_batch_mixed", "lmpc_prepare_failed_batch", "lmpc_set_launch_order", "lmpc_launch_order_from_iters", "lmpc_set_output_layout",
-                "lmpc_ss_query_idx_batch", "lmpc_solve_batch_ss_idx")
+                "lmpc_ss_query_idx_batch", "lmpc_solve_batch_ss_idx", "lmpc_solve_batch_warm")
 
 
 class LmpcError(RuntimeError):
@@ -328,7 +328,7 @@ class Solver:
                 "iters": torch.empty((B,), dtype=torch.int32, device=self.device),
                 "kkt": torch.empty((4, B), **kw)}
 
-    def solve(self, inp: dict, out: dict | None = None, ss_x=None, ss_j=None, mixed: bool = False, ss_idx=None):
+    def solve(self, inp: dict, out: dict | None = None, ss_x=None, ss_j=None, mixed: bool = False, ss_idx=None, warm=None):
         """lmpc_solve_batch, or with mixed=True lmpc_solve_batch_mixed (same fp64 arrays, fp32 interior-point iteration); with
         ss_idx (int32 [S][B] from ss_query_idx) lmpc_solve_batch_ss_idx: the safe set by reference instead of ss_x / ss_j."""
         self.use_current_stream()
@@ -337,6 +337,16 @@ class Solver:
         B = a[0].shape[1]
         if out is None:
             out = self.alloc_outputs(B)
+        if warm is not None:
+            # lmpc_solve_batch_warm: warm = True takes (X_ref, U_ref) as the plan (what the node does), or a dict with X_optm_ref / U_optm_ref
+            wx = a[2] if warm is True else self._t(warm["X_optm_ref"])
+            wu = a[3] if warm is True else self._t(warm["U_optm_ref"])
+            rc = self.lib.lmpc_solve_batch_warm(self._h, C.c_int32(B), *[_ptr(t) for t in a], C.c_double(float(inp["L"])), _ptr(wx), _ptr(wu),
+                                                _ptr(out["X_optm"]), _ptr(out["U_optm"]), _ptr(out["dU_optm"]), _ptr(out["status"]),
+                                                _ptr(out["iters"]), _ptr(out.get("kkt")))
+            self._check(rc, "lmpc_solve_batch_warm")
+            out["_inputs_keepalive"] = a + [wx, wu]
+            return out
         if ss_idx is not None:
             rc = self.lib.lmpc_solve_batch_ss_idx(self._h, C.c_int32(B), C.c_int32(2 if mixed else 0), *[_ptr(t) for t in a],
                                                   C.c_double(float(inp["L"])), _ptr(ss_idx), _ptr(out["X_optm"]), _ptr(out["U_optm"]),

@@ -10,7 +10,7 @@ from __future__ import annotations
 
 
 def run(solver, track: dict, x0, u0, steps: int, dt: float = 0.025, n_sub: int = 2, speed_scale: float = 0.9,
-        record_every: int = 0, restart_failed: bool = True, graph: bool = False, longest_first: bool = False):
+        record_every: int = 0, restart_failed: bool = True, graph: bool = False, longest_first: bool = False, warm: bool = False):
     """x0 [6][B], u0 [2][B] (torch, device).  Returns final state and statistics (torch tensors on device).
 
     One control period = solve, apply the first input of the plan (on failure: of the shifted previous plan,
@@ -20,6 +20,10 @@ def run(solver, track: dict, x0, u0, steps: int, dt: float = 0.025, n_sub: int =
 
     graph=True captures the period once as a HIP graph and replays it: a period is ~25 small launches around the QP
     kernel, and eager dispatch (~2 ms of host time) costs more than the 0.9 ms the GPU needs for them.
+
+    warm=True solves with lmpc_solve_batch_warm: the shifted previous plan (what `inp["X_ref"]`, `inp["U_ref"]` hold from the second
+    period on, racing_mpc_node.cpp:245-254) is tried as an active-set solve before any interior point.  Returns the share of
+    solves that took that route as "warm_hit_rate" (iters <= 2: one or two polish rounds).
 
     longest_first=True launches the QP kernel's workgroups in the order of the previous period's iteration counts, longest
     first (lmpc_set_launch_order): a car's count changes little from one period to the next, and the long problems then
@@ -36,6 +40,7 @@ def run(solver, track: dict, x0, u0, steps: int, dt: float = 0.025, n_sub: int =
     dist = torch.zeros(B, dtype=torch.float64, device=x.device)         # abscissa travelled (unwrapped)
     worst_excess = torch.zeros(B, dtype=torch.float64, device=x.device)  # max lateral excursion beyond the track edge
     n_fail = torch.zeros(B, dtype=torch.int64, device=x.device)
+    hits = torch.zeros((), dtype=torch.int64, device=x.device)
     half_b = float(solver.vehicle["b"]) / 2.0
     keys = ("X_ref", "U_ref", "T_ref", "bound_left", "bound_right", "curvatures", "vel_ref")
     trace = []
@@ -47,7 +52,9 @@ def run(solver, track: dict, x0, u0, steps: int, dt: float = 0.025, n_sub: int =
     def period():
         inp["x_ic"] = x
         inp["u_ic"] = u_prev
-        solver.solve(inp, out)
+        solver.solve(inp, out, warm=True if warm else None)
+        if warm:
+            hits.add_(((out["status"] == 0) & (out["iters"] <= 2)).sum())
         if order is not None:
             solver.launch_order_from_iters(out["iters"], order)   # for the next period (in place: the pointer is registered)
         ok = out["status"] == 0
@@ -93,7 +100,8 @@ def run(solver, track: dict, x0, u0, steps: int, dt: float = 0.025, n_sub: int =
     if order is not None:
         torch.cuda.synchronize(x.device)
         solver.set_launch_order(None)
-    return {"x": x, "distance": dist, "worst_excess": worst_excess, "n_fail": n_fail, "trace": trace}
+    return {"x": x, "distance": dist, "worst_excess": worst_excess, "n_fail": n_fail, "trace": trace,
+            "warm_hit_rate": (float(hits) / (B * max(steps, 1))) if warm else None}
 
 
 def record_laps(solver, track: dict, speed_scales=(0.80, 0.85, 0.90, 0.95, 1.0), dt: float = 0.03, n_sub: int = 3):

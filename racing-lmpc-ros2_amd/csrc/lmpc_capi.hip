@@ -26,6 +26,9 @@ __global__ void lmpc_plant_kernel(lmpc_params, int, lmpc_track, double*, const d
 template <typename real, int KQ, int KS, typename io>
 __global__ void lmpc_solve_kernel(lmpc_params, int, const io*, const io*, const io*, const io*, const io*, const io*,
                                   const io*, const io*, const io*, io*, io*, io*, io*, int*, int*, io*);
+template <int KQ>
+__global__ void lmpc_solve_warm_kernel(lmpc_params, int, const double*, const double*, const double*, const double*, const double*, const double*,
+                                       const double*, double*, double*, double*, int*, int*, double*);
 __global__ void lmpc_ss_query_kernel(int, int, int, int, const int*, const int*, const double*, double, const double*,
                                      double*, double*, int*, double*, int*);
 __global__ void lmpc_reg_residual_kernel(lmpc_vehicle, int, int, const int*, const double*, const double*, const double*,
@@ -133,6 +136,7 @@ struct solve_args {
   double* kkt;
   bool aos;  // results [batch][knot][component]
   const int* ss_idx;  // learning: the safe set by reference (lmpc_solve_batch_ss_idx) instead of ss_x / ss_j
+  const double *warm_X, *warm_U;  // lmpc_solve_batch_warm: the plan of the active-set attempt (null: cold)
 };
 
 template <int KQ, int KS, typename real = double>
@@ -217,6 +221,8 @@ void set_ss_reference(const lmpc_handle* h, lmpc_params& P, const solve_args& a)
   P.ss_off = h->ss_off;
   P.ss_laps = h->ss_laps;
   P.ss_L = h->ss_L;
+  P.warm_X = a.warm_X;
+  P.warm_U = a.warm_U;
 }
 
 int launch_cleanup(lmpc_handle* h, const void* fn, const solve_args& a) {
@@ -242,6 +248,34 @@ int launch_cleanup(lmpc_handle* h, const void* fn, const solve_args& a) {
 #endif
   const int grid = (a.B < 1024 || wide) ? a.B : 1024;  // (a percent of a batch is marked: 1024 workgroups take them in one or two turns)
   HIP_TRY(h, hipLaunchKernel(fn, dim3(grid), dim3(64), args, a.lds_bytes, h->stream));
+  return LMPC_OK;
+}
+
+// the warm-start kernels (fp64 tracking): one per KQ
+const void* pick_warm_fn(int kq) {
+  switch (kq) {
+    case 2: return reinterpret_cast<const void*>(&lmpc_solve_warm_kernel<2>);
+    case 4: return reinterpret_cast<const void*>(&lmpc_solve_warm_kernel<4>);
+    case 7: return reinterpret_cast<const void*>(&lmpc_solve_warm_kernel<7>);
+    case 11: return reinterpret_cast<const void*>(&lmpc_solve_warm_kernel<11>);
+    case 14: return reinterpret_cast<const void*>(&lmpc_solve_warm_kernel<14>);
+  }
+  return nullptr;
+}
+
+int launch_solve_warm(lmpc_handle* h, const solve_args& a) {
+  const void* fn = pick_warm_fn(kq_for(h->P.N));
+  if (!fn) return fail(h, LMPC_ERR_UNSUPPORTED, "no warm-start kernel for this N");
+  HIP_TRY(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)a.lds_bytes));
+  lmpc_params P = h->P;
+  P.out_aos = a.aos ? 1 : 0;
+  set_ss_reference(h, P, a);
+  P.launch_order = (h->order && a.B == h->order_n) ? h->order : nullptr;
+  int B = a.B;
+  const double* ws = h->ws;
+  void* args[] = {(void*)&P, (void*)&B, (void*)&ws, (void*)&a.x_ic, (void*)&a.u_ic, (void*)&a.T_ref, (void*)&a.bl, (void*)&a.br,
+                  (void*)&a.vref, (void*)&a.X, (void*)&a.U, (void*)&a.dU, (void*)&a.status, (void*)&a.iters, (void*)&a.kkt};
+  HIP_TRY(h, hipLaunchKernel(fn, dim3(8 * ((a.B + 7) / 8)), dim3(64), args, a.lds_bytes, h->stream));
   return LMPC_OK;
 }
 
@@ -547,7 +581,7 @@ int solve_batch_fp64_arrays(lmpc_handle* h, bool mixed, bool aos, int32_t batch,
                             const double* bound_right, const double* curvatures, const double* vel_ref,
                             double total_length, const double* ss_x, const double* ss_j, double* X_optm, double* U_optm,
                             double* dU_optm, double* convex_combi_optm, int32_t* status, int32_t* iters, double* kkt,
-                            const int32_t* ss_idx = nullptr) {
+                            const int32_t* ss_idx = nullptr, const double* warm_X = nullptr, const double* warm_U = nullptr) {
   if (!h) return LMPC_ERR_ARGUMENT;
   (void)total_length;  // abscissa alignment (racing_mpc.cpp:219-223) shifts s only; the QP is invariant to it
   if (batch < 0 || !x_ic || !u_ic || !X_ref || !U_ref || !T_ref || !bound_left || !bound_right || !curvatures ||
@@ -589,6 +623,9 @@ int solve_batch_fp64_arrays(lmpc_handle* h, bool mixed, bool aos, int32_t batch,
   a.x_ic = x_ic; a.u_ic = u_ic; a.T_ref = T_ref; a.bl = bound_left; a.br = bound_right; a.vref = vel_ref;
   a.ss_x = (h->P.learning && !ss_idx) ? ss_x : nullptr; a.ss_j = (h->P.learning && !ss_idx) ? ss_j : nullptr;
   a.ss_idx = h->P.learning ? ss_idx : nullptr;
+  // the warm start is built into the fp64 tracking kernels; everywhere else the call is the cold solve it would fall back to
+  a.warm_X = (!mixed && !h->P.learning) ? warm_X : nullptr;
+  a.warm_U = (!mixed && !h->P.learning) ? warm_U : nullptr;
   a.lam = h->P.learning ? convex_combi_optm : nullptr;
   a.X = X_optm; a.U = U_optm; a.dU = dU_optm; a.status = status; a.iters = iters; a.kkt = kkt;
   a.aos = aos;
@@ -605,6 +642,8 @@ int solve_batch_fp64_arrays(lmpc_handle* h, bool mixed, bool aos, int32_t batch,
   int rc = LMPC_OK;
   if (two_pass && cleanup_all)
     HIP_TRY(h, hipMemsetD32Async((hipDeviceptr_t)status, LMPC_SOLVE_UNVERIFIED, (size_t)batch, h->stream));
+  else if (a.warm_X && a.warm_U)
+    rc = launch_solve_warm(h, a);
   else
     rc = launch_solve(h, fn, a, (mixed && h->P.polish >= 0) ? 1 : 0);
   if (rc != LMPC_OK) return rc;
@@ -638,6 +677,18 @@ int lmpc_solve_batch_mixed(lmpc_handle* h, int32_t batch, const double* x_ic, co
   return solve_batch_fp64_arrays(h, true, h && h->out_aos, batch, x_ic, u_ic, X_ref, U_ref, T_ref, bound_left, bound_right, curvatures,
                                  vel_ref, total_length, ss_x, ss_j, X_optm, U_optm, dU_optm, convex_combi_optm, status,
                                  iters, kkt);
+}
+
+int lmpc_solve_batch_warm(lmpc_handle* h, int32_t batch, const double* x_ic, const double* u_ic, const double* X_ref, const double* U_ref,
+                          const double* T_ref, const double* bound_left, const double* bound_right, const double* curvatures,
+                          const double* vel_ref, double total_length, const double* X_optm_ref, const double* U_optm_ref, double* X_optm,
+                          double* U_optm, double* dU_optm, int32_t* status, int32_t* iters, double* kkt) {
+  if (!h) return LMPC_ERR_ARGUMENT;
+  if (!X_optm_ref || !U_optm_ref) return fail(h, LMPC_ERR_ARGUMENT, "lmpc_solve_batch_warm: X_optm_ref / U_optm_ref is null");
+  if (h->P.learning) return fail(h, LMPC_ERR_UNSUPPORTED, "lmpc_solve_batch_warm: the tracking problem only (learning handles: lmpc_solve_batch)");
+  return solve_batch_fp64_arrays(h, false, h->out_aos, batch, x_ic, u_ic, X_ref, U_ref, T_ref, bound_left, bound_right, curvatures, vel_ref,
+                                 total_length, nullptr, nullptr, X_optm, U_optm, dU_optm, nullptr, status, iters, kkt, nullptr, X_optm_ref,
+                                 U_optm_ref);
 }
 
 int lmpc_solve_batch_ss_idx(lmpc_handle* h, int32_t batch, int32_t precision, const double* x_ic, const double* u_ic, const double* X_ref,

@@ -46,6 +46,9 @@ struct lmpc_params {
   const int* ss_off;        // [ss_laps] first row of each lap
   int ss_laps;
   double ss_L;
+  // warm start (lmpc_solve_batch_warm): the plan the active-set attempt starts from, [6][N][B] and [2][N-1][B]; null: a cold solve
+  const double* warm_X;
+  const double* warm_U;
   lmpc_vehicle veh;
 };
 

@@ -402,6 +402,9 @@ __device__ __forceinline__ float slot_inv_scale(int sl) {
 }
 #define POLISH_THETA_L 1e8  // the simplex rows (always fp64)
 #define POLISH_STRONG 1e3   // a row with lam >= POLISH_STRONG t is one the interior point holds firmly
+#define WARM_ROUNDS 2       // repairs a warm start may spend before the cold start takes over
+#define WARM_ACT 1e-9       // a box row of the plan counts as active within this slack (a polished plan sits on its bounds to ~1e-16)
+#define WARM_ACT_EY 1e-3    // boundary rows: their bounds move with the shift (the track's half-width over one knot's travel)
 template <typename real> struct vec2;
 template <> struct vec2<double> { typedef double2 type; };
 template <> struct vec2<float> { typedef float2 type; };
@@ -1224,7 +1227,10 @@ __device__ __forceinline__ void riccati_solve(const Lds<real>& L, int lane, Prof
 // The linearised model can be open-loop unstable (|eig A| > 1 at low speed with dt = 25 ms), so
 // the start trajectory is generated under the stabilising Riccati feedback.  Same lane roles as the
 // forward sweep of riccati_solve.
-template <typename real>
+// WARM (lmpc_solve_batch_warm): the rollout TRACKS a plan -- v_i = v_i^plan - K_i (z_i - z_i^plan) -- whose knots sit in the rhs0
+// cells of the knot records ([z^plan (8) | v^plan (2)] at KN_R0: free between the factorisation that has read its weights
+// there and the first gradient): the plan made dynamically exact about this linearisation, a few 1e-3 from where it was.
+template <bool WARM = false, typename real>
 __device__ __forceinline__ void feedback_rollout(const Lds<real>& L, int lane) {
   FRESH_LANE(lane, 4);
   const int N = L.N, r = lane & 7;
@@ -1248,7 +1254,13 @@ __device__ __forceinline__ void feedback_rollout(const Lds<real>& L, int lane) {
     const real ax = acc;
     acc = rfma(col[6], dz[6], acc);
     acc = rfma(col[7], dz[7], acc);
-    const real v = -acc;
+    real v = -acc;
+    if constexpr (WARM) {  // (lanes 6, 7: col = a row of K)  v = v^plan + K z^plan - K z
+      real kz = kn[KN_R0 + 8 + (r & 1)];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) kz = rfma(col[k], kn[KN_R0 + k], kz);
+      v += kz;
+    }
     const real u = rfma(t, v, (r == 6) ? dz[6] : dz[7]);
     const real u0 = lane_bcast(u, 6), u1 = lane_bcast(u, 7);
     const real nx = g + rfma(col[7], u1, rfma(col[6], u0, ax));
@@ -1548,7 +1560,7 @@ __device__ __forceinline__ void riccati_solve_lean_dpp(const Lds<real>& L, Model
   PT_MARK(10 + NRHS - 1)
 }
 
-template <typename real>
+template <bool WARM = false, typename real>
 __device__ __forceinline__ void feedback_rollout_lean(const Lds<real>& L, ModelStream<real>& M, int lane) {
   FRESH_LANE(lane, 6);
   const int N = L.N, r = lane & 7;
@@ -1578,7 +1590,13 @@ __device__ __forceinline__ void feedback_rollout_lean(const Lds<real>& L, ModelS
     const real ax = acc;
     acc = rfma(col[6], dz[6], acc);
     acc = rfma(col[7], dz[7], acc);
-    const real v = -acc;
+    real v = -acc;
+    if constexpr (WARM) {  // (lanes 6, 7: col = a row of K)  v = v^plan + K z^plan - K z
+      real kz = kn[KN_R0 + 8 + (r & 1)];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) kz = rfma(col[k], kn[KN_R0 + k], kz);
+      v += kz;
+    }
     const real u = rfma(t, v, (r == 6) ? dz[6] : dz[7]);
     const real u0 = lane_bcast(u, 6), u1 = lane_bcast(u, 7);
     const real nx = g + rfma(col[7], u1, rfma(col[6], u0, ax));
@@ -1614,6 +1632,7 @@ struct PolishArgs {
   void* keep;      // this problem's block of the save area
   const void* ws;  // lean layout: this problem's records in the linearisation workspace (ModelStream::ws)
   int N, S, has_sigma, have0, have1, pol_rounds;
+  int max_rounds;  // repairs this attempt may spend (polish_limits::rounds; fewer for a warm start)
   real qsig, inv_m, sigma;
   int o_val[KQ], o_hl[KQ], s_gf[KQ];
   real s_tu[KQ], s_tl[KQ], s_lu[KQ], s_ll[KQ];
@@ -1741,7 +1760,8 @@ __device__ __forceinline__ PolishResult<real, KS> lmpc_polish(const PolishArgs<r
   const real sigma_keep = sigma;
   put_keep();
   bool accepted = false, noise = false;
-  for (int round = 0; round < pol::rounds; ++round) {
+  const int max_rounds = min((int)pol::rounds, uni(a.max_rounds));
+  for (int round = 0; round < max_rounds; ++round) {
     if (round > 0) {  // every round starts from the interior point's iterate
       wave_sync();
       get_primal();
@@ -2218,7 +2238,7 @@ __host__ __device__ constexpr int lmpc_opaque_sites(int real_bytes, int kq, int 
 
 // SECOND: the fp64 second pass of a mixed solve -- a handful of problems a whole batch waits for, sharing the chip with the next batch's
 // first pass: its waves run at the top issue priority throughout (and do not drop it between chains).
-template <typename real, int KQ, int KS, typename io, bool SECOND = false>
+template <typename real, int KQ, int KS, typename io, bool SECOND = false, bool WARMK = false>  // (WARMK: the warm-start kernels, below)
 __device__ __forceinline__ void lmpc_solve_problem(
     const lmpc_params& P, const int B, const int b, unsigned char* lds_raw, const io* __restrict__ ws_lin,
     const io* __restrict__ x_ic, const io* __restrict__ u_ic, const io* __restrict__ T_ref, const io* __restrict__ bl,
@@ -2535,45 +2555,6 @@ __device__ __forceinline__ void lmpc_solve_problem(
   // degenerate row whenever the boundary is inactive (sigma* = 0, multiplier 0) and costs two to three iterations.
   real sigma = 0.0;
 
-  // ---------------- start point: minimiser of the cost over the dynamics alone ----------------
-#pragma unroll
-  for (int q = 0; q < KQ; ++q) {
-    lds[o_w(q)] = 0.0;
-    lds[o_csig(q)] = 0.0;
-  }
-  if constexpr (KS > 0) {  // lambda frozen at 1/S: terminal cost eps'D eps only
-    if (lane < 36) TT[TL_PT + lane] = (lane % 7 == 0) ? TT[TL_E + lane / 7] : treal(0);
-  }
-  wave_sync();
-  if constexpr (LEAN) {
-    riccati_factor_lean<(KS > 0), false>(L, MS, lane, TT + TL_PT);
-    feedback_rollout_lean(L, MS, lane);
-  } else {
-    riccati_factor<(KS > 0), false>(L, lane, TT + TL_PT);
-    feedback_rollout(L, lane);
-  }
-  if constexpr (KS > 0) {
-    treal ul[6] = {0, 0, 0, 0, 0, 0};
-#pragma unroll
-    for (int q = 0; q < KS; ++q) {
-      treal uq[6];
-      sx.load_u(q, lane, uq);
-#pragma unroll
-      for (int k = 0; k < 6; ++k) ul[k] += uq[k] * sx.lm[q];
-    }
-    wave_sum_split<6>(ul, lane);
-    if (lane < 6) {
-      treal e = 0.0;
-#pragma unroll
-      for (int k = 0; k < 6; ++k)
-        if (k == lane) e = (treal(L.kn(N - 1)[k]) - sx.ss0[k]) - ul[k];
-      TT[TL_EPS + lane] = e;
-      TT[TL_TG + lane] = TT[TL_E + lane] * e;
-    }
-    wave_sync();
-  }
-  PT_MARK(1)
-
   const real tau = 0.995, mu0 = 0.1, thr_frac = 0.5;
   int status = LMPC_SOLVE_MAX_ITER, it = 0;
   real mu = 0.0, rdmax = 0.0, rd_check = 0.0, last_step = 0.0, hsig = 0.0, ce = 0.0, mu_prev = inf;
@@ -2603,8 +2584,9 @@ __device__ __forceinline__ void lmpc_solve_problem(
   // attempt returns the wave-wide scalars and the simplex weights of the polished point (the point itself is in LDS), a
   // refused one has put everything back.
   bool pol_noise = false;
-  auto polish_attempt = [&]() -> bool {
+  auto polish_attempt = [&](int max_rounds) -> bool {
     PolishArgs<real, KQ, KS> pa;
+    pa.max_rounds = max_rounds;
     pa.keep = reinterpret_cast<io*>(P.save) + (size_t)b * (10 * N - 4);
     pa.ws = MS.ws;
     pa.N = N;
@@ -2668,11 +2650,133 @@ __device__ __forceinline__ void lmpc_solve_problem(
     return accepted;
   };
 
+  // ---------------- start point: minimiser of the cost over the dynamics alone ----------------
+  // ... preceded, in a warm solve (lmpc_solve_batch_warm; fp64 tracking kernels), by an ACTIVE-SET attempt on the plan the caller
+  // hands in -- the reference's X_optm_ref / U_optm_ref (racing_mpc.cpp:293-305), in the node the previous solution shifted by
+  // one knot (racing_mpc_node.cpp:245-254).  Attempt 0: (1) the same zero-weight factorisation as the cold start; (2) the plan is
+  // written into the rhs0 cells and rolled out under that factorisation's feedback, v = v^plan - K (z - z^plan): dynamically exact
+  // about THIS linearisation, a few 1e-3 from the plan (which misses the new dynamics by the linearisation's change and x_0 by the
+  // plant's step); (3) the working set is read off the PLAN: a polished optimum sits on its active bounds to rounding and the
+  // boxes do not move with the shift (WARM_ACT); the boundary rows' bounds do, by the track's change over one knot (WARM_ACT_EY);
+  // (4) the polish solves on that set, verifies the KKT conditions of this problem and repairs the set, WARM_ROUNDS times at
+  // most.  Accepted: the optimum for about two iterations' worth of sweeps -- 92 .. 96 % of the periods of a closed loop at
+  // N = 20 .. 60 on the serial twin (scratch/r5/warm_loop.py), iterations 6.5 -> 1.5 in the mean, answers those of the cold
+  // solve to 1e-11.  Refused: attempt 1, the cold start, as if nothing had happened (the rounds spent are counted in `iters`).
+  constexpr bool WARM_BUILT = WARMK && sizeof(real) == 8 && KS == 0 && sizeof(io) == 8;
+  const bool warm = WARM_BUILT && P.warm_X != nullptr && polish_on && feasible;
+  bool warm_done = false;
+  for (int attempt = warm ? 0 : 1; attempt < 2 && !warm_done; ++attempt) {
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) {
+      lds[o_w(q)] = 0.0;
+      lds[o_csig(q)] = 0.0;
+    }
+    if constexpr (KS > 0) {  // lambda frozen at 1/S: terminal cost eps'D eps only
+      if (lane < 36) TT[TL_PT + lane] = (lane % 7 == 0) ? TT[TL_E + lane / 7] : treal(0);
+    }
+    wave_sync();
+    if constexpr (LEAN)
+      riccati_factor_lean<(KS > 0), false>(L, MS, lane, TT + TL_PT);
+    else
+      riccati_factor<(KS > 0), false>(L, lane, TT + TL_PT);
+    if constexpr (WARM_BUILT) {
+      if (attempt == 0) {
+        // the plan in the solver's variables into the rhs0 cells: z_i = [x_i; u_{i-1}] (knot 0: the measured state and the applied
+        // input), v_i = (u_i - u_{i-1}) / t_i
+        const double* const WX = P.warm_X;
+        const double* const WU = P.warm_U;
+        for (int e = lane; e < 10 * N; e += 64) {
+          const int i = e / 10, o = e - 10 * i;
+          real val = 0.0;
+          if (o < 6) {
+            val = i == 0 ? KN0[o] : real(WX[((size_t)o * N + i) * B + b]);
+          } else if (o < 8) {
+            val = i == 0 ? KN0[o] : real(WU[((size_t)(o - 6) * NS + (i - 1)) * B + b]);
+          } else if (i < NS) {
+            const real up = i == 0 ? KN0[o - 2] : real(WU[((size_t)(o - 8) * NS + (i - 1)) * B + b]);
+            val = (real(WU[((size_t)(o - 8) * NS + i) * B + b]) - up) / real(T_ref[(size_t)i * B + b]);
+          }
+          L.kn(i)[KN_R0 + o] = val;
+        }
+        wave_sync();
+        if constexpr (LEAN)
+          feedback_rollout_lean<true>(L, MS, lane);
+        else
+          feedback_rollout<true>(L, lane);
+        // the plan's boundary slack, then its working set (the interior point's row state is what the polish classifies by:
+        // a held row gets lam = 1 > t = 0, every other row lam = 0 <= t = its slack)
+        real vw[KQ];
+        real2 hlw[KQ];
+        real sgmax = 0.0;
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) {
+          vw[q] = lds[o_val[q] + KN_R0];
+          hlw[q] = bounds(q);
+          const int f = flags(q);
+          if (f & F_SIG) sgmax = fmax(sgmax, fmax((f & F_UP) ? vw[q] - hlw[q].x : real(0), (f & F_LO) ? hlw[q].y - vw[q] : real(0)));
+        }
+        sigma = uni(wave_max(sgmax));
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) {
+          const int f = flags(q);
+          const real sg = (f & F_SIG) ? sigma : real(0), tolw = (f & F_EY) ? real(WARM_ACT_EY) : real(WARM_ACT);
+          const real su = hlw[q].x + sg - vw[q], sd = vw[q] + sg - hlw[q].y;
+          const bool hu = (f & F_UP) && su <= tolw, hd = (f & F_LO) && sd <= tolw;
+          s_tu[q] = hu ? real(0) : fmax(su, real(0));
+          s_tl[q] = hd ? real(0) : fmax(sd, real(0));
+          s_lu[q] = hu ? real(1) : real(0);
+          s_ll[q] = hd ? real(1) : real(0);
+          s_tu[q] = (f & F_UP) ? s_tu[q] : real(1);
+          s_tl[q] = (f & F_LO) ? s_tl[q] : real(1);
+        }
+        wave_sync();
+        if (polish_attempt(WARM_ROUNDS)) {
+          polished = true;
+          status = LMPC_SOLVE_OPTIMAL;
+          warm_done = true;
+        } else {  // refused: the cold start sets everything up again (row state: at the end of its Newton step)
+          sigma = 0.0;
+#pragma unroll
+          for (int q = 0; q < KQ; ++q) {
+            s_tu[q] = s_tl[q] = 1.0;
+            s_lu[q] = s_ll[q] = 0.0;
+          }
+        }
+        continue;
+      }
+    }
+    if constexpr (LEAN)
+      feedback_rollout_lean(L, MS, lane);
+    else
+      feedback_rollout(L, lane);
+  }
+  if constexpr (KS > 0) {
+    treal ul[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < KS; ++q) {
+      treal uq[6];
+      sx.load_u(q, lane, uq);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) ul[k] += uq[k] * sx.lm[q];
+    }
+    wave_sum_split<6>(ul, lane);
+    if (lane < 6) {
+      treal e = 0.0;
+#pragma unroll
+      for (int k = 0; k < 6; ++k)
+        if (k == lane) e = (treal(L.kn(N - 1)[k]) - sx.ss0[k]) - ul[k];
+      TT[TL_EPS + lane] = e;
+      TT[TL_TG + lane] = TT[TL_E + lane] * e;
+    }
+    wave_sync();
+  }
+  PT_MARK(1)
+
   // it == -1 is the start-point Newton step (all row weights zero, full step); it >= 0 the
   // interior-point iterations.  The iterations are the INNER loop; a polish attempt (a call) sits between two runs of it
   // (outer loop: at most twice round).
   it = -1;
-  for (;;) {
+  for (; !warm_done;) {
   int hand_over = 0;  // why the interior point stopped: 0 for good (status says why), 1 the early polish attempt, 2 the one at its exit,
                       // 3 out of iterations but close (single precision): a last attempt
   for (; it <= max_iter; ++it) {
@@ -3314,7 +3418,7 @@ __device__ __forceinline__ void lmpc_solve_problem(
   }
   if (hand_over == 0) break;
   wave_sync();
-  if (polish_attempt()) {
+  if (polish_attempt(pol::rounds)) {
     polished = true;
     status = LMPC_SOLVE_OPTIMAL;
     break;
@@ -3457,6 +3561,26 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
   }
 }
 
+// The warm-start solve (lmpc_solve_batch_warm) is a kernel of its own: compiled into lmpc_solve_kernel, the attempt's code changed
+// the register allocation of the cold path -- 992 -> 1296 B of scratch per lane at KQ = 11, 1796 -> 2128 B at KQ = 14, 132 more
+// spilled scalars in the headline kernel -- for callers that never pass a plan.  Same body, WARMK = true.
+template <int KQ>
+__global__ __launch_bounds__(64, lmpc_waves_per_simd(8, KQ, 0)) void lmpc_solve_warm_kernel(
+    lmpc_params P, int B, const double* __restrict__ ws_lin, const double* __restrict__ x_ic, const double* __restrict__ u_ic,
+    const double* __restrict__ T_ref, const double* __restrict__ bl, const double* __restrict__ br, const double* __restrict__ vref,
+    double* __restrict__ X_out, double* __restrict__ U_out, double* __restrict__ dU_out, int* __restrict__ status_out,
+    int* __restrict__ iters_out, double* __restrict__ kkt_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  int b = (int)(blockIdx.x & 7) * ((B + 7) >> 3) + (int)(blockIdx.x >> 3);  // (as lmpc_solve_kernel)
+  if (P.launch_order) {
+    const int n = P.order_count ? *P.order_count : B;
+    b = (int)blockIdx.x < n ? P.launch_order[blockIdx.x] : B;
+  }
+  if (b >= B) return;
+  lmpc_solve_problem<double, KQ, 0, double, false, true>(P, B, b, lds_raw, ws_lin, x_ic, u_ic, T_ref, bl, br, vref, nullptr, nullptr, nullptr, X_out,
+                                                         U_out, dU_out, status_out, iters_out, kkt_out);
+}
+
 #define LMPC_INSTANTIATE(REAL, KQ, KS, IO)                                                                              \
   template __global__ void lmpc_solve_kernel<REAL, KQ, KS, IO>(lmpc_params, int, const IO*, const IO*, const IO*,        \
                                                                 const IO*, const IO*, const IO*, const IO*, const IO*,    \
@@ -3468,6 +3592,14 @@ LMPC_INSTANTIATE_X(LMPC_SINGLE_INSTANCE)
 LMPC_INSTANTIATE(float, 4, 2, double)
 LMPC_INSTANTIATE(float, 4, 3, double)
 #else
+#define LMPC_INSTANTIATE_WARM(KQ)                                                                                        \
+  template __global__ void lmpc_solve_warm_kernel<KQ>(lmpc_params, int, const double*, const double*, const double*, const double*,   \
+                                                      const double*, const double*, const double*, double*, double*, double*, int*, int*, double*);
+LMPC_INSTANTIATE_WARM(2)
+LMPC_INSTANTIATE_WARM(4)
+LMPC_INSTANTIATE_WARM(7)
+LMPC_INSTANTIATE_WARM(11)
+LMPC_INSTANTIATE_WARM(14)
 LMPC_INSTANTIATE(double, 2, 0, double)
 LMPC_INSTANTIATE(double, 4, 0, double)
 LMPC_INSTANTIATE(double, 7, 0, double)
