@@ -29,9 +29,9 @@ ALGO_BYTES_PER_SOLVE = (13 * 20 + 5) * 8 + (10 * 20 - 4) * 8 + 8  # 3696 B at N 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
 
 
-def measured_traffic_bytes(pmc_file="r04_pmc.json", kernel="lmpc_solve_kernel<double, 4, 0"):
+def measured_traffic_bytes(pmc_file="r05_pmc_tracking.json", kernel="lmpc_solve_kernel<double, 4, 0"):
     """HBM bytes per launch of the QP kernel from the committed rocprofv3 PMC passes of this same command
-    (profiles/r04_pmc.json: FETCH_SIZE and WRITE_SIZE are reported in KiB, collected in separate --pmc runs).
+    (profiles/r05_pmc_tracking.json: FETCH_SIZE and WRITE_SIZE are reported in KiB, collected in separate --pmc runs).
     The gfx950 FETCH_SIZE x2 correction of MI355X_MICROARCH.md applies to wide coalesced streams only; this
     kernel's reads are 8-byte strided or L2/MALL-resident workspace lines, so the raw counter is reported."""
     try:
@@ -72,7 +72,7 @@ def live_counters(workload_argv, kernel, passes=PMC_PASSES):
             for n, group in enumerate(passes):
                 out = os.path.join(d, "pass%d" % n)
                 cmd = [exe, "--pmc", *group, "-d", out, "-o", "run", "--", sys.executable, str(ROOT / "bench.py"), "--steps", "5",
-                       "--warmup", "1", "--no-cpu-baseline", "--no-batch1", "--no-others", "--no-latency", "--streams", "1", "--no-pmc"] + workload_argv
+                       "--warmup", "1", "--no-cpu-baseline", "--no-batch1", "--no-others", "--no-latency", "--streams", "1", "--no-pmc", "--min-window", "0"] + workload_argv
                 proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
                 try:
                     proc.wait(timeout=90)
@@ -122,7 +122,7 @@ def live_engines(counters, kernel_ms):
     return e
 
 
-def engine_utilisation(kernel_ms, pmc_file="r04_pmc.json", kernel="lmpc_solve_kernel<double, 4, 0"):
+def engine_utilisation(kernel_ms, pmc_file="r05_pmc_tracking.json", kernel="lmpc_solve_kernel<double, 4, 0"):
     """What actually bounds the QP kernel: busy fractions of the FP64 VALU and of the LDS pipeline from the same
     committed PMC passes (SQ_ACTIVE_INST_VALU is in 4-cycle units summed over waves, one VALU per SIMD, 4 SIMDs x
     256 CUs; SQ_LDS_IDX_ACTIVE in cycles summed over the 256 CU-local LDS pipelines), against the kernel duration of
@@ -638,7 +638,7 @@ def main():
             #                                    640 B of codes + the points from the L2-resident store instead, the figure is kept as SURVEY states it)
         achieved = algo_bytes * B / (sol_avg * 1e-3) / 1e9
         # committed PMC passes of this command: tracking, or the learning problem with 160 safe-set points
-        pmc_sel = ("r04_pmc_lmpc.json", "lmpc_solve_kernel<double, 4, 3") if lmpc else ("r04_pmc.json", "lmpc_solve_kernel<double, 4, 0")
+        pmc_sel = ("r04_pmc_lmpc.json", "lmpc_solve_kernel<double, 4, 3") if lmpc else ("r05_pmc_tracking.json", "lmpc_solve_kernel<double, 4, 0")
         pmc_shape = not (N != 20 or B != 4096 or iac or f32 or mixed)  # the shape the committed passes were taken on
         traffic, traffic_source, counters = None, None, {}
         if world == 1 and not args.no_pmc:

@@ -248,6 +248,13 @@ int lmpc_solve_host(lmpc_handle* h, const double* x_ic, const double* u_ic, cons
                     double* U_optm, double* dU_optm, double* convex_combi_optm, int32_t* status,
                     int32_t* iters);
 
+/* lmpc_solve_batch_warm for ONE problem with HOST pointers (layouts of lmpc_solve_host; X_optm_ref 6 x N, U_optm_ref 2 x (N-1)
+ * column-major): what the facade's RacingMPC::solve calls when the warm-start keys are present and the controller has solved before. */
+int lmpc_solve_host_warm(lmpc_handle* h, const double* x_ic, const double* u_ic, const double* X_ref, const double* U_ref,
+                         const double* T_ref, const double* bound_left, const double* bound_right, const double* curvatures,
+                         const double* vel_ref, double total_length, const double* X_optm_ref, const double* U_optm_ref, double* X_optm,
+                         double* U_optm, double* dU_optm, int32_t* status, int32_t* iters);
+
 /* RacingMPC(full_dynamics = true)::solve for a batch (racing_mpc.cpp:67-84: IPOPT on the problem whose dynamics rows are
  * x_{i+1} = f_d(x_i, u_i, k_i, t_i), :162-166, instead of their linearisation; the node uses it for its very first
  * solve, racing_mpc_node.cpp:299-314).  Sequential QPs over the batched kernels, globalised by a backtracking line search

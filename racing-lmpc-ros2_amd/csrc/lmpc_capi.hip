@@ -417,7 +417,7 @@ int lmpc_create(const lmpc_config* cfg, const lmpc_vehicle* veh, int device, lmp
   for (auto& e : h->ev) HIP_TRY(h, hipEventCreate(&e));
   {  // staging of the single-problem host path, once
     const size_t N = (size_t)P.N, S = (size_t)P.S;
-    h->stage_doubles = 8 + 6 * N + 2 * (N - 1) + (N - 1) + 4 * N + 7 * S + 6 * N + 4 * (N - 1) + S + 2;
+    h->stage_doubles = 8 + 6 * N + 2 * (N - 1) + (N - 1) + 4 * N + 7 * S + 6 * N + 4 * (N - 1) + S + 2 + 6 * N + 2 * (N - 1);  // (+ a warm plan)
     HIP_TRY(h, hipMalloc(&h->stage_dev, h->stage_doubles * sizeof(double)));
     HIP_TRY(h, hipHostMalloc(&h->stage_host, h->stage_doubles * sizeof(double)));
     HIP_TRY(h, hipMalloc(&h->stage_int, 3 * sizeof(int)));
@@ -859,7 +859,8 @@ int solve_host_impl(lmpc_handle* h, const double* x_ic, const double* u_ic, cons
                     const double* T_ref, const double* bound_left, const double* bound_right, const double* curvatures,
                     const double* vel_ref, double total_length, const double* ss_x, const double* ss_j, double* X_optm,
                     double* U_optm, double* dU_optm, double* convex_combi_optm, int32_t* status, int32_t* iters,
-                    int max_sqp, double step_tol, int32_t* sqp_iters, double* sqp_move, double* defect) {
+                    int max_sqp, double step_tol, int32_t* sqp_iters, double* sqp_move, double* defect,
+                    const double* X_warm = nullptr, const double* U_warm = nullptr) {
   if (!h) return LMPC_ERR_ARGUMENT;
   if (!x_ic || !u_ic || !X_ref || !U_ref || !T_ref || !bound_left || !bound_right || !curvatures || !vel_ref ||
       !X_optm || !U_optm || !dU_optm || !status || !iters)
@@ -868,7 +869,8 @@ int solve_host_impl(lmpc_handle* h, const double* x_ic, const double* u_ic, cons
   // staging layout (doubles): inputs then outputs, each in the batch = 1 device layout
   const size_t o_x = 0, o_u = 6, o_X = 8, o_U = o_X + 6 * N, o_T = o_U + 2 * NS, o_bl = o_T + NS, o_br = o_bl + N,
                o_k = o_br + N, o_v = o_k + N, o_sx = o_v + N, o_sj = o_sx + 6 * (size_t)S, o_Xo = o_sj + S,
-               o_Uo = o_Xo + 6 * N, o_dUo = o_Uo + 2 * NS, o_lam = o_dUo + 2 * NS, o_mv = o_lam + S, total = o_mv + 2;
+               o_Uo = o_Xo + 6 * N, o_dUo = o_Uo + 2 * NS, o_lam = o_dUo + 2 * NS, o_mv = o_lam + S, o_wX = o_mv + 2, o_wU = o_wX + 6 * N,
+               total = o_wU + 2 * NS;
   HIP_TRY(h, hipSetDevice(h->device));
   if (total != h->stage_doubles || !h->stage_dev || !h->stage_host) return fail(h, LMPC_ERR_RUNTIME, "lmpc_solve_host: staging not allocated");
   double* const host = h->stage_host;  // pinned: the two copies below are asynchronous DMA transfers
@@ -894,6 +896,14 @@ int solve_host_impl(lmpc_handle* h, const double* x_ic, const double* u_ic, cons
     }
   double* d = h->stage_dev;
   HIP_TRY(h, hipMemcpyAsync(d, host, o_Xo * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  const bool warm = X_warm && U_warm && max_sqp <= 0 && !h->P.learning;
+  if (warm) {  // the plan, column-major -> [6][N] / [2][N-1]
+    for (int i = 0; i < N; ++i)
+      for (int k = 0; k < 6; ++k) host[o_wX + (size_t)k * N + i] = X_warm[(size_t)i * 6 + k];
+    for (int i = 0; i < NS; ++i)
+      for (int k = 0; k < 2; ++k) host[o_wU + (size_t)k * NS + i] = U_warm[(size_t)i * 2 + k];
+    HIP_TRY(h, hipMemcpyAsync(d + o_wX, host + o_wX, (total - o_wX) * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  }
   const int rc = max_sqp > 0
       ? lmpc_solve_full_dynamics_batch(h, 1, d + o_x, d + o_u, d + o_X, d + o_U, d + o_T, d + o_bl, d + o_br, d + o_k, d + o_v,
                                        total_length, S ? d + o_sx : nullptr, S ? d + o_sj : nullptr, max_sqp, step_tol,
@@ -901,10 +911,11 @@ int solve_host_impl(lmpc_handle* h, const double* x_ic, const double* u_ic, cons
                                        h->stage_int + 1, h->stage_int + 2, d + o_mv, d + o_mv + 1)
       : solve_batch_fp64_arrays(h, false, false, 1, d + o_x, d + o_u, d + o_X, d + o_U, d + o_T, d + o_bl, d + o_br, d + o_k, d + o_v,
                                 total_length, S ? d + o_sx : nullptr, S ? d + o_sj : nullptr, d + o_Xo, d + o_Uo,
-                                d + o_dUo, S ? d + o_lam : nullptr, h->stage_int, h->stage_int + 1, nullptr);  // (the staging buffer is unpacked as [6][N])
+                                d + o_dUo, S ? d + o_lam : nullptr, h->stage_int, h->stage_int + 1, nullptr,  // (the staging buffer is unpacked as [6][N])
+                                nullptr, warm ? d + o_wX : nullptr, warm ? d + o_wU : nullptr);
   if (rc != LMPC_OK) return rc;
   int* const si = h->stage_int_host;
-  HIP_TRY(h, hipMemcpyAsync(host + o_Xo, d + o_Xo, (total - o_Xo) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(host + o_Xo, d + o_Xo, (o_wX - o_Xo) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipMemcpyAsync(si, h->stage_int, 3 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   for (int i = 0; i < N; ++i)
@@ -931,6 +942,16 @@ int lmpc_solve_host(lmpc_handle* h, const double* x_ic, const double* u_ic, cons
                     double* U_optm, double* dU_optm, double* convex_combi_optm, int32_t* status, int32_t* iters) {
   return solve_host_impl(h, x_ic, u_ic, X_ref, U_ref, T_ref, bound_left, bound_right, curvatures, vel_ref, total_length, ss_x,
                          ss_j, X_optm, U_optm, dU_optm, convex_combi_optm, status, iters, 0, 0.0, nullptr, nullptr, nullptr);
+}
+
+int lmpc_solve_host_warm(lmpc_handle* h, const double* x_ic, const double* u_ic, const double* X_ref, const double* U_ref,
+                         const double* T_ref, const double* bound_left, const double* bound_right, const double* curvatures,
+                         const double* vel_ref, double total_length, const double* X_optm_ref, const double* U_optm_ref, double* X_optm,
+                         double* U_optm, double* dU_optm, int32_t* status, int32_t* iters) {
+  if (h && (!X_optm_ref || !U_optm_ref)) return fail(h, LMPC_ERR_ARGUMENT, "lmpc_solve_host_warm: X_optm_ref / U_optm_ref is null");
+  if (h && h->P.learning) return fail(h, LMPC_ERR_UNSUPPORTED, "lmpc_solve_host_warm: the tracking problem only");
+  return solve_host_impl(h, x_ic, u_ic, X_ref, U_ref, T_ref, bound_left, bound_right, curvatures, vel_ref, total_length, nullptr, nullptr,
+                         X_optm, U_optm, dU_optm, nullptr, status, iters, 0, 0.0, nullptr, nullptr, nullptr, X_optm_ref, U_optm_ref);
 }
 
 int lmpc_solve_full_dynamics_host(lmpc_handle* h, const double* x_ic, const double* u_ic, const double* X_ref,

@@ -67,12 +67,16 @@ void RacingMPC::solve(const DMDict& in, DMDict& out, Dict& stats) {
   const DM& vel_ref = in.at("vel_ref");
   // Warm start (racing_mpc.cpp:287-327).  With the keys: all four are required (upstream reads them with at()), and
   // T_optm_ref replaces T_ref.  Without them upstream restarts from its own previous solution -- and throws when there is
-  // none.  The interior-point solve does not use a primal warm start, so only the contract is kept: the keys are
-  // checked, and a controller that has never run its solver refuses a call without them.
+  // none.  Since round 5 the plan is USED by the tracking QP (lmpc_solve_host_warm: an active-set solve on it before any
+  // interior point; refused, the cold solve -- the same optimum either way); the learning problem and the sequential-QP solve
+  // keep the contract only: the keys are checked, and a controller that has never run its solver refuses a call without them.
   const bool warm = in.count("X_optm_ref") > 0;
+  const DM* X_warm = nullptr;
+  const DM* U_warm = nullptr;
   if (warm) {
-    (void)in.at("U_optm_ref");
-    (void)in.at("dU_optm_ref");
+    X_warm = &in.at("X_optm_ref");
+    U_warm = &in.at("U_optm_ref");
+    (void)in.at("dU_optm_ref");  // (implied by U_optm_ref and u_ic: u_i = u_{i-1} + t_i dU_i is a row of the QP)
   } else if (!ran_) {
     throw std::runtime_error("No warm start given and no previous solution found.");
   }
@@ -132,11 +136,23 @@ void RacingMPC::solve(const DMDict& in, DMDict& out, Dict& stats) {
     stats["dynamics_defect"] = defect;
     if (status == LMPC_SOLVE_OPTIMAL && !(move <= 1e-8)) status = LMPC_SOLVE_MAX_ITER;
   } else {
-    const int rc = lmpc_solve_host(h_, x_ic.data.data(), u_ic.data.data(), X_ref.data.data(), U_ref.data.data(),
-                                   T.data.data(), bound_left.data.data(), bound_right.data.data(),
-                                   curvatures.data.data(), vel_ref.data.data(), total_length, S ? ss_x_.data() : nullptr,
-                                   S ? ss_j_.data() : nullptr, X.data.data(), U.data.data(), dU.data.data(),
-                                   S ? lam.data.data() : nullptr, &status, &iters);
+    // a plan is worth trying once the controller has a solution behind it (the node's first call hands the zero-input rollout)
+    const bool use_plan = warm && ran_ && !S && X_warm->rows == 6 && X_warm->cols == N && U_warm->rows == 2 && U_warm->cols == N - 1;
+    DM Xw;
+    if (use_plan) {  // the same abscissa alignment as X_ref (racing_mpc.cpp:297-301)
+      Xw = *X_warm;
+      for (std::size_t i = 0; i < N; ++i) Xw(0, i) = align_abscissa(Xw(0, i), x_ic(0, 0), total_length);
+    }
+    const int rc = use_plan
+        ? lmpc_solve_host_warm(h_, x_ic.data.data(), u_ic.data.data(), X_ref.data.data(), U_ref.data.data(), T.data.data(),
+                               bound_left.data.data(), bound_right.data.data(), curvatures.data.data(), vel_ref.data.data(), total_length,
+                               Xw.data.data(), U_warm->data.data(), X.data.data(), U.data.data(), dU.data.data(), &status, &iters)
+        : lmpc_solve_host(h_, x_ic.data.data(), u_ic.data.data(), X_ref.data.data(), U_ref.data.data(),
+                          T.data.data(), bound_left.data.data(), bound_right.data.data(),
+                          curvatures.data.data(), vel_ref.data.data(), total_length, S ? ss_x_.data() : nullptr,
+                          S ? ss_j_.data() : nullptr, X.data.data(), U.data.data(), dU.data.data(),
+                          S ? lam.data.data() : nullptr, &status, &iters);
+    stats["warm_start"] = use_plan ? 1.0 : 0.0;
     if (rc != LMPC_OK) {
       std::cerr << "RacingMPC::solve: " << lmpc_last_error(h_) << '\n';
       return;

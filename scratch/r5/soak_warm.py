@@ -18,15 +18,15 @@ torch.cuda.synchronize(); _sv.close()
 for N in (20, 60):
     steps = int(3.2 * tab["L"] / 3.0 / 0.025) if N == 20 else 200
     res = {}
-    for graph, warm in ((True, False), (True, True), (False, True)):
+    for graph, warm, lf in ((True, False, False), (True, True, False), (False, True, False), (True, True, True)):
         solver = pkg.Solver(dict(pkg.presets.barc_tracking_mpc(N)), pkg.presets.barc_vehicle(), 0)
         torch.cuda.synchronize(); t0 = time.time()
-        r = pkg.closed_loop.run(solver, tab, torch.as_tensor(x0, device="cuda"), torch.zeros((2, B), dtype=torch.float64, device="cuda"), steps=steps, speed_scale=0.9, graph=graph, warm=warm)
+        r = pkg.closed_loop.run(solver, tab, torch.as_tensor(x0, device="cuda"), torch.zeros((2, B), dtype=torch.float64, device="cuda"), steps=steps, speed_scale=0.9, graph=graph, warm=warm, longest_first=lf)
         torch.cuda.synchronize(); dt = time.time() - t0
         d = r["distance"].cpu().numpy(); f = r["n_fail"].cpu().numpy()
-        res[(graph, warm)] = (r["x"].cpu().numpy(), f)
-        print("N = %d graph=%s warm=%s: %d cars x %d periods in %.2f s (%.2f M car-steps/s, %.3f ms per period); warm hit rate %s; laps median %.2f; cars with a failed solve: %d"
-              % (N, graph, warm, B, steps, dt, B * steps / dt / 1e6, dt / steps * 1e3, ("%.4f" % r["warm_hit_rate"]) if warm else "-", np.median(d) / tab["L"], (f > 0).sum()), flush=True)
+        res[(graph, warm)] = res.get((graph, warm)) if lf else (r["x"].cpu().numpy(), f)
+        print(("N = %d graph=%s warm=%s" + (" longest-first" if lf else "") + ": %d cars x %d periods in %.2f s (%.2f M car-steps/s, %.3f ms per period); warm hit rate %s; laps median %.2f; cars with a failed solve: %d"
+               ) % (N, graph, warm, B, steps, dt, B * steps / dt / 1e6, dt / steps * 1e3, ("%.4f" % r["warm_hit_rate"]) if warm else "-", np.median(d) / tab["L"], (f > 0).sum()), flush=True)
         solver.close()
     (xc, fc), (xw, fw) = res[(True, False)], res[(True, True)]
     same = (fc == 0) & (fw == 0)
