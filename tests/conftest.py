@@ -1,5 +1,13 @@
+import os
 import sys
 from pathlib import Path
+
+# The dense oracle factorises 400 .. 1500-row matrices a few thousand times per suite.  On a box that shows a hundred cores to a
+# container allowed sixteen, OpenBLAS starts a thread per visible core and a 30 ms factorisation takes 1.3 s: the suite spent most of
+# its time there.  Four threads (set before numpy loads where possible, and again through threadpoolctl below for the case where a
+# plugin has imported numpy first).
+os.environ.setdefault("OMP_NUM_THREADS", "4")
+os.environ.setdefault("OPENBLAS_NUM_THREADS", "4")
 
 import pytest
 
@@ -10,6 +18,17 @@ if str(ROOT) not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _blas_threads():
+    try:
+        from threadpoolctl import threadpool_limits
+    except ImportError:
+        yield
+        return
+    with threadpool_limits(limits=4):
+        yield
 
 
 @pytest.fixture(scope="session")
