@@ -1478,6 +1478,18 @@ static int ipm_solve(prob_t* p, work_t* w, polish_t* pq, int* iters_out, double*
 /* problem set-up from the C-ABI style inputs (batch axis fastest)                             */
 /* ------------------------------------------------------------------------------------------ */
 
+/* the caller's plan in the solver's variables (used by the warm start only): z_i = [x_i; u_{i-1}], v_i = (u_i - u_{i-1}) / t_i.
+   lmpc_solve_batch_warm's (X_plan, U_plan); when the plan is the linearisation trajectory itself, (X_ref, U_ref). */
+static void set_plan(prob_t* p, int B, int b, const double* X_plan, const double* U_plan) {
+  const int N = p->N;
+  for (int i = 0; i < N; ++i) {
+    for (int k = 0; k < 6; ++k) p->zw[i][k] = i == 0 ? p->z[0][k] : X_plan[(size_t)(k * N + i) * B + b];
+    for (int k = 0; k < 2; ++k) p->zw[i][6 + k] = i == 0 ? p->z[0][6 + k] : U_plan[(size_t)(k * (N - 1) + i - 1) * B + b];
+  }
+  for (int i = 0; i < N - 1; ++i)
+    for (int k = 0; k < 2; ++k) p->vw[i][k] = (U_plan[(size_t)(k * (N - 1) + i) * B + b] - p->zw[i][6 + k]) / p->dt[i];
+}
+
 static void setup_problem(prob_t* p, const lmpc_config* cfg, const lmpc_vehicle* veh, int B, int b,
                           const double* x_ic, const double* u_ic, const double* X_ref,
                           const double* U_ref, const double* T_ref, const double* bl,
@@ -1499,13 +1511,6 @@ static void setup_problem(prob_t* p, const lmpc_config* cfg, const lmpc_vehicle*
   }
   for (int k = 0; k < 6; ++k) p->z[0][k] = x_ic[(size_t)k * B + b];
   for (int k = 0; k < 2; ++k) p->z[0][6 + k] = u_ic[(size_t)k * B + b];
-  /* the reference as a plan in the solver's variables (used by the warm start only): z_i = [x_i; u_{i-1}], v_i = (u_i - u_{i-1}) / t_i */
-  for (int i = 0; i < N; ++i) {
-    for (int k = 0; k < 6; ++k) p->zw[i][k] = i == 0 ? p->z[0][k] : X_ref[(size_t)(k * N + i) * B + b];
-    for (int k = 0; k < 2; ++k) p->zw[i][6 + k] = i == 0 ? p->z[0][6 + k] : U_ref[(size_t)(k * (N - 1) + i - 1) * B + b];
-  }
-  for (int i = 0; i < N - 1; ++i)
-    for (int k = 0; k < 2; ++k) p->vw[i][k] = (U_ref[(size_t)(k * (N - 1) + i) * B + b] - p->zw[i][6 + k]) / p->dt[i];
   /* cost */
   const double qd[6] = {0.0, cfg->q_contour, cfg->q_heading, cfg->q_vel, cfg->q_vy, cfg->q_vyaw};
   for (int i = 0; i < N; ++i)
@@ -1605,7 +1610,7 @@ static int solve_range_impl(const lmpc_config* cfg, const lmpc_vehicle* veh, int
                             const double* bound_right, const double* curvatures,
                             const double* vel_ref, const double* ss_x, const double* ss_j,
                             double* X_optm, double* U_optm, double* dU_optm, double* lambda_out,
-                            int32_t* status, int32_t* iters, double* kkt, int warm);
+                            int32_t* status, int32_t* iters, double* kkt, int warm, const double* X_plan, const double* U_plan);
 
 /* Same signature family as lmpc_solve_batch (host pointers); b0..b1 is the slice solved. */
 int lmpc_oracle_solve_range(const lmpc_config* cfg, const lmpc_vehicle* veh, int32_t batch, int32_t b0,
@@ -1616,7 +1621,7 @@ int lmpc_oracle_solve_range(const lmpc_config* cfg, const lmpc_vehicle* veh, int
                             double* X_optm, double* U_optm, double* dU_optm, double* lambda_out,
                             int32_t* status, int32_t* iters, double* kkt) {
   return solve_range_impl(cfg, veh, batch, b0, b1, x_ic, u_ic, X_ref, U_ref, T_ref, bound_left, bound_right, curvatures, vel_ref, ss_x, ss_j,
-                          X_optm, U_optm, dU_optm, lambda_out, status, iters, kkt, 0);
+                          X_optm, U_optm, dU_optm, lambda_out, status, iters, kkt, 0, NULL, NULL);
 }
 
 /* lmpc_solve_batch_warm: (X_ref, U_ref) is the previous optimal plan, shifted (see ipm_solve) */
@@ -1628,7 +1633,21 @@ int lmpc_oracle_solve_range_warm(const lmpc_config* cfg, const lmpc_vehicle* veh
                                  double* X_optm, double* U_optm, double* dU_optm, double* lambda_out,
                                  int32_t* status, int32_t* iters, double* kkt) {
   return solve_range_impl(cfg, veh, batch, b0, b1, x_ic, u_ic, X_ref, U_ref, T_ref, bound_left, bound_right, curvatures, vel_ref, ss_x, ss_j,
-                          X_optm, U_optm, dU_optm, lambda_out, status, iters, kkt, 1);
+                          X_optm, U_optm, dU_optm, lambda_out, status, iters, kkt, 1, X_ref, U_ref);
+}
+
+/* lmpc_solve_batch_warm with its own plan arguments: linearised along (X_ref, U_ref), started from (X_plan, U_plan) */
+int lmpc_oracle_solve_range_warm_plan(const lmpc_config* cfg, const lmpc_vehicle* veh, int32_t batch, int32_t b0,
+                                      int32_t b1, const double* x_ic, const double* u_ic, const double* X_ref,
+                                      const double* U_ref, const double* T_ref, const double* bound_left,
+                                      const double* bound_right, const double* curvatures,
+                                      const double* vel_ref, const double* ss_x, const double* ss_j,
+                                      const double* X_plan, const double* U_plan,
+                                      double* X_optm, double* U_optm, double* dU_optm, double* lambda_out,
+                                      int32_t* status, int32_t* iters, double* kkt) {
+  if (!X_plan || !U_plan) return LMPC_ERR_ARGUMENT;
+  return solve_range_impl(cfg, veh, batch, b0, b1, x_ic, u_ic, X_ref, U_ref, T_ref, bound_left, bound_right, curvatures, vel_ref, ss_x, ss_j,
+                          X_optm, U_optm, dU_optm, lambda_out, status, iters, kkt, 1, X_plan, U_plan);
 }
 
 static int solve_range_impl(const lmpc_config* cfg, const lmpc_vehicle* veh, int32_t batch, int32_t b0,
@@ -1637,7 +1656,7 @@ static int solve_range_impl(const lmpc_config* cfg, const lmpc_vehicle* veh, int
                             const double* bound_right, const double* curvatures,
                             const double* vel_ref, const double* ss_x, const double* ss_j,
                             double* X_optm, double* U_optm, double* dU_optm, double* lambda_out,
-                            int32_t* status, int32_t* iters, double* kkt, int warm) {
+                            int32_t* status, int32_t* iters, double* kkt, int warm, const double* X_plan, const double* U_plan) {
   const int N = cfg->N, B = batch;
   if (N < 3 || N > NMAX) return LMPC_ERR_ARGUMENT;
   if (cfg->learning && (cfg->num_ss_pts < 1 || cfg->num_ss_pts > SMAX)) return LMPC_ERR_ARGUMENT;
@@ -1654,6 +1673,7 @@ static int solve_range_impl(const lmpc_config* cfg, const lmpc_vehicle* veh, int
     setup_problem(p, cfg, veh, B, b, x_ic, u_ic, X_ref, U_ref, T_ref, bound_left, bound_right,
                   curvatures, vel_ref, ss_x, ss_j);
     p->warm = warm;
+    if (warm) set_plan(p, B, b, X_plan, U_plan);
     int it = 0, st;
     double kk[4] = {0, 0, 0, 0};
     if (!knot0_feasible(p, cfg)) {
