@@ -62,19 +62,33 @@ ShardedSolver::ShardedSolver(const lmpc_config& cfg, const lmpc_vehicle& veh, co
     if (rc != ncclSuccess) throw std::runtime_error(std::string("ncclCommInitAll: ") + ncclGetErrorString(rc));
     for (std::size_t r = 0; r < devices.size(); ++r) shards_[r].comm = comms[r];
   }
-  for (Shard& s : shards_) s.worker = std::thread([this, &s] { run(s); });
-  issue(CMD_INIT);
+  // A constructor that throws does not run the destructor, and a joinable std::thread that is destroyed terminates the process:
+  // whatever fails from here on, the workers are told to quit (they release what they created, on their device) and joined first.
+  try {
+    for (Shard& s : shards_) s.worker = std::thread([this, &s] { run(s); });
+    issue(CMD_INIT);
+  } catch (...) {
+    quit();
+    throw;
+  }
 }
 
-ShardedSolver::~ShardedSolver() {
+ShardedSolver::~ShardedSolver() { quit(); }
+
+void ShardedSolver::quit() {
   {
     std::lock_guard<std::mutex> lk(mu_);
     cmd_ = CMD_QUIT;
     ++generation_;
   }
   cv_go_.notify_all();
-  for (Shard& s : shards_)
-    if (s.worker.joinable()) s.worker.join();
+  for (Shard& s : shards_) {
+    if (s.worker.joinable())
+      s.worker.join();  // (the worker destroyed its communicator, handle, stream and buffers)
+    else if (s.comm)    // its thread never started (std::thread's constructor threw)
+      (void)ncclCommDestroy(static_cast<ncclComm_t>(s.comm));
+    s.comm = nullptr;
+  }
 }
 
 void ShardedSolver::run(Shard& s) {
@@ -165,11 +179,14 @@ int ShardedSolver::do_track(Shard& s) {
   double* t[4] = {nullptr, nullptr, nullptr, nullptr};
   const double* src[4] = {t_kap_, t_bl_, t_br_, t_vel_};
   for (int k = 0; k < 4; ++k) {
-    if (dmalloc(&t[k], M)) {
-      s.error = "hipMalloc failed";
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&t[k]), M * sizeof(double));
+    if (e == hipSuccess) e = hipMemcpy(t[k], src[k], M * sizeof(double), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {  // the tables in use stay in use
+      for (double* q : t)
+        if (q) (void)hipFree(q);
+      s.error = std::string("track tables: ") + hipGetErrorString(e);
       return -1;
     }
-    SH_HIP(s, hipMemcpy(t[k], src[k], M * sizeof(double), hipMemcpyHostToDevice));
   }
   for (const double* p : {s.track.curvature, s.track.bound_left, s.track.bound_right, s.track.vel})
     if (p) (void)hipFree(const_cast<double*>(p));

@@ -88,6 +88,7 @@ class ShardedSolver {
   enum Command { CMD_NONE, CMD_INIT, CMD_TRACK, CMD_PREPARE, CMD_SOLVE, CMD_QUIT };
   void run(Shard& s);
   void issue(Command c);  // wake every worker with `c`, wait for all, throw the first error
+  void quit();            // CMD_QUIT + join (destructor, and a constructor that is about to throw)
   int do_init(Shard& s);
   int do_track(Shard& s);
   int do_prepare(Shard& s);
