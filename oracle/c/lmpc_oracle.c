@@ -894,8 +894,12 @@ static void primal_update(prob_t* p, double alpha) {
  * the same).  The terminal block can hold at most MA_MAX free simplex weights explicitly; with more the polish is not
  * attempted. */
 #define POLISH_THETA 1e8
+#ifndef POLISH_MU /* (scratch/r5/twin_variant.py builds variants with -D) */
 #define POLISH_MU 1e-8
+#endif
+#ifndef POLISH_RD
 #define POLISH_RD 1e-6
+#endif
 #define POLISH_ROUNDS 4
 #define POLISH_STEPS 4 /* at most; the loop stops after the second when that one moved the iterate by <= POLISH_STEP_OK */
 #define POLISH_STEP_OK 1e-7
@@ -1103,7 +1107,12 @@ static int polish(prob_t* p, work_t* w, polish_t* q, int m_rows, int* rounds_out
  * degenerate problems, where any interior point is O(sqrt(mu)) away.                                 */
 static int ipm_solve(prob_t* p, work_t* w, polish_t* pq, int* iters_out, double* kkt_out) {
   const int N = p->N, S = p->S;
-  const double tau = 0.995, mu0 = 0.1, thr_frac = 0.5;
+#ifndef IPM_TAU /* (scratch/r5/twin_variant.py builds variants with -D) */
+#define IPM_TAU 0.995
+#define IPM_MU0 0.1
+#define IPM_THR 0.5
+#endif
+  const double tau = IPM_TAU, mu0 = IPM_MU0, thr_frac = IPM_THR;
   int warm_spent = 0;
   memset(w, 0, sizeof(work_t)); /* (the caller owns the allocation: one per range, not one mmap per solve) */
   /* ---- initial point: the minimiser of the cost over the dynamics alone (no inequality
