@@ -319,6 +319,9 @@ def main():
                     help="--workload lmpc: spec (default) = SURVEY.md 8d config 3 as written: the five laps are produced by the tracking "
                          "loop at speed scales 0.80 .. 1.0 (closed_loop.record_laps) and the 4096 queries are config 2's random x0; "
                          "near = the friendlier workload of rounds 1 - 4 (analytic laps, states drawn near the last lap), kept for continuity")
+    ap.add_argument("--laps", type=int, choices=[3, 5], default=5,
+                    help="--workload lmpc: laps stored in the safe set, 32 points each: 5 (default) = SURVEY.md 8d config 3 (160 points), "
+                         "3 = the value the reference ships (barc_lmpc.param.yaml: max_lap_stored 3, num_ss_pts 96; the newest three of the five laps)")
     ap.add_argument("--ss-mode", choices=["idx", "arrays"], default="idx",
                     help="--workload lmpc: idx (default) = the safe set by reference (lmpc_ss_query_idx_batch + lmpc_solve_batch_ss_idx: 640 B of "
                          "codes per query); arrays = (ss_x, ss_j) materialised per query (8960 B), the interface of rounds 1 - 4")
@@ -392,7 +395,7 @@ def main():
     iac = args.workload == "iac"
     tr = pkg.workloads.synthetic_track("putnam" if iac else "barc")
     if lmpc:
-        cfgd = pkg.presets.barc_lmpc(N, 5)  # 5 laps stored, 32 per lap -> 160 points
+        cfgd = pkg.presets.barc_lmpc(N, args.laps)  # 5 laps stored, 32 per lap -> 160 points (3: the shipped 96)
         if args.lmpc_data == "spec":
             # "produced by running config 1's tracking loop for 5 laps with seed-indexed speed scales {0.80 .. 1.0}", 0.03 s samples
             trk_sv = pkg.Solver(pkg.presets.barc_tracking_mpc(20), pkg.presets.barc_vehicle(), device=local)
@@ -400,6 +403,7 @@ def main():
             trk_sv.close()
         else:
             laps = pkg.workloads.synthetic_laps(tr, 5)
+        laps = laps[-args.laps:]  # (oldest first: the manager keeps the newest max_lap_stored)
 
         reg_laps = []
         if args.regression:
@@ -662,7 +666,8 @@ def main():
             # the timed region: `steps` x `timed_repeats` steps back to back (>= 200 steps and >= --min-window seconds)
             "timed_steps": timed_steps, "timed_repeats": repeats, "timed_window_s": elapsed,
             "vs_baseline": None, "dtype": "f32" if f32 else ("f32 iteration, f64 arrays" if mixed else "f64"), "data": "synthetic",
-            "config": {"workload": ("BARC LMPC with 5-lap safe set (160 points), batch=%d per GPU, N=%d, fp64: safe-set kNN kernel + "
+            "config": {"workload": (("BARC LMPC with 5-lap safe set (160 points)" if args.laps == 5 else "BARC LMPC with the shipped 3-lap safe set (96 points)") +
+                                    ", batch=%d per GPU, N=%d, fp64: safe-set kNN kernel + "
                                     "QP kernel per step (BASELINE configs[2])" + (": laps from the tracking loop at speed scales 0.80 .. 1.0, queries = "
                                     "configs[1]'s random x0 (SURVEY.md 8d config 3)" if args.lmpc_data == "spec" else ": analytic laps, states drawn near the last "
                                     "lap (the workload of rounds 1 - 4; NOT SURVEY.md 8d's)") if lmpc else

@@ -222,6 +222,15 @@ int lmpc_solve_batch_mixed(lmpc_handle* h, int32_t batch, const double* x_ic, co
                            const double* ss_j, double* X_optm, double* U_optm, double* dU_optm,
                            double* convex_combi_optm, int32_t* status, int32_t* iters, double* kkt);
 
+/* How many times a warm start (lmpc_solve_batch_warm, lmpc_solve_host_warm) may repair its working set before it is refused and
+ * the cold start takes over.  No counterpart upstream.  0 restores the default, 2.  A round costs about one interior-point
+ * iteration; a refused attempt has spent its rounds on top of the cold solve that follows.  In a closed loop about 86 % of the
+ * attempts are accepted in the first round, 8 % in the second, 2 %, 1 %, 1 % in the third to fifth: more rounds trade a longer
+ * worst case for fewer cold solves -- which of the two sets a batch's duration depends on its size.  The
+ * answer does not depend on the setting (an accepted attempt is the optimum, a refused one falls back to the cold solve); `iters`
+ * does.  rounds: 0 or 1 .. 16. */
+int lmpc_set_warm_rounds(lmpc_handle* h, int32_t rounds);
+
 /* Single precision (BASELINE configs[3]: "IAC Putnam tracking MPC, N=40, ..., fp32"): the tracking problem with every
  * array in float and the interior point / Riccati recursion in fp32 (the linearisation is evaluated in fp64 and
  * rounded).  Same layouts and meaning as lmpc_solve_batch, no safe-set arguments; kkt [4][B] optional.  The abscissa

@@ -903,7 +903,9 @@ static void primal_update(prob_t* p, double alpha) {
 #define POLISH_ROUNDS 4
 #define POLISH_STEPS 4 /* at most; the loop stops after the second when that one moved the iterate by <= POLISH_STEP_OK */
 #define POLISH_STEP_OK 1e-7
+#ifndef WARM_ROUNDS
 #define WARM_ROUNDS 2       /* repairs a warm start may spend before the cold start takes over */
+#endif
 #define WARM_ACT 1e-9       /* a box row of the plan counts as active within this slack (physical units; a polished plan: ~1e-16) */
 #define WARM_ACT_EY 1e-3    /* boundary rows: their bounds move with the shift (the track half-width over one knot's travel) */
 #define POLISH_FEAS 1e-9
@@ -1105,6 +1107,9 @@ static int polish(prob_t* p, work_t* w, polish_t* q, int m_rows, int* rounds_out
  * down to mu ~ 1e-14; against the dense optimum the returned point is within 1e-6 (scaled) wherever strict
  * complementarity holds with a margin >= 1e-4 (oracle/qp.py strict_complementarity) and within ~1e-5 on
  * degenerate problems, where any interior point is O(sqrt(mu)) away.                                 */
+static int g_warm_rounds = 0; /* lmpc_set_warm_rounds (0: WARM_ROUNDS); a process-wide setting of this test library */
+void lmpc_oracle_set_warm_rounds(int rounds) { g_warm_rounds = rounds; }
+
 static int ipm_solve(prob_t* p, work_t* w, polish_t* pq, int* iters_out, double* kkt_out) {
   const int N = p->N, S = p->S;
 #ifndef IPM_TAU /* (scratch/r5/twin_variant.py builds variants with -D) */
@@ -1180,7 +1185,7 @@ static int ipm_solve(prob_t* p, work_t* w, polish_t* pq, int* iters_out, double*
     w->frozen_lambda = 0;
     int wr = 0;
     double wmu = 0.0;
-    if (polish_rounds(p, w, pq, mw, &wr, &wmu, WARM_ROUNDS)) {
+    if (polish_rounds(p, w, pq, mw, &wr, &wmu, g_warm_rounds > 0 ? g_warm_rounds : WARM_ROUNDS)) {
       *iters_out = wr;
       if (kkt_out) {
         kkt_out[0] = 0.0;

@@ -82,7 +82,7 @@ def _c(a):
 
 
 def solve_batch(cfg: MPCConfig, veh: Vehicle, inp: dict, ss_x=None, ss_j=None, b0=0, b1=None,
-                max_iter: int = 0, tol: float = 0.0, polish: int = 0, warm: bool = False, warm_plan: dict | None = None) -> dict:
+                max_iter: int = 0, tol: float = 0.0, polish: int = 0, warm: bool = False, warm_plan: dict | None = None, warm_rounds: int = 0) -> dict:
     """inp as produced by oracle.scenario.cold_start_inputs (batch axis last).  warm: the active-set warm start of
     lmpc_solve_batch_warm; the plan is warm_plan's (X_ref, U_ref) when given, else the linearisation trajectory itself."""
     N = cfg.N
@@ -100,6 +100,7 @@ def solve_batch(cfg: MPCConfig, veh: Vehicle, inp: dict, ss_x=None, ss_j=None, b
     kkt = np.zeros((4, B))
     cc, cv = c_config(cfg, max_iter, tol, polish), c_vehicle(veh)
     plan = []
+    lib().lmpc_oracle_set_warm_rounds(C.c_int(warm_rounds))  # (lmpc_set_warm_rounds; 0: the default)
     fn = lib().lmpc_oracle_solve_range_warm if warm else lib().lmpc_oracle_solve_range
     if warm and warm_plan is not None:
         fn = lib().lmpc_oracle_solve_range_warm_plan

@@ -20,7 +20,7 @@ _ABI_SYMBOLS = ("lmpc_create", "lmpc_destroy", "lmpc_last_error", "lmpc_set_stre
                 "lmpc_prepare_batch", "lmpc_reserve", "lmpc_query_launch", "lmpc_enable_timing",
                 "lmpc_last_kernel_ms", "lmpc_query_residency", "lmpc_query_launch_for", "lmpc_solve_host", "lmpc_shift_batch",
                 "lmpc_plant_step_batch", "lmpc_solve_full_dynamics_batch", "lmpc_solve_full_dynamics_host", "lmpc_set_regression_laps", "lmpc_regress_batch", "lmpc_ss_query_host", "lmpc_solve_batch_f32",
-                "lmpc_solve_batch_mixed", "lmpc_prepare_failed_batch", "lmpc_set_launch_order", "lmpc_launch_order_from_iters", "lmpc_set_output_layout",
+                "lmpc_solve_batch_mixed", "lmpc_prepare_failed_batch", "lmpc_set_launch_order", "lmpc_set_warm_rounds", "lmpc_launch_order_from_iters", "lmpc_set_output_layout",
                 "lmpc_ss_query_idx_batch", "lmpc_solve_batch_ss_idx", "lmpc_solve_batch_warm", "lmpc_solve_host_warm")
 
 
@@ -269,6 +269,10 @@ class Solver:
         passes result tensors of the matching shape (alloc_outputs follows the setting)."""
         self._aos = {"soa": False, "aos": True}[layout]
         self._check(self.lib.lmpc_set_output_layout(self._h, C.c_int32(int(self._aos))), "lmpc_set_output_layout")
+
+    def set_warm_rounds(self, rounds: int = 0):
+        """Repair rounds a warm start may spend before the cold start takes over (include/lmpc_hip.h); 0: the default (2)."""
+        self._check(self.lib.lmpc_set_warm_rounds(self._h, C.c_int32(int(rounds))), "lmpc_set_warm_rounds")
 
     # ---- launch order (longest job first; include/lmpc_hip.h) ----
     def set_launch_order(self, order):

@@ -10,7 +10,8 @@ from __future__ import annotations
 
 
 def run(solver, track: dict, x0, u0, steps: int, dt: float = 0.025, n_sub: int = 2, speed_scale: float = 0.9,
-        record_every: int = 0, restart_failed: bool = True, graph: bool = False, longest_first: bool = False, warm: bool = False):
+        record_every: int = 0, restart_failed: bool = True, graph: bool = False, longest_first: bool = False, warm: bool = False,
+        warm_rounds: int = 0):
     """x0 [6][B], u0 [2][B] (torch, device).  Returns final state and statistics (torch tensors on device).
 
     One control period = solve, apply the first input of the plan (on failure: of the shifted previous plan,
@@ -23,7 +24,8 @@ def run(solver, track: dict, x0, u0, steps: int, dt: float = 0.025, n_sub: int =
 
     warm=True solves with lmpc_solve_batch_warm: the shifted previous plan (what `inp["X_ref"]`, `inp["U_ref"]` hold from the second
     period on, racing_mpc_node.cpp:245-254) is tried as an active-set solve before any interior point.  Returns the share of
-    solves that took that route as "warm_hit_rate" (iters <= 2: one or two polish rounds).
+    solves that took that route as "warm_hit_rate" (iters <= the rounds allowed: a refused attempt reports its rounds + the cold
+    solve's iterations).  warm_rounds: lmpc_set_warm_rounds for this run (0: the default, 2); the handle is back on the default afterwards.
 
     longest_first=True launches the QP kernel's workgroups in the order of the previous period's iteration counts, longest
     first (lmpc_set_launch_order): a car's count changes little from one period to the next, and the long problems then
@@ -44,6 +46,8 @@ def run(solver, track: dict, x0, u0, steps: int, dt: float = 0.025, n_sub: int =
     half_b = float(solver.vehicle["b"]) / 2.0
     keys = ("X_ref", "U_ref", "T_ref", "bound_left", "bound_right", "curvatures", "vel_ref")
     trace = []
+    if warm:
+        solver.set_warm_rounds(warm_rounds)
     order = None
     if longest_first:
         order = torch.arange(B, dtype=torch.int32, device=x.device)
@@ -54,7 +58,7 @@ def run(solver, track: dict, x0, u0, steps: int, dt: float = 0.025, n_sub: int =
         inp["u_ic"] = u_prev
         solver.solve(inp, out, warm=True if warm else None)
         if warm:
-            hits.add_(((out["status"] == 0) & (out["iters"] <= 2)).sum())
+            hits.add_(((out["status"] == 0) & (out["iters"] <= (warm_rounds or 2))).sum())
         if order is not None:
             solver.launch_order_from_iters(out["iters"], order)   # for the next period (in place: the pointer is registered)
         ok = out["status"] == 0
@@ -100,6 +104,8 @@ def run(solver, track: dict, x0, u0, steps: int, dt: float = 0.025, n_sub: int =
     if order is not None:
         torch.cuda.synchronize(x.device)
         solver.set_launch_order(None)
+    if warm and warm_rounds:
+        solver.set_warm_rounds(0)
     return {"x": x, "distance": dist, "worst_excess": worst_excess, "n_fail": n_fail, "trace": trace,
             "warm_hit_rate": (float(hits) / (B * max(steps, 1))) if warm else None}
 

@@ -55,6 +55,7 @@ struct lmpc_handle {
                          // solve the library launches for itself (the SQP's QPs, the single-problem host path) writes the default layout
   const int* order = nullptr;  // lmpc_set_launch_order: device [order_n], applied to solves of that batch size only
   int order_n = 0;
+  int warm_rounds = 0;  // lmpc_set_warm_rounds (0: the kernels' WARM_ROUNDS)
   double* ws = nullptr;  // [cap][N-1][LMPC_LIN_RECORD]
   int* unverified = nullptr;  // [cap + 1]: the problems a mixed first pass could not verify, and their number
   void* save = nullptr;       // [save_cap][10 N - 4] elements of save_elem bytes: the polish's save area (grown by reserve_save)
@@ -270,6 +271,7 @@ int launch_solve_warm(lmpc_handle* h, const solve_args& a) {
   lmpc_params P = h->P;
   P.out_aos = a.aos ? 1 : 0;
   set_ss_reference(h, P, a);
+  P.warm_rounds = h->warm_rounds;
   P.launch_order = (h->order && a.B == h->order_n) ? h->order : nullptr;
   int B = a.B;
   const double* ws = h->ws;
@@ -1241,6 +1243,13 @@ int lmpc_set_output_layout(lmpc_handle* h, int32_t layout) {
   if (!h) return LMPC_ERR_ARGUMENT;
   if (layout != LMPC_LAYOUT_SOA && layout != LMPC_LAYOUT_AOS) return fail(h, LMPC_ERR_ARGUMENT, "lmpc_set_output_layout: unknown layout");
   h->out_aos = layout == LMPC_LAYOUT_AOS;
+  return LMPC_OK;
+}
+
+int lmpc_set_warm_rounds(lmpc_handle* h, int32_t rounds) {
+  if (!h) return LMPC_ERR_ARGUMENT;
+  if (rounds < 0 || rounds > 16) return fail(h, LMPC_ERR_ARGUMENT, "lmpc_set_warm_rounds: 0 (the default) or 1 .. 16 rounds");
+  h->warm_rounds = rounds;
   return LMPC_OK;
 }
 

@@ -37,7 +37,7 @@ struct lmpc_params {
   int flag_unverified;
   int hard_hull;  // all-zero convex_hull_slack: chs2 = 2 LMPC_HARD_HULL_WEIGHT and the residual is checked at the exit
   int out_aos;  // lmpc_set_output_layout: results [batch][knot][component] instead of [component][knot][batch]
-  int reserved_;  // (keeps the block's layout)
+  int warm_rounds;  // lmpc_set_warm_rounds: repairs a warm start may spend before the cold start takes over (0: WARM_ROUNDS); read by the warm kernels only
   // the safe set by reference (lmpc_solve_batch_ss_idx): S codes per problem from lmpc_ss_query_idx_batch, [S][B], and the lap
   // store they point into (the handle's copy: lmpc_set_safe_set); ss_idx == null: the points arrive as arrays (ss_x, ss_j)
   const int* ss_idx;

@@ -2730,7 +2730,7 @@ __device__ __forceinline__ void lmpc_solve_problem(
           s_tl[q] = (f & F_LO) ? s_tl[q] : real(1);
         }
         wave_sync();
-        if (polish_attempt(WARM_ROUNDS)) {
+        if (polish_attempt(P.warm_rounds > 0 ? P.warm_rounds : WARM_ROUNDS)) {
           polished = true;
           status = LMPC_SOLVE_OPTIMAL;
           warm_done = true;

@@ -68,6 +68,21 @@ def test_warm_from_the_optimum_from_noise_and_from_the_shifted_plan(pkg, N):
     tw = cbind.solve_batch(cfg, veh, _np(nxt), warm=True)
     assert np.array_equal(tw["status"] == 0, ok3)
     assert _err(w3, tw, ok3) < TOL_DU and (np.abs(w3["iters"][ok3] - tw["iters"][ok3]) == 0).mean() > 0.9
+    # (4) lmpc_set_warm_rounds: more repair rounds accept more attempts, the answers stay the cold solve's, kernel and twin agree;
+    # an accepted attempt reports at most the rounds allowed, a refused one more
+    sv.set_warm_rounds(5)
+    w5 = _np(sv.solve(nxt, warm=True))
+    tw5 = cbind.solve_batch(cfg, veh, _np(nxt), warm=True, warm_rounds=5)
+    sv.set_warm_rounds(0)
+    assert np.array_equal(w5["status"] == 0, ok3) and _err(w5, c3, ok3) < TOL_TWIN
+    hit5 = ok3 & (w5["iters"] <= 5)
+    print("   five rounds allowed: accepted on %.3f (two rounds: %.3f)" % (hit5.sum() / ok3.sum(), hit.sum() / ok3.sum()))
+    assert hit5.sum() >= hit.sum() and np.array_equal(w5["iters"][hit], w3["iters"][hit])
+    assert _err(w5, tw5, ok3) < TOL_DU and (np.abs(w5["iters"][ok3] - tw5["iters"][ok3]) == 0).mean() > 0.9
+    w0 = _np(sv.solve(nxt, warm=True))          # back on the default: the two-round result again
+    assert np.array_equal(w0["iters"], w3["iters"])
+    with pytest.raises(pkg.LmpcError, match="lmpc_set_warm_rounds"):
+        sv.set_warm_rounds(17)
     sv.close()
 
 

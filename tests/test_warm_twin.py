@@ -39,6 +39,13 @@ def test_twin_warm_from_the_dense_optimum_and_from_noise(pkg, name):
     assert exu.max() < TOL_XU and ed.max() < TOL_DU
     assert (w["iters"] <= 2).mean() > 0.9
 
+    # more rounds allowed (lmpc_set_warm_rounds): whatever was accepted within two rounds is unchanged, the rest may be accepted later
+    w6 = cbind.solve_batch(cfg, veh, sl, warm=True, warm_plan=plan, warm_rounds=6)
+    two = w["iters"] <= 2
+    assert np.array_equal(w6["iters"][two], w["iters"][two]) and (w6["iters"] <= 6).sum() >= two.sum() and (w6["status"] == 0).all()
+    exu, ed = per_problem_err(w6, fxs)
+    assert exu.max() < TOL_XU and ed.max() < TOL_DU
+
     rng = np.random.default_rng(5)
     noise = dict(sl, X_ref=rng.normal(size=fxs["X_optm"].shape), U_ref=0.01 * rng.normal(size=fxs["U_optm"].shape))
     n = cbind.solve_batch(cfg, veh, sl, warm=True, warm_plan=noise)
