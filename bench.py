@@ -322,6 +322,8 @@ def main():
     ap.add_argument("--laps", type=int, choices=[3, 5], default=5,
                     help="--workload lmpc: laps stored in the safe set, 32 points each: 5 (default) = SURVEY.md 8d config 3 (160 points), "
                          "3 = the value the reference ships (barc_lmpc.param.yaml: max_lap_stored 3, num_ss_pts 96; the newest three of the five laps)")
+    ap.add_argument("--laps-npz", default=None, help=argparse.SUPPRESS)  # (the counter passes nested in a run: the laps the parent recorded,
+    #                                                                       so that the profiled child does not drive the tracking loop again)
     ap.add_argument("--ss-mode", choices=["idx", "arrays"], default="idx",
                     help="--workload lmpc: idx (default) = the safe set by reference (lmpc_ss_query_idx_batch + lmpc_solve_batch_ss_idx: 640 B of "
                          "codes per query); arrays = (ss_x, ss_j) materialised per query (8960 B), the interface of rounds 1 - 4")
@@ -396,7 +398,10 @@ def main():
     tr = pkg.workloads.synthetic_track("putnam" if iac else "barc")
     if lmpc:
         cfgd = pkg.presets.barc_lmpc(N, args.laps)  # 5 laps stored, 32 per lap -> 160 points (3: the shipped 96)
-        if args.lmpc_data == "spec":
+        if args.laps_npz:
+            with np.load(args.laps_npz) as z:
+                laps = [z["lap%d" % i] for i in range(len(z.files))]
+        elif args.lmpc_data == "spec":
             # "produced by running config 1's tracking loop for 5 laps with seed-indexed speed scales {0.80 .. 1.0}", 0.03 s samples
             trk_sv = pkg.Solver(pkg.presets.barc_tracking_mpc(20), pkg.presets.barc_vehicle(), device=local)
             laps = pkg.closed_loop.record_laps(trk_sv, tr)
@@ -638,19 +643,30 @@ def main():
         sol_avg = float(np.mean(sol_ms))
         algo_bytes = ((13 * N + 5) + (10 * N - 4)) * (4 if f32 else 8) + 8
         if lmpc:
-            algo_bytes += (7 + 1) * 160 * 8  # + ss_x, ss_j in and lambda out (13 936 B at S = 160; by reference the kernel reads
-            #                                    640 B of codes + the points from the L2-resident store instead, the figure is kept as SURVEY states it)
+            algo_bytes += (7 + 1) * cfgd["num_ss_pts"] * 8  # + ss_x, ss_j in and lambda out (13 936 B at S = 160, 9840 B at S = 96; by reference
+            #                                                  the kernel reads 4 S B of codes + the points from the L2-resident store instead, the figure is kept as SURVEY states it)
         achieved = algo_bytes * B / (sol_avg * 1e-3) / 1e9
         # committed PMC passes of this command: tracking, or the learning problem with 160 safe-set points
         pmc_sel = ("r04_pmc_lmpc.json", "lmpc_solve_kernel<double, 4, 3") if lmpc else ("r05_pmc_tracking.json", "lmpc_solve_kernel<double, 4, 0")
         pmc_shape = not (N != 20 or B != 4096 or iac or f32 or mixed)  # the shape the committed passes were taken on
+        if lmpc and (args.lmpc_data != "near" or args.laps != 5):        # (r04_pmc_lmpc.json: the rounds-1-4 learning workload, 160 points)
+            pmc_shape = False
         traffic, traffic_source, counters = None, None, {}
         if world == 1 and not args.no_pmc:
             wl_argv = ["--batch", str(B), "--horizon", str(N), "--workload", args.workload, "--precision", args.precision, "--lmpc-data", args.lmpc_data, "--ss-mode", args.ss_mode]
             if args.regression:
                 wl_argv.append("--regression")
-            kname = "lmpc_solve_kernel<%s, " % ("float" if (f32 or mixed) else "double")
+            laps_file = None
+            if lmpc:  # the profiled children take the laps of this run (recording them drives ~2000 periods of the tracking loop: minutes under --pmc)
+                import tempfile
+                laps_file = tempfile.NamedTemporaryFile(suffix=".npz", dir="/tmp", delete=False).name
+                np.savez(laps_file, **{"lap%d" % i: np.asarray(a) for i, a in enumerate(laps)})
+                wl_argv += ["--laps", str(args.laps), "--laps-npz", laps_file]
+            # (SQL LIKE pattern: the learning kernels are the KS = 2 (<= 128 points) / 3 instantiations, the tracking ones KS = 0)
+            kname = "lmpc_solve_kernel<%s, %%, %d, " % ("float" if (f32 or mixed) else "double", 0 if not lmpc else (2 if cfgd["num_ss_pts"] <= 128 else 3))
             counters = live_counters(wl_argv, kname)
+            if laps_file:
+                os.unlink(laps_file)
             traffic = live_traffic_bytes(counters)
             traffic_source = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, two passes of this command at --steps 5, measured in this run"
         if traffic is None and pmc_shape:

@@ -1108,7 +1108,7 @@ static int polish(prob_t* p, work_t* w, polish_t* q, int m_rows, int* rounds_out
  * complementarity holds with a margin >= 1e-4 (oracle/qp.py strict_complementarity) and within ~1e-5 on
  * degenerate problems, where any interior point is O(sqrt(mu)) away.                                 */
 static int g_warm_rounds = 0; /* lmpc_set_warm_rounds (0: WARM_ROUNDS); a process-wide setting of this test library */
-void lmpc_oracle_set_warm_rounds(int rounds) { g_warm_rounds = rounds; }
+void lmpc_oracle_set_warm_rounds(int rounds) { g_warm_rounds = rounds > POLISH_ROUNDS ? POLISH_ROUNDS : rounds; } /* (1 .. 4 as lmpc_set_warm_rounds) */
 
 static int ipm_solve(prob_t* p, work_t* w, polish_t* pq, int* iters_out, double* kkt_out) {
   const int N = p->N, S = p->S;

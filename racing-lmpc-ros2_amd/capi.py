@@ -271,7 +271,8 @@ class Solver:
         self._check(self.lib.lmpc_set_output_layout(self._h, C.c_int32(int(self._aos))), "lmpc_set_output_layout")
 
     def set_warm_rounds(self, rounds: int = 0):
-        """Repair rounds a warm start may spend before the cold start takes over (include/lmpc_hip.h); 0: the default (2)."""
+        """Repair rounds a warm start may spend before the cold start takes over (include/lmpc_hip.h): 1 .. 4, or 0 for the default
+        (2 rounds; 4 when the batch is at least four times what the device holds at once)."""
         self._check(self.lib.lmpc_set_warm_rounds(self._h, C.c_int32(int(rounds))), "lmpc_set_warm_rounds")
 
     # ---- launch order (longest job first; include/lmpc_hip.h) ----

@@ -24,8 +24,9 @@ def run(solver, track: dict, x0, u0, steps: int, dt: float = 0.025, n_sub: int =
 
     warm=True solves with lmpc_solve_batch_warm: the shifted previous plan (what `inp["X_ref"]`, `inp["U_ref"]` hold from the second
     period on, racing_mpc_node.cpp:245-254) is tried as an active-set solve before any interior point.  Returns the share of
-    solves that took that route as "warm_hit_rate" (iters <= the rounds allowed: a refused attempt reports its rounds + the cold
-    solve's iterations).  warm_rounds: lmpc_set_warm_rounds for this run (0: the default, 2); the handle is back on the default afterwards.
+    solves that took that route as "warm_hit_rate" (iters <= 4: an attempt has four rounds at most and a refused one reports its
+    rounds + the cold solve's iterations, five at least).  warm_rounds: lmpc_set_warm_rounds for this run (0: the library's default
+    by batch size); the handle is back on the default afterwards.
 
     longest_first=True launches the QP kernel's workgroups in the order of the previous period's iteration counts, longest
     first (lmpc_set_launch_order): a car's count changes little from one period to the next, and the long problems then
@@ -58,7 +59,7 @@ def run(solver, track: dict, x0, u0, steps: int, dt: float = 0.025, n_sub: int =
         inp["u_ic"] = u_prev
         solver.solve(inp, out, warm=True if warm else None)
         if warm:
-            hits.add_(((out["status"] == 0) & (out["iters"] <= (warm_rounds or 2))).sum())
+            hits.add_(((out["status"] == 0) & (out["iters"] <= 4)).sum())   # (an attempt has 4 rounds at most; a cold solve takes 5 iterations at least)
         if order is not None:
             solver.launch_order_from_iters(out["iters"], order)   # for the next period (in place: the pointer is registered)
         ok = out["status"] == 0

@@ -55,7 +55,8 @@ struct lmpc_handle {
                          // solve the library launches for itself (the SQP's QPs, the single-problem host path) writes the default layout
   const int* order = nullptr;  // lmpc_set_launch_order: device [order_n], applied to solves of that batch size only
   int order_n = 0;
-  int warm_rounds = 0;  // lmpc_set_warm_rounds (0: the kernels' WARM_ROUNDS)
+  int warm_rounds = 0;    // lmpc_set_warm_rounds (0: by batch size, see launch_solve_warm)
+  int warm_resident = 0;  // problems the device holds at once in the warm kernel (CUs x workgroups per CU); 0: no warm kernel for this handle
   double* ws = nullptr;  // [cap][N-1][LMPC_LIN_RECORD]
   int* unverified = nullptr;  // [cap + 1]: the problems a mixed first pass could not verify, and their number
   void* save = nullptr;       // [save_cap][10 N - 4] elements of save_elem bytes: the polish's save area (grown by reserve_save)
@@ -271,7 +272,13 @@ int launch_solve_warm(lmpc_handle* h, const solve_args& a) {
   lmpc_params P = h->P;
   P.out_aos = a.aos ? 1 : 0;
   set_ss_reference(h, P, a);
-  P.warm_rounds = h->warm_rounds;
+  // Repair rounds before the cold start takes over.  A refused attempt is the longest job of its batch (its rounds + a cold solve)
+  // and an accepted one the shortest: while the batch fits the device a few times over, its duration is that of the longest jobs
+  // and a refusal should come early (2 rounds: 95 % accepted at N = 20, 73 % at N = 60); once the batch is many times what the
+  // device holds, throughput counts and every cold solve saved pays (4 rounds: 99 % / 89 %).  Measured in the closed loop
+  // (profiles/r05_closed_loop_warm_rounds.txt): N = 20, 4096 cars (2 x resident) 5.50 / 5.36 / 5.17 M car-steps/s at 2 / 3 / 4
+  // rounds, 16384 cars (8 x) 10.43 / 10.64 / 10.54; N = 60, 4096 cars (4 x) 1.00 / 1.02 / 1.05.
+  P.warm_rounds = h->warm_rounds > 0 ? h->warm_rounds : ((h->warm_resident > 0 && a.B >= 4 * h->warm_resident) ? 4 : 2);
   P.launch_order = (h->order && a.B == h->order_n) ? h->order : nullptr;
   int B = a.B;
   const double* ws = h->ws;
@@ -434,6 +441,16 @@ int lmpc_create(const lmpc_config* cfg, const lmpc_vehicle* veh, int device, lmp
     int rc = lmpc_reserve(h, 1);
     if (rc == LMPC_OK) rc = reserve_sqp(h, 1);
     if (rc != LMPC_OK) return rc;
+  }
+  if (!P.learning) {  // what the device holds of the warm kernel at once (the default of lmpc_set_warm_rounds goes by it)
+    if (const void* fn = pick_warm_fn(kq_for(P.N))) {
+      const size_t lds = lmpc_lds_bytes(P.N, 0, 0, 8);
+      int per_cu = 0, cus = 0;
+      HIP_TRY(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64, lds));
+      HIP_TRY(h, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
+      h->warm_resident = per_cu * cus;
+    }
   }
   return LMPC_OK;
 }
@@ -1248,7 +1265,7 @@ int lmpc_set_output_layout(lmpc_handle* h, int32_t layout) {
 
 int lmpc_set_warm_rounds(lmpc_handle* h, int32_t rounds) {
   if (!h) return LMPC_ERR_ARGUMENT;
-  if (rounds < 0 || rounds > 16) return fail(h, LMPC_ERR_ARGUMENT, "lmpc_set_warm_rounds: 0 (the default) or 1 .. 16 rounds");
+  if (rounds < 0 || rounds > 4) return fail(h, LMPC_ERR_ARGUMENT, "lmpc_set_warm_rounds: 0 (the default) or 1 .. 4 rounds");
   h->warm_rounds = rounds;
   return LMPC_OK;
 }
