@@ -829,7 +829,8 @@ def test_bench_two_ranks_preflight_on_one_gpu(launcher):
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["scaling"] == "weak" and d["value"] > 1e5
+    # (control flow, not speed: the gather goes through gloo and host memory here -- 95 k .. 400 k solves/s from run to run)
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["scaling"] == "weak" and d["value"] > 1e4
     assert d["solved_fraction"] > 0.99 and "cpu_baseline" not in d
     assert [r_["rank"] for r_ in d["config"]["ranks_seen"]] == [0, 1]
 
