@@ -1301,7 +1301,10 @@ static int ipm_solve(prob_t* p, work_t* w, polish_t* pq, int* iters_out, double*
     if (it == p->max_iter) break;
     if (pq && !pol_tried && mu <= POLISH_MU && rdmax <= POLISH_RD) { /* the active set is usually settled by now */
       pol_tried = 1;
-      if (polish(p, w, pq, m, &pol_rounds, &mu)) {
+#ifndef EARLY_ROUNDS /* (scratch/r5/twin_variant.py) */
+#define EARLY_ROUNDS POLISH_ROUNDS
+#endif
+      if (polish_rounds(p, w, pq, m, &pol_rounds, &mu, EARLY_ROUNDS)) {
         status = LMPC_SOLVE_OPTIMAL;
         pol_done = 1;
         break;
