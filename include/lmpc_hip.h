@@ -408,6 +408,27 @@ int lmpc_shift_batch(lmpc_handle* h, int32_t batch, const lmpc_track* track, con
 int lmpc_plant_step_batch(lmpc_handle* h, int32_t batch, const lmpc_track* track, double* x,
                           const double* u, double dt_sim, int32_t n_sub);
 
+/* Everything between two solves of a closed loop in ONE launch: what RacingMPCNode::on_step_timer does with a solve's result and
+ * what the simulator does with the node's command, for a batch of cars.  Per car:
+ *   the input applied  -- the plan's first input U_optm[:, 0], or after a failed solve (status != 0) the first input of the plan the
+ *                         solve started from, U_ref[:, 0] (racing_mpc_node.cpp:322-332); written to u_prev [2][B] (the next u_ic);
+ *   the plant          -- lmpc_plant_step_batch on x [6][B] in place (racing_simulator.cpp:46-69,97-112);
+ *   the next inputs    -- lmpc_shift_batch (racing_mpc_node.cpp:245-254) from the solution, or from the old plan after a failed
+ *                         solve; with restart_failed != 0 a car whose solve failed is instead prepared from a cold start at its
+ *                         new state (lmpc_prepare_failed_batch; racing_mpc_node.cpp:210-235) -- X_ref, U_ref, T_ref, bound_left,
+ *                         bound_right, curvatures, vel_ref are updated IN PLACE (they must not alias X_optm / U_optm);
+ *   bookkeeping        -- optional accumulators, any of them NULL: distance [B] += abscissa travelled (unwrapped), worst_excess [B]
+ *                         = max(itself, excursion of the body beyond the track edge at the new state against the bounds of knot 0),
+ *                         n_fail [B] += 1 after a failed solve, *n_accepted += number of cars whose warm start was accepted
+ *                         (status 0 and iters <= 4; needs iters).
+ * The same arithmetic as the three entry points it replaces, bit for bit (tests/test_gpu_loop.py); a period of a closed loop is then
+ * three launches -- linearisation, QP, this -- instead of ~45.  SOA result layout only.  All pointers DEVICE. */
+int lmpc_loop_advance_batch(lmpc_handle* h, int32_t batch, const lmpc_track* track, const int32_t* status, const int32_t* iters,
+                            const double* X_optm, const double* U_optm, double* x, double* u_prev, double dt, double dt_sim,
+                            int32_t n_sub, double speed_scale, double speed_limit, int32_t restart_failed, double* X_ref,
+                            double* U_ref, double* T_ref, double* bound_left, double* bound_right, double* curvatures,
+                            double* vel_ref, double* distance, double* worst_excess, int64_t* n_fail, uint64_t* n_accepted);
+
 /* Layout of the RESULT arrays X_optm, U_optm, dU_optm of lmpc_solve_batch and lmpc_solve_batch_mixed AS THE CALLER INVOKES THEM
  * (inputs, status, iters, kkt and convex_combi_optm are not affected).  Nothing else follows the setting: lmpc_solve_batch_f32,
  * lmpc_solve_full_dynamics_batch (its inner QPs feed the line search and the next linearisation), the single-problem host

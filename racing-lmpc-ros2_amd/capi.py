@@ -20,7 +20,7 @@ _ABI_SYMBOLS = ("lmpc_create", "lmpc_destroy", "lmpc_last_error", "lmpc_set_stre
                 "lmpc_prepare_batch", "lmpc_reserve", "lmpc_query_launch", "lmpc_enable_timing",
                 "lmpc_last_kernel_ms", "lmpc_query_residency", "lmpc_query_launch_for", "lmpc_solve_host", "lmpc_shift_batch",
                 "lmpc_plant_step_batch", "lmpc_solve_full_dynamics_batch", "lmpc_solve_full_dynamics_host", "lmpc_set_regression_laps", "lmpc_regress_batch", "lmpc_ss_query_host", "lmpc_solve_batch_f32",
-                "lmpc_solve_batch_mixed", "lmpc_prepare_failed_batch", "lmpc_set_launch_order", "lmpc_set_warm_rounds", "lmpc_launch_order_from_iters", "lmpc_set_output_layout",
+                "lmpc_solve_batch_mixed", "lmpc_prepare_failed_batch", "lmpc_set_launch_order", "lmpc_set_warm_rounds", "lmpc_loop_advance_batch", "lmpc_launch_order_from_iters", "lmpc_set_output_layout",
                 "lmpc_ss_query_idx_batch", "lmpc_solve_batch_ss_idx", "lmpc_solve_batch_warm", "lmpc_solve_host_warm")
 
 
@@ -301,6 +301,23 @@ class Solver:
                                             C.c_double(dt_sim), C.c_int32(n_sub))
         self._check(rc, "lmpc_plant_step_batch")
         return x
+
+    def loop_advance(self, track: dict, inp: dict, sol: dict, x, u_prev, dt: float, dt_sim: float, n_sub: int = 1, speed_scale: float = 1.0,
+                     speed_limit: float | None = None, restart_failed: bool = True, distance=None, worst_excess=None, n_fail=None,
+                     n_accepted=None):
+        """lmpc_loop_advance_batch: input selection + plant step + the next period's inputs (shift, or cold restart of failed cars) +
+        bookkeeping in one launch.  `inp`'s reference arrays, `x` [6][B] and `u_prev` [2][B] are updated in place; the accumulators
+        (float64 [B], float64 [B], int64 [B], int64 scalar tensor) are optional."""
+        self.use_current_stream()
+        ct = self._ctrack(track)
+        if speed_limit is None:
+            speed_limit = float(self.config["x_max"][3])
+        rc = self.lib.lmpc_loop_advance_batch(
+            self._h, C.c_int32(x.shape[1]), C.byref(ct), _ptr(sol["status"]), _ptr(sol["iters"]), _ptr(sol["X_optm"]), _ptr(sol["U_optm"]),
+            _ptr(x), _ptr(u_prev), C.c_double(dt), C.c_double(dt_sim), C.c_int32(n_sub), C.c_double(speed_scale), C.c_double(speed_limit),
+            C.c_int32(1 if restart_failed else 0), *[_ptr(inp[k]) for k in ("X_ref", "U_ref", "T_ref", "bound_left", "bound_right", "curvatures", "vel_ref")],
+            _ptr(distance), _ptr(worst_excess), _ptr(n_fail), _ptr(n_accepted))
+        self._check(rc, "lmpc_loop_advance_batch")
 
     # ---- discrete_dynamics_jacobian (single_track_planar_model.cpp:377-387) ----
     def linearize(self, inp: dict):

@@ -11,7 +11,7 @@ from __future__ import annotations
 
 def run(solver, track: dict, x0, u0, steps: int, dt: float = 0.025, n_sub: int = 2, speed_scale: float = 0.9,
         record_every: int = 0, restart_failed: bool = True, graph: bool = False, longest_first: bool = False, warm: bool = False,
-        warm_rounds: int = 0):
+        warm_rounds: int = 0, fused: bool = True):
     """x0 [6][B], u0 [2][B] (torch, device).  Returns final state and statistics (torch tensors on device).
 
     One control period = solve, apply the first input of the plan (on failure: of the shifted previous plan,
@@ -27,6 +27,10 @@ def run(solver, track: dict, x0, u0, steps: int, dt: float = 0.025, n_sub: int =
     solves that took that route as "warm_hit_rate" (iters <= 4: an attempt has four rounds at most and a refused one reports its
     rounds + the cold solve's iterations, five at least).  warm_rounds: lmpc_set_warm_rounds for this run (0: the library's default
     by batch size); the handle is back on the default afterwards.
+
+    fused=True (default) does everything behind the solve -- input selection, plant step, statistics, shift or cold restart -- with
+    one launch, lmpc_loop_advance_batch; fused=False goes through lmpc_plant_step_batch, lmpc_shift_batch, lmpc_prepare_failed_batch
+    and torch element-wise operations (~45 launches per period), the same arithmetic (tests/test_gpu_loop.py: bit for bit).
 
     longest_first=True launches the QP kernel's workgroups in the order of the previous period's iteration counts, longest
     first (lmpc_set_launch_order): a car's count changes little from one period to the next, and the long problems then
@@ -58,10 +62,14 @@ def run(solver, track: dict, x0, u0, steps: int, dt: float = 0.025, n_sub: int =
         inp["x_ic"] = x
         inp["u_ic"] = u_prev
         solver.solve(inp, out, warm=True if warm else None)
-        if warm:
-            hits.add_(((out["status"] == 0) & (out["iters"] <= 4)).sum())   # (an attempt has 4 rounds at most; a cold solve takes 5 iterations at least)
         if order is not None:
             solver.launch_order_from_iters(out["iters"], order)   # for the next period (in place: the pointer is registered)
+        if fused:
+            solver.loop_advance(trk, inp, out, x, u_prev, dt, dt / n_sub, n_sub, speed_scale=speed_scale, restart_failed=restart_failed,
+                                distance=dist, worst_excess=worst_excess, n_fail=n_fail, n_accepted=hits if warm else None)
+            return
+        if warm:
+            hits.add_(((out["status"] == 0) & (out["iters"] <= 4)).sum())   # (an attempt has 4 rounds at most; a cold solve takes 5 iterations at least)
         ok = out["status"] == 0
         n_fail.add_((~ok).to(torch.int64))
         u_apply = torch.where(ok[None, :], out["U_optm"][:, 0, :], inp["U_ref"][:, 0, :]).contiguous()

@@ -1056,6 +1056,28 @@ int lmpc_plant_step_batch(lmpc_handle* h, int32_t batch, const lmpc_track* track
   return LMPC_OK;
 }
 
+int lmpc_loop_advance_batch(lmpc_handle* h, int32_t batch, const lmpc_track* track, const int32_t* status, const int32_t* iters,
+                            const double* X_optm, const double* U_optm, double* x, double* u_prev, double dt, double dt_sim, int32_t n_sub,
+                            double speed_scale, double speed_limit, int32_t restart_failed, double* X_ref, double* U_ref, double* T_ref,
+                            double* bound_left, double* bound_right, double* curvatures, double* vel_ref, double* distance,
+                            double* worst_excess, int64_t* n_fail, uint64_t* n_accepted) {
+  if (!h) return LMPC_ERR_ARGUMENT;
+  if (batch < 0 || !track_ok(track) || !status || !X_optm || !U_optm || !x || !u_prev || !X_ref || !U_ref || !T_ref || !bound_left ||
+      !bound_right || !curvatures || !vel_ref || !(dt > 0.0) || !(dt_sim > 0.0) || n_sub < 1 || (n_accepted && !iters))
+    return fail(h, LMPC_ERR_ARGUMENT, "lmpc_loop_advance_batch: bad argument");
+  if (X_ref == X_optm || U_ref == U_optm) return fail(h, LMPC_ERR_ARGUMENT, "lmpc_loop_advance_batch: the references must not alias the solution");
+  if (h->out_aos) return fail(h, LMPC_ERR_UNSUPPORTED, "lmpc_loop_advance_batch reads the solution in the [component][knot][batch] layout");
+  if (batch == 0) return LMPC_OK;
+  HIP_TRY(h, hipSetDevice(h->device));
+  static_assert(sizeof(long long) == sizeof(int64_t) && sizeof(unsigned long long) == sizeof(uint64_t), "counter types");
+  hipLaunchKernelGGL(lmpc_loop_advance_kernel, dim3((batch + 63) / 64), dim3(64), 0, h->stream, h->P, batch, *track, status, iters, X_optm,
+                     U_optm, x, u_prev, dt, dt_sim, n_sub, speed_scale, speed_limit, restart_failed ? 1 : 0, X_ref, U_ref, T_ref, bound_left,
+                     bound_right, curvatures, vel_ref, distance, worst_excess, reinterpret_cast<long long*>(n_fail),
+                     reinterpret_cast<unsigned long long*>(n_accepted));
+  HIP_TRY(h, hipGetLastError());
+  return LMPC_OK;
+}
+
 int lmpc_set_safe_set(lmpc_handle* h, int32_t n_laps, const int32_t* n_pts, const double* x, double total_length) {
   if (!h) return LMPC_ERR_ARGUMENT;
   if (n_laps < 0 || (n_laps > 0 && (!n_pts || !x)) || !(total_length > 0.0))
@@ -1265,7 +1287,8 @@ int lmpc_set_output_layout(lmpc_handle* h, int32_t layout) {
 
 int lmpc_set_warm_rounds(lmpc_handle* h, int32_t rounds) {
   if (!h) return LMPC_ERR_ARGUMENT;
-  if (rounds < 0 || rounds > 4) return fail(h, LMPC_ERR_ARGUMENT, "lmpc_set_warm_rounds: 0 (the default) or 1 .. 4 rounds");
+  static_assert(LMPC_WARM_ROUNDS_MAX == 4, "the message below");
+  if (rounds < 0 || rounds > LMPC_WARM_ROUNDS_MAX) return fail(h, LMPC_ERR_ARGUMENT, "lmpc_set_warm_rounds: 0 (the default) or 1 .. 4 rounds");
   h->warm_rounds = rounds;
   return LMPC_OK;
 }

@@ -52,6 +52,8 @@ struct lmpc_params {
   lmpc_vehicle veh;
 };
 
+#define LMPC_WARM_ROUNDS_MAX 4  // lmpc_set_warm_rounds' upper limit = the polish's rounds (polish_limits::rounds); a cold solve reports more iterations
+
 // LDS record sizes (in doubles) of the solve kernel; see DESIGN.md "data layout".
 #define LMPC_STAGE_STRIDE 78
 #define LMPC_KNOT_STRIDE 36

@@ -403,6 +403,7 @@ __device__ __forceinline__ float slot_inv_scale(int sl) {
 #define POLISH_THETA_L 1e8  // the simplex rows (always fp64)
 #define POLISH_STRONG 1e3   // a row with lam >= POLISH_STRONG t is one the interior point holds firmly
 #define WARM_ROUNDS 2       // repairs a warm start may spend before the cold start takes over
+static_assert(polish_limits<double>::rounds == LMPC_WARM_ROUNDS_MAX, "lmpc_set_warm_rounds' upper limit is the polish's");
 #define WARM_ACT 1e-9       // a box row of the plan counts as active within this slack (a polished plan sits on its bounds to ~1e-16)
 #define WARM_ACT_EY 1e-3    // boundary rows: their bounds move with the shift (the track's half-width over one knot's travel)
 template <typename real> struct vec2;
