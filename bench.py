@@ -290,6 +290,41 @@ def other_configs(steps, warmup):
     return out
 
 
+def closed_loop_leg(pkg, dev, cars=4096, periods=400):
+    """SURVEY.md 8(f) rank 1 measured next to the headline: `cars` cars in closed loop on the synthetic BARC-scale track, one
+    control period = linearisation + QP + lmpc_loop_advance_batch (input selection, plant step, shift / cold restart, statistics),
+    captured as a HIP graph; cold solves and the active-set warm start on the shifted previous plan."""
+    import torch
+    tr = pkg.workloads.synthetic_track("barc")
+    rng = np.random.default_rng(3)
+    s0 = rng.uniform(0, tr["L"], cars)
+    vel = np.interp(s0, np.arange(len(tr["vel"])) * tr["L"] / len(tr["vel"]), np.asarray(tr["vel"]))
+    x0 = torch.as_tensor(np.stack([s0, rng.uniform(-0.08, 0.08, cars), rng.normal(0, 0.03, cars), rng.uniform(0.6, 0.9, cars) * vel, np.zeros(cars), np.zeros(cars)]), device=dev)
+    u0 = torch.zeros((2, cars), dtype=torch.float64, device=dev)
+    out = {"cars": cars, "periods": periods, "horizon": 20, "unit": "car-steps/s",
+           "period": "linearise + QP + lmpc_loop_advance_batch (plant RK4 x 2, shift or cold restart, statistics); HIP graph"}
+    try:
+        for warm in (False, True):
+            sv = pkg.Solver(pkg.presets.barc_tracking_mpc(20), pkg.presets.barc_vehicle(), device=dev.index)
+            best, r = None, None
+            for _ in range(2):  # (the first run pays the capture and the workspace)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                r = pkg.closed_loop.run(sv, tr, x0, u0, steps=periods, speed_scale=0.9, graph=True, warm=warm)
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+                best = dt if best is None else min(best, dt)
+            sv.close()
+            key = "warm" if warm else "cold"
+            out[key] = {"value": cars * periods / best, "ms_per_period": best / periods * 1e3, "cars_with_a_failed_solve": int((r["n_fail"] > 0).sum()),
+                        "median_laps": float(r["distance"].median()) / float(tr["L"])}
+            if warm:
+                out[key]["warm_starts_accepted"] = r["warm_hit_rate"]
+    except Exception as ex:  # reported, not hidden
+        out["error"] = "%s: %s" % (type(ex).__name__, str(ex)[:300])
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -734,6 +769,7 @@ def main():
         default_run = (world == 1 and not lmpc and not iac and not f32 and not mixed and N == 20 and B == 4096)
         if default_run and not args.no_others:
             res["others"] = other_configs(args.steps, args.warmup)
+            res["closed_loop"] = closed_loop_leg(pkg, dev)
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()
