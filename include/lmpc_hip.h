@@ -421,7 +421,9 @@ int lmpc_plant_step_batch(lmpc_handle* h, int32_t batch, const lmpc_track* track
  *                         = max(itself, excursion of the body beyond the track edge at the new state against the bounds of knot 0),
  *                         n_fail [B] += 1 after a failed solve, *n_accepted += number of cars whose warm start was accepted
  *                         (status 0 and iters <= 4; needs iters).
- * The same arithmetic as the three entry points it replaces, bit for bit (tests/test_gpu_loop.py); a period of a closed loop is then
+ * The same arithmetic as the three entry points it replaces -- bit for bit, except that the last knot of a shifted solution (one model
+ * step from the knot before it) may differ by 1 - 2 ulp, the compiler contracting the inlined model differently in the two kernels
+ * (tests/test_gpu_loop.py) --; a period of a closed loop is then
  * three launches -- linearisation, QP, this -- instead of ~45.  SOA result layout only.  All pointers DEVICE. */
 int lmpc_loop_advance_batch(lmpc_handle* h, int32_t batch, const lmpc_track* track, const int32_t* status, const int32_t* iters,
                             const double* X_optm, const double* U_optm, double* x, double* u_prev, double dt, double dt_sim,

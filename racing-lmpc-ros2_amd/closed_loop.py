@@ -30,7 +30,7 @@ def run(solver, track: dict, x0, u0, steps: int, dt: float = 0.025, n_sub: int =
 
     fused=True (default) does everything behind the solve -- input selection, plant step, statistics, shift or cold restart -- with
     one launch, lmpc_loop_advance_batch; fused=False goes through lmpc_plant_step_batch, lmpc_shift_batch, lmpc_prepare_failed_batch
-    and torch element-wise operations (~45 launches per period), the same arithmetic (tests/test_gpu_loop.py: bit for bit).
+    and torch element-wise operations (~45 launches per period), the same arithmetic (tests/test_gpu_loop.py: bit for bit but for 1 - 2 ulp on the last knot's rollout).
 
     longest_first=True launches the QP kernel's workgroups in the order of the previous period's iteration counts, longest
     first (lmpc_set_launch_order): a car's count changes little from one period to the next, and the long problems then

@@ -1070,7 +1070,7 @@ int lmpc_loop_advance_batch(lmpc_handle* h, int32_t batch, const lmpc_track* tra
   if (batch == 0) return LMPC_OK;
   HIP_TRY(h, hipSetDevice(h->device));
   static_assert(sizeof(long long) == sizeof(int64_t) && sizeof(unsigned long long) == sizeof(uint64_t), "counter types");
-  hipLaunchKernelGGL(lmpc_loop_advance_kernel, dim3((batch + 63) / 64), dim3(64), 0, h->stream, h->P, batch, *track, status, iters, X_optm,
+  hipLaunchKernelGGL(lmpc_loop_advance_kernel, dim3((batch + 63) / 64), dim3(64 * LMPC_LOOP_WAVES), 0, h->stream, h->P, batch, *track, status, iters, X_optm,
                      U_optm, x, u_prev, dt, dt_sim, n_sub, speed_scale, speed_limit, restart_failed ? 1 : 0, X_ref, U_ref, T_ref, bound_left,
                      bound_right, curvatures, vel_ref, distance, worst_excess, reinterpret_cast<long long*>(n_fail),
                      reinterpret_cast<unsigned long long*>(n_accepted));

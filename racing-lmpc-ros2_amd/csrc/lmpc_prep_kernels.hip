@@ -260,65 +260,99 @@ __global__ __launch_bounds__(256) void lmpc_prepare_kernel(lmpc_params P, int B,
 // the plant step (racing_simulator.cpp:46-69,97-112), the bookkeeping a Monte-Carlo harness keeps per car, and the next
 // period's inputs: the warm-start shift (:245-254) or, for a car whose solve failed and `restart_failed`, the cold-start
 // preparation at its new state (:210-235, 261-292).  The same arithmetic as lmpc_plant_kernel, lmpc_shift_kernel and
-// lmpc_prepare_kernel in that order -- bit for bit (tests/test_gpu_loop.py) -- without the ~40 small launches between them.
-// One thread per car.  The reference arrays are updated IN PLACE (a thread reads knot i + 1 before it writes knot i + 1), so
-// they carry no __restrict__.
-__global__ __launch_bounds__(64) void lmpc_loop_advance_kernel(lmpc_params P, int B, lmpc_track trk, const int* __restrict__ status,
-                                                               const int* __restrict__ iters, const double* __restrict__ X_sol,
-                                                               const double* __restrict__ U_sol, double* __restrict__ x_io,
-                                                               double* __restrict__ u_prev, double dt, double dt_sim, int nsub,
-                                                               double speed_scale, double speed_limit, int restart_failed, double* X_ref,
-                                                               double* U_ref, double* T_ref, double* bl, double* br, double* curv,
-                                                               double* vref, double* __restrict__ distance,
-                                                               double* __restrict__ worst_excess, long long* __restrict__ n_fail,
-                                                               unsigned long long* __restrict__ n_accepted) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+// lmpc_prepare_kernel in that order (tests/test_gpu_loop.py: bit for bit, but for the last knot's one-step rollout, where the inlined
+// model is contracted differently here and there: 1 - 2 ulp) without the ~40 small launches between them.
+// A workgroup is 64 cars (the lanes) x LMPC_LOOP_WAVES waves.  Wave 0 applies the input, steps the plant and keeps the books;
+// the shift of a car whose solve succeeded has no chain in it except the last knot's rollout, so the waves share its knots
+// (wave w: knots w, w + W, ...; reads from the solution only, writes the references: no hazard, no barrier).  A car whose solve
+// failed is wave 0's alone, knot after knot: the cold restart is a rollout, and the shift of the OLD plan is done in place (a
+// thread reads knot i + 1 before it writes knot i + 1) -- which is why the reference arrays carry no __restrict__.
+#define LMPC_LOOP_WAVES 8
+__global__ __launch_bounds__(64 * LMPC_LOOP_WAVES) void lmpc_loop_advance_kernel(
+    lmpc_params P, int B, lmpc_track trk, const int* __restrict__ status, const int* __restrict__ iters, const double* __restrict__ X_sol,
+    const double* __restrict__ U_sol, double* __restrict__ x_io, double* __restrict__ u_prev, double dt, double dt_sim, int nsub,
+    double speed_scale, double speed_limit, int restart_failed, double* X_ref, double* U_ref, double* T_ref, double* bl, double* br,
+    double* curv, double* vref, double* __restrict__ distance, double* __restrict__ worst_excess, long long* __restrict__ n_fail,
+    unsigned long long* __restrict__ n_accepted) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int b = blockIdx.x * 64 + lane;
   const int N = P.N, NS = N - 1;
   const bool live = b < B;
   const bool ok = live && status[b] == 0;
-  if (n_accepted) {  // warm attempts accepted: at most LMPC_WARM_ROUNDS_MAX rounds; a cold solve takes more iterations than that
+  if (n_accepted && w == 0) {  // warm attempts accepted: at most LMPC_WARM_ROUNDS_MAX rounds; a cold solve takes more iterations than that
     const unsigned long long m = __ballot(ok && iters[b] <= LMPC_WARM_ROUNDS_MAX);
-    if ((threadIdx.x & 63) == 0 && m) atomicAdd(n_accepted, (unsigned long long)__popcll(m));
+    if (lane == 0 && m) atomicAdd(n_accepted, (unsigned long long)__popcll(m));
   }
   if (!live) return;
-  // ---- the input applied, the plant ----
-  double x[6], xn[6], u[2];
-#pragma unroll
-  for (int k = 0; k < 2; ++k) u[k] = ok ? U_sol[(size_t)(k * NS) * B + b] : U_ref[(size_t)(k * NS) * B + b];
-#pragma unroll
-  for (int k = 0; k < 6; ++k) x[k] = x_io[(size_t)k * B + b];
-  const double s_before = x[0];
-  for (int j = 0; j < nsub; ++j) {
-    if (fabs(x[3]) < 1e-6) x[3] = copysign(1e-6, x[3]);
-    const double kap = track_lookup(trk.curvature, trk.M, trk.L, x[0]);
-    lmpc_fd(P.veh, x, u, kap, dt_sim, xn);
-    const double s1 = xn[0], s2 = trk.L / 2.0;
-    const double kk = fabs(s2 - s1) + trk.L / 2.0;
-    const double ll = kk - fmod(kk, trk.L);
-    xn[0] = s1 + ll * ((s2 > s1) - (s2 < s1));
-#pragma unroll
-    for (int k = 0; k < 6; ++k) x[k] = xn[k];
-  }
-#pragma unroll
-  for (int k = 0; k < 6; ++k) x_io[(size_t)k * B + b] = x[k];
-#pragma unroll
-  for (int k = 0; k < 2; ++k) u_prev[(size_t)k * B + b] = u[k];
-  // ---- bookkeeping: abscissa travelled (unwrapped), worst excursion of the body beyond the track edge, failed solves ----
-  if (distance) {
-    const double ds = x[0] - s_before;
-    distance[b] += (ds < -trk.L / 2.0) ? ds + trk.L : ds;
-  }
-  if (worst_excess) {
-    const double half_b = P.veh.b / 2.0;
-    const double exc = fmax(x[1] + half_b - bl[b], br[b] - (x[1] - half_b));  // (knot 0 of the period that has just been driven)
-    worst_excess[b] = fmax(worst_excess[b], exc);
-  }
-  if (n_fail && !ok) n_fail[b] += 1;
-  // ---- the next period's inputs ----
   const double d = P.max_vel_ref_diff;
-  if (!ok && restart_failed) {  // cold start at the new state (lmpc_prepare_kernel)
-    const double u0[2] = {1e-9, 1e-9};
-    for (int i = 0; i < N; ++i) {
+  double x[6], xn[6], u[2];
+  if (w == 0) {
+    // ---- the input applied, the plant ----
+#pragma unroll
+    for (int k = 0; k < 2; ++k) u[k] = ok ? U_sol[(size_t)(k * NS) * B + b] : U_ref[(size_t)(k * NS) * B + b];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) x[k] = x_io[(size_t)k * B + b];
+    const double s_before = x[0];
+    for (int j = 0; j < nsub; ++j) {
+      if (fabs(x[3]) < 1e-6) x[3] = copysign(1e-6, x[3]);
+      const double kap = track_lookup(trk.curvature, trk.M, trk.L, x[0]);
+      lmpc_fd(P.veh, x, u, kap, dt_sim, xn);
+      const double s1 = xn[0], s2 = trk.L / 2.0;
+      const double kk = fabs(s2 - s1) + trk.L / 2.0;
+      const double ll = kk - fmod(kk, trk.L);
+      xn[0] = s1 + ll * ((s2 > s1) - (s2 < s1));
+#pragma unroll
+      for (int k = 0; k < 6; ++k) x[k] = xn[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) x_io[(size_t)k * B + b] = x[k];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) u_prev[(size_t)k * B + b] = u[k];
+    // ---- bookkeeping: abscissa travelled (unwrapped), worst excursion of the body beyond the track edge, failed solves ----
+    if (distance) {
+      const double ds = x[0] - s_before;
+      distance[b] += (ds < -trk.L / 2.0) ? ds + trk.L : ds;
+    }
+    if (worst_excess) {
+      const double half_b = P.veh.b / 2.0;
+      const double exc = fmax(x[1] + half_b - bl[b], br[b] - (x[1] - half_b));  // (knot 0 of the period that has just been driven)
+      worst_excess[b] = fmax(worst_excess[b], exc);
+    }
+    if (n_fail && !ok) n_fail[b] += 1;
+  }
+  // ---- the next period's inputs ----
+  if (!ok) {
+    if (w != 0) return;
+    if (restart_failed) {  // cold start at the new state (lmpc_prepare_kernel)
+      const double u0[2] = {1e-9, 1e-9};
+      for (int i = 0; i < N; ++i) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) X_ref[(size_t)(k * N + i) * B + b] = x[k];
+        double b_l, b_r, kap, vr;
+        sample_refs(trk, x[0], x[3], d, speed_scale, speed_limit, b_l, b_r, kap, vr);
+        bl[(size_t)i * B + b] = b_l;
+        br[(size_t)i * B + b] = b_r;
+        curv[(size_t)i * B + b] = kap;
+        vref[(size_t)i * B + b] = vr;
+        if (i < NS) {
+          U_ref[(size_t)(0 * NS + i) * B + b] = u0[0];
+          U_ref[(size_t)(1 * NS + i) * B + b] = u0[1];
+          T_ref[(size_t)i * B + b] = dt;
+          lmpc_fd(P.veh, x, u0, kap, dt, xn);
+#pragma unroll
+          for (int k = 0; k < 6; ++k) x[k] = xn[k];
+        }
+      }
+      return;
+    }
+    for (int i = 0; i < N; ++i) {  // the plan the failed solve started from, shifted in place (lmpc_shift_kernel with X_old = X_ref)
+      if (i < NS) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) x[k] = X_ref[(size_t)(k * N + i + 1) * B + b];
+      } else {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) x[k] = xn[k];
+      }
 #pragma unroll
       for (int k = 0; k < 6; ++k) X_ref[(size_t)(k * N + i) * B + b] = x[k];
       double b_l, b_r, kap, vr;
@@ -328,25 +362,32 @@ __global__ __launch_bounds__(64) void lmpc_loop_advance_kernel(lmpc_params P, in
       curv[(size_t)i * B + b] = kap;
       vref[(size_t)i * B + b] = vr;
       if (i < NS) {
-        U_ref[(size_t)(0 * NS + i) * B + b] = u0[0];
-        U_ref[(size_t)(1 * NS + i) * B + b] = u0[1];
-        T_ref[(size_t)i * B + b] = dt;
-        lmpc_fd(P.veh, x, u0, kap, dt, xn);
+        const int src = (i < NS - 1) ? i + 1 : NS - 1;
 #pragma unroll
-        for (int k = 0; k < 6; ++k) x[k] = xn[k];
+        for (int k = 0; k < 2; ++k) {
+          u[k] = U_ref[(size_t)(k * NS + src) * B + b];
+          U_ref[(size_t)(k * NS + i) * B + b] = u[k];
+        }
+        T_ref[(size_t)i * B + b] = dt;
+        if (i == NS - 1) lmpc_fd(P.veh, x, u, kap, dt, xn);
       }
     }
     return;
   }
-  const double* Xs = ok ? X_sol : X_ref;  // (lmpc_shift_kernel: the solution, or after a failed solve the plan it started from)
-  const double* Us = ok ? U_sol : U_ref;
-  for (int i = 0; i < N; ++i) {
+  // the solution, shifted: knot i of the new reference is knot i + 1 of the solution; the last one is rolled out from the
+  // new knot N - 2 with the repeated last input (racing_mpc_node.cpp:247-249)
+  for (int i = w; i < N; i += LMPC_LOOP_WAVES) {
     if (i < NS) {
 #pragma unroll
-      for (int k = 0; k < 6; ++k) x[k] = Xs[(size_t)(k * N + i + 1) * B + b];
+      for (int k = 0; k < 6; ++k) x[k] = X_sol[(size_t)(k * N + i + 1) * B + b];
     } else {
+      double xm[6];
 #pragma unroll
-      for (int k = 0; k < 6; ++k) x[k] = xn[k];
+      for (int k = 0; k < 6; ++k) xm[k] = X_sol[(size_t)(k * N + NS) * B + b];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) u[k] = U_sol[(size_t)(k * NS + NS - 1) * B + b];
+      const double kap_m = track_lookup(trk.curvature, trk.M, trk.L, xm[0]);
+      lmpc_fd(P.veh, xm, u, kap_m, dt, x);
     }
 #pragma unroll
     for (int k = 0; k < 6; ++k) X_ref[(size_t)(k * N + i) * B + b] = x[k];
@@ -359,12 +400,8 @@ __global__ __launch_bounds__(64) void lmpc_loop_advance_kernel(lmpc_params P, in
     if (i < NS) {
       const int src = (i < NS - 1) ? i + 1 : NS - 1;
 #pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        u[k] = Us[(size_t)(k * NS + src) * B + b];
-        U_ref[(size_t)(k * NS + i) * B + b] = u[k];
-      }
+      for (int k = 0; k < 2; ++k) U_ref[(size_t)(k * NS + i) * B + b] = U_sol[(size_t)(k * NS + src) * B + b];
       T_ref[(size_t)i * B + b] = dt;
-      if (i == NS - 1) lmpc_fd(P.veh, x, u, kap, dt, xn);
     }
   }
 }

@@ -39,7 +39,10 @@ for N, B, steps in ((20, 4096, 666), (20, 16384, 200), (20, 1024, 666), (60, 409
             dt, r = loop(N, B, steps, warm, fused)
             line += "  %s %.2f M car-steps/s (%.3f ms per period)" % ("one launch behind the solve" if fused else "separate launches", B * steps / dt / 1e6, dt / steps * 1e3)
             ref[fused] = r
-        same = torch.equal(ref[True]["x"], ref[False]["x"]) and torch.equal(ref[True]["n_fail"], ref[False]["n_fail"]) and torch.equal(ref[True]["distance"], ref[False]["distance"])
-        print(line + "; same final states, distances and failures: %s; accepted %s" % (same, ref[True]["warm_hit_rate"]), flush=True)
+        okc = ((ref[True]["n_fail"] == 0) & (ref[False]["n_fail"] == 0)).cpu().numpy()
+        sx = np.array([2000.0, 10.0, 0.1, 80.0, 2.0, 2.0])[:, None]
+        err = np.abs((ref[True]["x"].cpu().numpy() - ref[False]["x"].cpu().numpy()) / sx)[:, okc].max()
+        print(line + "; final states against each other %.1e (scaled); same cars failed: %s; accepted %s"
+              % (err, torch.equal(ref[True]["n_fail"] > 0, ref[False]["n_fail"] > 0), ref[True]["warm_hit_rate"]), flush=True)
 dt, r = loop(20, 4096, 666, True, True, graph=False)
 print("N = 20, 4096 cars, warm, one launch behind the solve, eager (no graph): %.2f M car-steps/s (%.3f ms per period)" % (4096 * 666 / dt / 1e6, dt / 666 * 1e3))
