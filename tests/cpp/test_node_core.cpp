@@ -61,6 +61,7 @@ int main(int argc, char** argv) {
   VehicleActuation act;
   MPCTelemetry tel;
   int n_published = 0, n_failed = 0, n_initial = 0, n_discarded = 0, n_diag = 0;
+  double iters_mean_sum = 0.0, iters_max_sum = 0.0, iters_min_sum = 0.0;
   bool changed = false;
   double travelled = 0.0, worst_excess = -1e9, solve_ms = 0.0, t = 0.0;
   const int max_steps = (int)(laps_wanted * L / 1.0 / dt);  // (bounded: at least 1 m/s average)
@@ -108,6 +109,9 @@ int main(int argc, char** argv) {
         if (!(mn <= mean && mean <= mx && mx > 0.0) || (da.status[0].level == DiagnosticStatus::WARN) != (mx > dt * 1e3) ||
             (da.status[1].level == DiagnosticStatus::WARN) != (it_max > 50) || it_max < 1) { std::puts("FAIL: diagnostics levels"); return 1; }
         if (node.take_diagnostics(da)) { std::puts("FAIL: diagnostics handed out twice"); return 1; }
+        iters_mean_sum += std::atof(da.status[1].values[1].second.c_str());  // (mean of the window of 10 this array reports)
+        iters_max_sum += it_max;
+        iters_min_sum += std::atof(da.status[1].values[2].second.c_str());
       }
       // racing_mpc_node.cpp:509-571, once, mid-run: the same race line loaded again is another reference-line object -- the plan
       // goes old Frenet -> global -> new Frenet and must come back where it was (abscissa modulo the lap), and the run goes on
@@ -150,8 +154,9 @@ int main(int argc, char** argv) {
     t += dt;
     if (!std::isfinite(x[3])) { std::puts("FAIL: plant state not finite"); return 1; }
   }
-  std::printf("laps %.3f time %.3f published %d failed %d initial %d discarded %d worst_excess %.4f mean_step_ms %.3f\n",
-              travelled / L, t, n_published, n_failed, n_initial, n_discarded, worst_excess, solve_ms / (n_published ? n_published : 1));
+  std::printf("laps %.3f time %.3f published %d failed %d initial %d discarded %d worst_excess %.4f mean_step_ms %.3f mean_iters %.2f (windows of 10: min %.2f max %.2f)\n",
+              travelled / L, t, n_published, n_failed, n_initial, n_discarded, worst_excess, solve_ms / (n_published ? n_published : 1),
+              n_diag ? iters_mean_sum / n_diag : 0.0, n_diag ? iters_min_sum / n_diag : 0.0, n_diag ? iters_max_sum / n_diag : 0.0);
   const bool ok = travelled >= laps_wanted * L && n_initial == 1 && n_discarded == 1 && n_failed <= n_published / 100 && worst_excess < 0.02 &&
                   n_diag == n_published / 10 && (changed || df || n_published < 57);
   if (df) std::fclose(df);
