@@ -267,7 +267,9 @@ __global__ __launch_bounds__(256) void lmpc_prepare_kernel(lmpc_params P, int B,
 // (wave w: knots w, w + W, ...; reads from the solution only, writes the references: no hazard, no barrier).  A car whose solve
 // failed is wave 0's alone, knot after knot: the cold restart is a rollout, and the shift of the OLD plan is done in place (a
 // thread reads knot i + 1 before it writes knot i + 1) -- which is why the reference arrays carry no __restrict__.
+#ifndef LMPC_LOOP_WAVES  // (4 / 8 / 16 measured on the closed loop, profiles/r05_tail_ab.txt: 6.49 / 6.53 / 6.36 M car-steps/s at 4096 cars warm)
 #define LMPC_LOOP_WAVES 8
+#endif
 __global__ __launch_bounds__(64 * LMPC_LOOP_WAVES) void lmpc_loop_advance_kernel(
     lmpc_params P, int B, lmpc_track trk, const int* __restrict__ status, const int* __restrict__ iters, const double* __restrict__ X_sol,
     const double* __restrict__ U_sol, double* __restrict__ x_io, double* __restrict__ u_prev, double dt, double dt_sim, int nsub,
