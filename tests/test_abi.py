@@ -45,3 +45,38 @@ def test_product_does_not_import_oracle():
         if f.suffix in (".py", ".hip", ".h", ".cpp", ".hpp") and f.is_file():
             src = f.read_text()
             assert not re.search(r"(import\s+oracle|from\s+oracle|from\s+\.+oracle|#include\s+[\"<][^\n]*oracle|liblmpc_oracle|oracle/_)", src), f
+
+
+def test_header_is_plain_c_and_the_closed_loop_example_links(pkg, tmp_path):
+    """include/lmpc_hip.h compiles as C11 (the boundary the reference's FFI would bind), and the C closed loop INTEGRATION.md shows --
+    cold start, then lmpc_solve_batch_warm + lmpc_loop_advance_batch per period -- compiles and links against the built library
+    (gcc, no HIP headers; nothing is run: there is no GPU here)."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    src = tmp_path / "loop.c"
+    src.write_text(r'''
+#include <stddef.h>
+#include "lmpc_hip.h"
+int run(lmpc_handle* h, int B, int periods, lmpc_track track, double dt, double scale, double vmax, double* x, double* u_prev,
+        double* X_ref, double* U_ref, double* T_ref, double* bl, double* br, double* kap, double* vref, double* X, double* U, double* dU,
+        int32_t* status, int32_t* iters, double* distance, double* worst_excess, int64_t* n_fail, uint64_t* n_accepted) {
+  int rc = lmpc_prepare_batch(h, B, &track, x, dt, scale, vmax, X_ref, U_ref, T_ref, bl, br, kap, vref);
+  for (int k = 0; k < periods && rc == LMPC_OK; ++k) {
+    rc = lmpc_solve_batch_warm(h, B, x, u_prev, X_ref, U_ref, T_ref, bl, br, kap, vref, track.L, X_ref, U_ref, X, U, dU, status, iters, NULL);
+    if (rc == LMPC_OK)
+      rc = lmpc_loop_advance_batch(h, B, &track, status, iters, X, U, x, u_prev, dt, dt / 2, 2, scale, vmax, 1, X_ref, U_ref, T_ref, bl, br,
+                                   kap, vref, distance, worst_excess, n_fail, n_accepted);
+  }
+  return rc;
+}
+int main(void) { return lmpc_set_warm_rounds(NULL, 0) == LMPC_ERR_ARGUMENT ? 0 : 1; }
+''')
+    lib = Path(pkg.capi.library_path()).resolve() if hasattr(pkg.capi, "library_path") else ROOT / "racing-lmpc-ros2_amd" / "lib" / "liblmpc_hip.so"
+    assert lib.exists()
+    exe = tmp_path / "loop"
+    r = subprocess.run([gcc, "-std=c11", "-Wall", "-Wextra", "-Werror", "-pedantic", f"-I{ROOT / 'include'}", str(src), "-o", str(exe),
+                        f"-L{lib.parent}", "-llmpc_hip", f"-Wl,-rpath,{lib.parent}", "-Wl,--allow-shlib-undefined"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
