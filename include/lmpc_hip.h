@@ -101,7 +101,7 @@ typedef struct lmpc_config {
   int32_t num_ss_pts;         /* S                                                          */
   int32_t num_ss_pts_per_lap; /* K                                                          */
   int32_t max_lap_stored;
-  int32_t max_iter;           /* interior-point iteration cap (<=0: default 40)             */
+  int32_t max_iter;           /* interior-point iteration cap (<=0: default 60)             */
   int32_t polish;             /* active-set polish of the interior-point answer, the role of OSQP's polish = true
                                  (racing_mpc.cpp:90-95): 0 (default) on, < 0 off; 1: on, and lmpc_solve_batch_mixed
                                  leaves out its fp64 pass -- problems whose fp32 answer it could not verify keep
@@ -207,12 +207,21 @@ int lmpc_solve_batch_warm(lmpc_handle* h, int32_t batch, const double* x_ic, con
  * block (racing_mpc.cpp:484-504).  In fp32: the stage records in LDS, the Riccati factor and sweeps and the stage rows --
  * half the LDS footprint, so twice the resident problems per CU where fp64 is capacity-bound.  Horizons: every N the
  * fp64 entry accepts for the tracking problem (iac_car_tracking_mpc.param.yaml ships N = 80); N <= 23 for the learning
- * problem (longer: LMPC_ERR_UNSUPPORTED, the fp64 entry serves them; so does the hard hull equality).
+ * problem.  A configuration without a reduced-precision kernel -- the learning problem at N >= 24 (barc_lmpc.param.yaml ships
+ * N = 40: measured slower than fp64 in this layout), the hard hull equality -- is SOLVED IN FP64 by this entry (round 6;
+ * it was LMPC_ERR_UNSUPPORTED): same results and statuses as lmpc_solve_batch, and lmpc_last_solve_precision() reports
+ * LMPC_PRECISION_F64 for the call, so a caller iterating over horizons needs no special case and can still tell what ran
+ * (lmpc_query_launch_for(h, LMPC_PRECISION_MIXED, ..) keeps answering LMPC_ERR_UNSUPPORTED for such a handle: "no mixed kernel").
  * Two passes when lmpc_config.polish = 0 (the default): the fp32 kernel ends with the active-set polish and a KKT test of
  * its answer (rows 1e-5, multipliers -1e-3, last step 1e-4, scaled); every problem whose answer did not pass -- polish
  * refused, out of iterations, infeasible by single-precision residuals -- is solved again by the fp64 kernel behind it,
- * which writes the fp64 entry's own answer and status over it (a percent of a batch).  Stated accuracy: 1e-3 (scaled) of
- * the fp64 answer on every problem; fit for well-scaled problems (IAC) and for the learning problem, NOT for the BARC
+ * which writes the fp64 entry's own answer and status over it (a percent of a batch).  Stated accuracy (scaled, against the fp64
+ * answer; tests/tolerances.py): 1e-3 on every problem of the tracking configurations and of the learning problem on states near the
+ * stored laps; on the learning workload of SURVEY.md 8(d) (random initial states) 1e-3 at the 99.99 % quantile and 5e-3 on every
+ * problem -- a few problems per 32768 pass the single-precision KKT test with the weights of two or three nearly exchangeable
+ * safe-set points off in the third digit (1.2 .. 3.4e-3 measured); away from the BASELINE shapes (every N, 96 points) 2e-3.
+ * lmpc_solve_batch_f32 has no fp64 pass behind it: 1e-3 on the BASELINE shape (N = 40), 2e-3 at N >= 65.
+ * Fit for well-scaled problems (IAC) and for the learning problem, NOT for the BARC
  * tracking problem at low speed, whose soft boundary needs complementarity below 1e-9.
  * polish < 0: one pass, the fp32 interior point's own answers (faster, a tail of problems up to 3e-2 away). */
 int lmpc_solve_batch_mixed(lmpc_handle* h, int32_t batch, const double* x_ic, const double* u_ic,
@@ -365,7 +374,9 @@ int lmpc_ss_query_idx_batch(lmpc_handle* h, int32_t batch, const double* query, 
 
 /* lmpc_solve_batch (precision = LMPC_PRECISION_F64) or lmpc_solve_batch_mixed (LMPC_PRECISION_MIXED) for the learning problem with
  * the safe set by reference: ss_idx [S][B] from lmpc_ss_query_idx_batch ON THIS HANDLE, against the store lmpc_set_safe_set left
- * on it (do not replace the store between the query and the solve).  Everything else as lmpc_solve_batch. */
+ * on it.  The store must be the one the query ran against: after another lmpc_set_safe_set (or without a query on this handle) the
+ * call is refused with LMPC_ERR_ARGUMENT, and a code that names no row of the store is read as "no point" (-1), never out of bounds.
+ * Everything else as lmpc_solve_batch. */
 int lmpc_solve_batch_ss_idx(lmpc_handle* h, int32_t batch, int32_t precision, const double* x_ic, const double* u_ic, const double* X_ref,
                             const double* U_ref, const double* T_ref, const double* bound_left, const double* bound_right,
                             const double* curvatures, const double* vel_ref, double total_length, const int32_t* ss_idx, double* X_optm,
@@ -477,6 +488,11 @@ int lmpc_query_residency(lmpc_handle* h, int32_t* problems_per_cu);
 #define LMPC_PRECISION_F32 1
 #define LMPC_PRECISION_MIXED 2
 int lmpc_query_launch_for(lmpc_handle* h, int32_t precision, int32_t* lds_bytes_per_problem, int32_t* problems_per_cu);
+
+/* The precision the most recent batched solve on this handle ran in: LMPC_PRECISION_MIXED after lmpc_solve_batch_mixed (or
+ * lmpc_solve_batch_ss_idx with that precision) where a reduced-precision kernel exists for the handle's (N, num_ss_pts),
+ * LMPC_PRECISION_F64 where the entry fell back to the fp64 kernels (above), LMPC_PRECISION_F32 after lmpc_solve_batch_f32. */
+int lmpc_last_solve_precision(const lmpc_handle* h, int32_t* precision);
 
 /* Per-kernel timing for benchmarks: when enabled, lmpc_solve_batch brackets its two launches
  * with HIP events on the handle's stream; lmpc_last_kernel_ms waits for them and returns the

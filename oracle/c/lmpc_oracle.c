@@ -1517,7 +1517,7 @@ static void setup_problem(prob_t* p, const lmpc_config* cfg, const lmpc_vehicle*
   p->N = N;
   p->has_sigma = cfg->q_boundary > 0.0;
   p->S = cfg->learning ? cfg->num_ss_pts : 0;
-  p->max_iter = cfg->max_iter > 0 ? cfg->max_iter : 40;
+  p->max_iter = cfg->max_iter > 0 ? cfg->max_iter : 60; /* (as lmpc_create) */
   p->tol = cfg->tol > 0 ? cfg->tol : 3e-14;
   for (int i = 0; i < N - 1; ++i) {
     double x[6], u[2], xp[6];

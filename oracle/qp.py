@@ -105,8 +105,12 @@ def effective_bounds(cfg: MPCConfig, veh: Vehicle):
     return u_lo, u_hi, du_lo, du_hi
 
 
-def build_qp(cfg: MPCConfig, veh: Vehicle, inp: dict, ss_x=None, ss_j=None) -> DenseQP:
-    """Assemble the QP exactly as RacingMPC::RacingMPC builds it (racing_mpc.cpp:106-201)."""
+def build_qp(cfg: MPCConfig, veh: Vehicle, inp: dict, ss_x=None, ss_j=None, lin=None) -> DenseQP:
+    """Assemble the QP exactly as RacingMPC::RacingMPC builds it (racing_mpc.cpp:106-201).
+
+    lin = (A [N-1,6,6], B [N-1,6,2], g [N-1,6]): stage models to use INSTEAD of the linearisation about (X_ref, U_ref) -- the model
+    with the error-dynamics regression's correction added (safe_set.cpp:182-245), which has no caller upstream and therefore no place
+    in the reference's problem definition; the tests that compare on regressed models pass the product's corrected (A, B, g) here."""
     N = cfg.N
     learning = cfg.learning
     S = 0
@@ -124,7 +128,7 @@ def build_qp(cfg: MPCConfig, veh: Vehicle, inp: dict, ss_x=None, ss_j=None) -> D
     bl = np.asarray(inp["bound_left"], dtype=np.float64).reshape(-1)
     br = np.asarray(inp["bound_right"], dtype=np.float64).reshape(-1)
     vref = np.asarray(inp["vel_ref"], dtype=np.float64).reshape(-1)
-    Ad, Bd, gd = linearise(cfg, veh, inp)
+    Ad, Bd, gd = linearise(cfg, veh, inp) if lin is None else (np.asarray(a, dtype=np.float64) for a in lin)
 
     R2 = cfg.R + cfg.R.T
     Rd2 = cfg.R_d + cfg.R_d.T

@@ -21,7 +21,8 @@ _ABI_SYMBOLS = ("lmpc_create", "lmpc_destroy", "lmpc_last_error", "lmpc_set_stre
                 "lmpc_last_kernel_ms", "lmpc_query_residency", "lmpc_query_launch_for", "lmpc_solve_host", "lmpc_shift_batch",
                 "lmpc_plant_step_batch", "lmpc_solve_full_dynamics_batch", "lmpc_solve_full_dynamics_host", "lmpc_set_regression_laps", "lmpc_regress_batch", "lmpc_ss_query_host", "lmpc_solve_batch_f32",
                 "lmpc_solve_batch_mixed", "lmpc_prepare_failed_batch", "lmpc_set_launch_order", "lmpc_set_warm_rounds", "lmpc_loop_advance_batch", "lmpc_launch_order_from_iters", "lmpc_set_output_layout",
-                "lmpc_ss_query_idx_batch", "lmpc_solve_batch_ss_idx", "lmpc_solve_batch_warm", "lmpc_solve_host_warm")
+                "lmpc_ss_query_idx_batch", "lmpc_solve_batch_ss_idx", "lmpc_solve_batch_warm", "lmpc_solve_host_warm",
+                "lmpc_last_solve_precision")
 
 
 class LmpcError(RuntimeError):
@@ -359,6 +360,9 @@ class Solver:
         B = a[0].shape[1]
         if out is None:
             out = self.alloc_outputs(B)
+        if warm is not None and mixed:
+            # (this combination used to run the fp64 warm solve and say nothing)
+            raise ValueError("Solver.solve: warm start and mixed precision do not combine (lmpc_solve_batch_warm is the fp64 entry)")
         if warm is not None:
             # lmpc_solve_batch_warm: warm = True takes (X_ref, U_ref) as the plan (what the node does), or a dict with X_optm_ref / U_optm_ref
             wx = a[2] if warm is True else self._t(warm["X_optm_ref"])
@@ -387,6 +391,13 @@ class Solver:
         self._check(rc, "lmpc_solve_batch_mixed" if mixed else "lmpc_solve_batch")
         out["_inputs_keepalive"] = a
         return out
+
+    def last_solve_precision(self) -> str:
+        """lmpc_last_solve_precision: "f64", "f32" or "mixed" -- what the most recent batched solve ran in (solve(mixed=True) falls
+        back to fp64 where no reduced-precision kernel exists for this (N, num_ss_pts): include/lmpc_hip.h)."""
+        p = C.c_int32(-1)
+        self._check(self.lib.lmpc_last_solve_precision(self._h, C.byref(p)), "lmpc_last_solve_precision")
+        return {0: "f64", 1: "f32", 2: "mixed"}[p.value]
 
     # ---- single precision (BASELINE configs[3]) ----
     def solve_f32(self, inp: dict, out: dict | None = None):

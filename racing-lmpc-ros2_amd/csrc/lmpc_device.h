@@ -45,6 +45,7 @@ struct lmpc_params {
   const int* ss_npts;       // [ss_laps]
   const int* ss_off;        // [ss_laps] first row of each lap
   int ss_laps;
+  int ss_rows;              // rows of the store: a code naming a row past it (or a fourth copy) is treated as "no point"
   double ss_L;
   // warm start (lmpc_solve_batch_warm): the plan the active-set attempt starts from, [6][N][B] and [2][N-1][B]; null: a cold solve
   const double* warm_X;

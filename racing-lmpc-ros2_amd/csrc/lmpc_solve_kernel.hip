@@ -2439,7 +2439,7 @@ __device__ __forceinline__ void lmpc_solve_problem(
     const bool by_ref = P.ss_idx != nullptr;
     auto ss_point = [&](int j, io (&pt)[6], io& jv) {  // point j of this problem's safe set (storage precision) and its J (not yet relative)
       const int code = P.ss_idx[(size_t)j * B + b];
-      if (code < 0) {
+      if (code < 0 || (code >> 2) >= P.ss_rows || (code & 3) == 3) {  // (no point; or not a code of this store: never read out of bounds)
 #pragma unroll
         for (int k = 0; k < 6; ++k) pt[k] = io(0);
         jv = io(0);

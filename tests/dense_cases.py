@@ -22,6 +22,8 @@ CASES = {
     "iac_tracking_n40": ("iac", 40, 512, "configs[3]"),
     "barc_lmpc_n20_s160": ("lrn", 20, 512, "configs[2] / configs[4] (5 laps, 160 points)"),
     "barc_lmpc_n20_s96": ("rec", 20, 512, "configs[2] on the reference's recorded laps (3 laps, 96 points)"),
+    "barc_lmpc_spec_n20_s160": ("spc", 20, 512, "configs[2] / configs[4] AS bench.py QUOTES THEM since round 5 (--lmpc-data spec): laps recorded by the "
+                                               "tracking loop at five speed scales, configs[1]'s random x0 (SURVEY.md 8d config 3)"),
     "barc_tracking_n40": ("trk", 40, 128, "shipped horizon"),
     "barc_tracking_n60": ("trk", 60, 96, "shipped horizon (barc_tracking_mpc.param.yaml)"),
     "barc_tracking_n80": ("trk", 80, 64, "shipped horizon"),
@@ -29,6 +31,22 @@ CASES = {
     "barc_lmpc_n40_s160": ("lrn", 40, 96, "shipped horizon (barc_lmpc.param.yaml)"),
     "barc_lmpc_n60_s160": ("lrn", 60, 64, "shipped horizon (iac_car_lmpc.param.yaml's N)"),
 }
+
+
+def spec_laps():
+    """The committed recording of SURVEY.md 8(d) config 3's laps: [n][6] each, oldest (slowest) first."""
+    from pathlib import Path
+
+    with np.load(Path(__file__).resolve().parent / "golden" / "spec_laps.npz") as z:
+        return [z["lap%d" % i] for i in range(5)]
+
+
+def ss_query_point(inp: dict, L: float) -> np.ndarray:
+    """(s, e_y) of the last reference knot, abscissa aligned to x_ic (racing_mpc.cpp:219-223, 249-254; lmpc_utils/utils.hpp:35-41) --
+    as bench.py forms the safe-set query."""
+    s_last, s0 = inp["X_ref"][0, -1], inp["x_ic"][0]
+    kk = np.abs(s0 - s_last) + L / 2
+    return np.stack([s_last + (kk - np.fmod(kk, L)) * np.sign(s0 - s_last), inp["X_ref"][1, -1]])
 
 
 def build(pkg, name: str):
@@ -55,6 +73,18 @@ def build(pkg, name: str):
         kk = np.abs(s0 - s_last) + L / 2      # lmpc_utils/utils.hpp:35-41, as bench.py forms the query
         q = np.stack([s_last + (kk - np.fmod(kk, L)) * np.sign(s0 - s_last), inp["X_ref"][1, -1]])
         ss_x, ss_j, _ = cbind.ss_query_batch(laps, L, cfg.num_ss_pts, cfg.num_ss_pts_per_lap, q)
+        return cfg, veh, inp, ss_x, ss_j
+    if family == "spc":
+        # SURVEY.md 8(d) config 3 as written, = bench.py --workload lmpc --lmpc-data spec on rank 0: the five laps the tracking loop
+        # records at speed scales 0.80 .. 1.0 (closed_loop.record_laps on the GPU; committed as DATA, tests/golden/spec_laps.npz, by
+        # tests/golden/make_spec_laps.py -- tests/test_gpu_spec_workload.py holds a fresh recording to the file) and configs[1]'s x0
+        tr = wl.synthetic_track("barc")
+        cfg, veh = P.barc_lmpc(N, 5), P.barc_vehicle()
+        laps = spec_laps()
+        x, u = wl.sample_initial_states("barc", BATCH, tr["L"], [-0.01, -0.314159], [0.01, 0.314159], seed=0)
+        inp = S.cold_start_inputs(cfg, veh, tr, x[:count], u[:count], 0.025)
+        q = ss_query_point(inp, tr["L"])
+        ss_x, ss_j, _ = cbind.ss_query_batch(laps, tr["L"], cfg.num_ss_pts, cfg.num_ss_pts_per_lap, q)
         return cfg, veh, inp, ss_x, ss_j
     if family == "rec":
         import lmpc_scenario as LS

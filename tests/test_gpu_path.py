@@ -762,8 +762,10 @@ def test_mixed_precision_solve_on_the_iac_problem(pkg, golden):
     lm.set_safe_set(LS.load_laps(), LS.L_BARC_SS)
     veh_, cfg_, tr_, laps_, inp_, q_ = LS.make(4, 2, N=40)
     ss_x, ss_j, _ = lm.ss_query(q_)
-    with pytest.raises(pkg.LmpcError, match="no kernel"):
-        lm.solve(inp_, ss_x=ss_x, ss_j=ss_j, mixed=True)
+    om_, o64_ = to_np(lm.solve(inp_, ss_x=ss_x, ss_j=ss_j, mixed=True)), None
+    assert lm.last_solve_precision() == "f64"   # (round 6: served by the fp64 kernels instead of LMPC_ERR_UNSUPPORTED; the dense
+    o64_ = to_np(lm.solve(inp_, ss_x=ss_x, ss_j=ss_j))   #  N = 40 fixture holds that route in tests/test_gpu_dense_fixtures.py)
+    assert np.array_equal(om_["X_optm"], o64_["X_optm"]) and np.array_equal(om_["status"], o64_["status"])
 
 
 def test_c_abi_rejects_misuse_without_crashing(pkg):
@@ -833,6 +835,39 @@ def test_bench_two_ranks_preflight_on_one_gpu(launcher):
     assert d["n_gpus"] == 2 and d["steps"] == 6 and d["scaling"] == "weak" and d["value"] > 1e4
     assert d["solved_fraction"] > 0.99 and "cpu_baseline" not in d
     assert [r_["rank"] for r_ in d["config"]["ranks_seen"]] == [0, 1]
+
+
+@pytest.mark.parametrize("name,argv", [
+    ("configs[3]", ["--workload", "iac", "--horizon", "40", "--precision", "f32", "--batch", "1024"]),
+    ("configs[4]", ["--workload", "lmpc", "--precision", "mixed", "--regression", "--batch", "2048"]),
+])
+def test_bench_two_ranks_preflight_of_the_configs_that_name_eight_gpus(name, argv):
+    """The same preflight for the two BASELINE configs that are DEFINED as multi-GPU runs (until round 6 only
+    the default tracking workload had ever run with world > 1): configs[3] -- IAC, N = 40, fp32, a float gather buffer -- and
+    configs[4] -- learning + regression, mixed precision; rank 0 records the laps and the regression's sample pairs and broadcasts
+    them (the safe set is replicated), every rank draws its own states."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parents[1]
+    env = dict(os.environ, LMPC_BENCH_SHARED_GPU="1", MASTER_ADDR="127.0.0.1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", str(root / "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--min-window", "0.1"] + argv
+    r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 1e4 and d["solved_fraction"] > 0.99, d
+    assert [r_["rank"] for r_ in d["config"]["ranks_seen"]] == [0, 1]
+    g = d["config"]["gathered"]
+    assert g["problems"] == 2 * d["config"]["batch_per_gpu"] and g["solved_fraction"] > 0.99, g
+    assert d["dtype"] == ("f32" if name == "configs[3]" else "f32 iteration, f64 arrays")
 
 
 def test_bench_refuses_a_world_that_disagrees_with_gpus():
@@ -963,8 +998,10 @@ def test_hard_convex_hull_equality(pkg):
     assert n_inf_agree >= 0.9 * n_inf
     both = (o["status"] == 0) & (tw["status"] == 0)
     assert both.sum() >= 0.9 * n_dense and scaled_err(o["X_optm"][:, :, both], tw["X_optm"][:, :, both], P.SCALE_X) < TOL_TWIN
-    with pytest.raises(pkg.LmpcError, match="fp64 only"):
-        solver.solve(inp, out, ss_x=ss_x, ss_j=ss_j, mixed=True)
+    # the mixed entry serves the hard equality in fp64 (round 6: it was LMPC_ERR_UNSUPPORTED "fp64 only") and says so
+    st64 = o["status"].copy()
+    om = to_np(solver.solve(inp, out, ss_x=ss_x, ss_j=ss_j, mixed=True))
+    assert solver.last_solve_precision() == "f64" and np.array_equal(om["status"], st64) and np.array_equal(om["X_optm"], o["X_optm"])
 
 
 @pytest.mark.parametrize("N,n_laps,n_dense", [(40, 3, 6), (80, 5, 3)])

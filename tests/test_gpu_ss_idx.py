@@ -128,3 +128,41 @@ def test_padded_safe_set_against_the_dense_optimum(pkg, by_ref):
         exu, ed = per_problem_err({k: r[k][..., :16] for k in ref}, ref)
         assert exu.max() < TOL_XU and ed.max() < TOL_DU, (who, exu.max(), ed.max())
     sv.close()
+
+
+def test_stale_or_foreign_codes_are_refused_not_dereferenced(pkg):
+    """the gather trusted caller-supplied codes.  (1) Codes from before another lmpc_set_safe_set -- possibly a smaller
+    store -- are refused by the entry point (a generation counter on the handle), as are codes on a handle that never ran the index
+    query; (2) a code that names no row of the store (or a fourth copy) is read as "no point", never out of bounds: the problem
+    then solves on the points that are left, or reports a status, but the launch does not fault."""
+    B = 256
+    sv, cfg, laps, tr, inp, q = _setup(pkg, 5, B)
+    S = int(cfg["num_ss_pts"])
+    idx, _ = sv.ss_query_idx(q)
+
+    def solve(codes):
+        out = sv.alloc_outputs(B)
+        out["convex_combi_optm"] = torch.zeros((S, B), dtype=torch.float64, device="cuda")
+        return sv.solve(inp, out, ss_idx=codes)
+
+    ok = solve(idx)
+    assert (ok["status"] == 0).all()
+    sv.set_safe_set(laps[:2], tr["L"])                 # a smaller store: the old codes point past its end
+    with pytest.raises(pkg.LmpcError, match="safe set was replaced"):
+        solve(idx)
+    idx2, _ = sv.ss_query_idx(q)                        # a fresh query on the new store is accepted again
+    assert (solve(idx2)["status"].cpu().numpy() <= 2).all()
+    other = pkg.Solver(cfg, pkg.presets.barc_vehicle(), device=0)
+    other.set_safe_set(laps, tr["L"])
+    with pytest.raises(pkg.LmpcError, match="no such query ran"):
+        out = other.alloc_outputs(B)
+        other.solve(inp, out, ss_idx=idx)
+    other.close()
+    # garbage codes inside a valid generation: rows past the store, the fourth copy
+    bad = idx2.clone()
+    bad[::3] = (10 ** 6) * 4 + 1
+    bad[1::3] = bad[1::3] | 3
+    st = solve(bad)["status"].cpu().numpy()
+    torch.cuda.synchronize()
+    assert ((st >= 0) & (st <= 2)).all()
+    sv.close()
