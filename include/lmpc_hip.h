@@ -194,11 +194,44 @@ int lmpc_solve_batch(lmpc_handle* h, int32_t batch, const double* x_ic, const do
  * the periods of a closed loop -- the answer is the optimum the cold solve finds (same 1e-6 contract; measured 1e-11 apart) for
  * about two iterations' worth of work instead of seven; `iters` then counts the rounds (1 or 2).  Refused, the call IS
  * lmpc_solve_batch (the rounds spent are added to `iters`).  A bad plan costs time, never correctness: nothing is returned that
- * has not passed the KKT test of this problem.  fp64 tracking problem; learning handles are refused (LMPC_ERR_UNSUPPORTED). */
+ * has not passed the KKT test of this problem.  fp64 tracking problem; learning handles: lmpc_solve_batch_warm_ss below. */
 int lmpc_solve_batch_warm(lmpc_handle* h, int32_t batch, const double* x_ic, const double* u_ic, const double* X_ref, const double* U_ref,
                           const double* T_ref, const double* bound_left, const double* bound_right, const double* curvatures,
                           const double* vel_ref, double total_length, const double* X_optm_ref, const double* U_optm_ref, double* X_optm,
                           double* U_optm, double* dU_optm, int32_t* status, int32_t* iters, double* kkt);
+
+/* The same for the LEARNING problem (round 6; racing_mpc.cpp:281 `set_initial(convex_combi_, convex_combi_optm_ref)` and :293-305
+ * apply to the learning controller too).  One more piece of the plan: convex_combi_optm_ref [S][B], the simplex weights of the plan's
+ * terminal point ALIGNED WITH THIS CALL'S safe-set points (entry j weighs point j of ss_x / ss_idx).  Their support is the working
+ * set of the simplex rows -- free where the weight is positive, held at zero elsewhere --, the weights start the multiplier steps, the
+ * stage rows' working set is read off (X_optm_ref, U_optm_ref) as above; the candidate is verified against the KKT conditions of this
+ * problem (simplex rows included) and repaired, or the cold solve runs.  The safe set as arrays (ss_x, ss_j; ss_idx NULL) or by
+ * reference (ss_idx from lmpc_ss_query_idx_batch on this handle; ss_x, ss_j NULL).  The query returns its neighbours nearest first, so
+ * from one control period to the next the POSITION of a point in the set changes: lmpc_shift_lambda_batch below carries the previous
+ * solution's weights over by the identity of the points.  convex_combi_optm_ref NULL (or all zero): the cold solve.  fp64; horizons up
+ * to N = 60 (longer: the cold solve).  lmpc_get_warm_accepted tells which problems took the short route. */
+int lmpc_solve_batch_warm_ss(lmpc_handle* h, int32_t batch, const double* x_ic, const double* u_ic, const double* X_ref, const double* U_ref,
+                             const double* T_ref, const double* bound_left, const double* bound_right, const double* curvatures,
+                             const double* vel_ref, double total_length, const double* ss_x, const double* ss_j, const int32_t* ss_idx,
+                             const double* X_optm_ref, const double* U_optm_ref, const double* convex_combi_optm_ref, double* X_optm,
+                             double* U_optm, double* dU_optm, double* convex_combi_optm, int32_t* status, int32_t* iters, double* kkt);
+
+/* convex_combi_optm_ref for lmpc_solve_batch_warm_ss when the safe set goes by reference: lambda_prev [S][B] of the previous
+ * solution on the codes ss_idx_prev [S][B] it was solved on -> lambda_ref [S][B] on this period's codes ss_idx.  From one period to
+ * the next a support point of the optimum stays, moves one recorded sample along its lap, or two (measured in the LMPC experiment):
+ * every support point (weight > 1e-9) is placed on the sample `advance` steps on when that is among the new neighbours, else on
+ * the point itself, else `advance` + 1 steps on -- at most six positive entries per problem, what the solver's terminal block keeps
+ * explicit; a support point none of whose candidates is in the new set drops out (the solver renormalises).  An active-set start
+ * needs the support RIGHT: in the LMPC experiment this guess is (advance = 1; four repair rounds) for a quarter of the periods, and
+ * the rest pay the refused rounds on top of their cold solve -- closed_loop.run_lmpc leaves it off by default.
+ * No counterpart upstream: the reference hands the previous weights to OSQP by position.  All pointers DEVICE. */
+int lmpc_shift_lambda_batch(lmpc_handle* h, int32_t batch, const int32_t* ss_idx_prev, const double* lambda_prev, const int32_t* ss_idx,
+                            int32_t advance, double* lambda_ref);
+
+/* accepted [batch] (DEVICE, int32): 1 where the most recent warm solve of this batch size on this handle (lmpc_solve_batch_warm,
+ * lmpc_solve_batch_warm_ss) returned the active-set attempt's answer, 0 where the cold solve ran (refused attempt, or no warm kernel
+ * for the configuration).  Written by the kernel itself (until round 6 callers inferred it from iters <= 4). */
+int lmpc_get_warm_accepted(lmpc_handle* h, int32_t batch, int32_t* accepted);
 
 /* Mixed precision (BASELINE configs[4]: "mixed fp32/fp64 KKT"): same arguments, layouts and fp64 arrays as
  * lmpc_solve_batch.  In fp64: the linearisation (discrete_dynamics_jacobian), the error-dynamics regression onto it when
@@ -274,6 +307,14 @@ int lmpc_solve_host_warm(lmpc_handle* h, const double* x_ic, const double* u_ic,
                          const double* T_ref, const double* bound_left, const double* bound_right, const double* curvatures,
                          const double* vel_ref, double total_length, const double* X_optm_ref, const double* U_optm_ref, double* X_optm,
                          double* U_optm, double* dU_optm, int32_t* status, int32_t* iters);
+
+/* lmpc_solve_batch_warm_ss for ONE problem with HOST pointers (layouts of lmpc_solve_host; convex_combi_optm_ref S values): what the
+ * facade's RacingMPC::solve calls for a learning controller when `convex_combi_optm_ref` is among the inputs (racing_mpc.cpp:281). */
+int lmpc_solve_host_warm_ss(lmpc_handle* h, const double* x_ic, const double* u_ic, const double* X_ref, const double* U_ref,
+                            const double* T_ref, const double* bound_left, const double* bound_right, const double* curvatures,
+                            const double* vel_ref, double total_length, const double* ss_x, const double* ss_j, const double* X_optm_ref,
+                            const double* U_optm_ref, const double* convex_combi_optm_ref, double* X_optm, double* U_optm, double* dU_optm,
+                            double* convex_combi_optm, int32_t* status, int32_t* iters);
 
 /* RacingMPC(full_dynamics = true)::solve for a batch (racing_mpc.cpp:67-84: IPOPT on the problem whose dynamics rows are
  * x_{i+1} = f_d(x_i, u_i, k_i, t_i), :162-166, instead of their linearisation; the node uses it for its very first
@@ -430,7 +471,7 @@ int lmpc_plant_step_batch(lmpc_handle* h, int32_t batch, const lmpc_track* track
  *                         bound_right, curvatures, vel_ref are updated IN PLACE (they must not alias X_optm / U_optm);
  *   bookkeeping        -- optional accumulators, any of them NULL: distance [B] += abscissa travelled (unwrapped), worst_excess [B]
  *                         = max(itself, excursion of the body beyond the track edge at the new state against the bounds of knot 0),
- *                         n_fail [B] += 1 after a failed solve, *n_accepted += number of cars whose warm start was accepted
+ *                         n_fail [B] += 1 after a failed solve, *n_accepted += number of cars whose warm start was accepted (the warm kernel's own flag; 0 after a cold solve)
  *                         (status 0 and iters <= 4; needs iters).
  * The same arithmetic as the three entry points it replaces -- bit for bit, except that the last knot of a shifted solution (one model
  * step from the knot before it) may differ by 1 - 2 ulp, the compiler contracting the inlined model differently in the two kernels

@@ -220,6 +220,8 @@ typedef struct {
   double ss0[6];
   int warm;                       /* lmpc_oracle_solve_range_warm: (X_ref, U_ref) is the previous optimal plan, shifted */
   double zw[NMAX][8], vw[NMAX][2]; /* that plan in the solver's variables */
+  int has_lamw;                    /* learning: the plan's simplex weights were handed in (convex_combi_optm_ref, racing_mpc.cpp:281) */
+  double lamw[SMAX];               /* ... per KEPT point (the copies of a run report 0 and are ignored) */
   int S_in, ss_map[SMAX]; /* points as handed in, and which of them each kept point is (runs of identical points are one point) */
   int hard_hull; /* all-zero convex_hull_slack: the hull row is an equality, realised as the penalty limit */
   /* bounds per slot */
@@ -1144,7 +1146,19 @@ static int ipm_solve(prob_t* p, work_t* w, polish_t* pq, int* iters_out, double*
    * the track's change over one knot, so they are taken with a tolerance --; (3) the polish solves on that set, verifies the KKT
    * conditions of THIS problem and repairs the set, WARM_ROUNDS times at most.  Accepted: the optimum, for the price of about two
    * iterations.  Refused: the cold start below, as if nothing had happened (the attempt has cost about two more). */
-  if (p->warm && pq && !S) {
+  /* The learning problem (round 6) takes the same route with one more piece of the plan: the simplex weights of its terminal point,
+   * the reference's convex_combi_optm_ref (set_initial(convex_combi_, ...), racing_mpc.cpp:281).  Their support -- the safe-set
+   * points that carried weight -- is the working set of the simplex rows: free where the plan's weight is positive, held at zero
+   * elsewhere (a polished plan's held weights are zero to rounding); the weights themselves start the multiplier steps.  Without
+   * them there is no working set to start from (all S weights free is more than the terminal block keeps explicit) and the solve is
+   * cold. */
+  int lam_ok = !S;
+  if (S && p->has_lamw) {
+    double sum = 0.0;
+    for (int j = 0; j < S; ++j) sum += p->lamw[j] > 0.0 ? p->lamw[j] : 0.0;
+    lam_ok = sum > 0.0;
+  }
+  if (p->warm && pq && lam_ok) {
     for (int i = 0; i < N - 1; ++i) {
       for (int a = 0; a < 2; ++a) {
         double acc = p->vw[i][a];
@@ -1182,6 +1196,18 @@ static int ipm_solve(prob_t* p, work_t* w, polish_t* pq, int* iters_out, double*
           ++mw;
         }
       }
+    if (S) {
+      double sum = 0.0;
+      for (int j = 0; j < S; ++j) sum += p->lamw[j] > 0.0 ? p->lamw[j] : 0.0;
+      for (int j = 0; j < S; ++j) {
+        const double lm = (p->lamw[j] > 0.0 ? p->lamw[j] : 0.0) / sum;
+        const int fr = lm > WARM_ACT;
+        p->lmb[j] = lm;
+        p->tl[j] = fr ? lm : 0.0; /* (the polish classifies by ll > tl: held) */
+        p->ll[j] = fr ? 0.0 : 1.0;
+        ++mw;
+      }
+    }
     w->frozen_lambda = 0;
     int wr = 0;
     double wmu = 0.0;
@@ -1204,6 +1230,12 @@ static int ipm_solve(prob_t* p, work_t* w, polish_t* pq, int* iters_out, double*
     for (int i = 1; i < N; ++i) memset(p->z[i], 0, sizeof(p->z[i]));
     memset(p->v, 0, sizeof(p->v));
     p->sigma = 0.0;
+    for (int j = 0; j < S; ++j) {
+      p->lmb[j] = 1.0 / S;
+      p->tl[j] = p->ll[j] = 0.0;
+      w->thl[j] = 1.0;
+      w->cfl[j] = 0.0;
+    }
     w->frozen_lambda = 1;
     newton_factor(p, w, 0);
   }
@@ -1627,7 +1659,8 @@ static int solve_range_impl(const lmpc_config* cfg, const lmpc_vehicle* veh, int
                             const double* bound_right, const double* curvatures,
                             const double* vel_ref, const double* ss_x, const double* ss_j,
                             double* X_optm, double* U_optm, double* dU_optm, double* lambda_out,
-                            int32_t* status, int32_t* iters, double* kkt, int warm, const double* X_plan, const double* U_plan);
+                            int32_t* status, int32_t* iters, double* kkt, int warm, const double* X_plan, const double* U_plan,
+                            const double* lam_plan);
 
 /* Same signature family as lmpc_solve_batch (host pointers); b0..b1 is the slice solved. */
 int lmpc_oracle_solve_range(const lmpc_config* cfg, const lmpc_vehicle* veh, int32_t batch, int32_t b0,
@@ -1638,7 +1671,7 @@ int lmpc_oracle_solve_range(const lmpc_config* cfg, const lmpc_vehicle* veh, int
                             double* X_optm, double* U_optm, double* dU_optm, double* lambda_out,
                             int32_t* status, int32_t* iters, double* kkt) {
   return solve_range_impl(cfg, veh, batch, b0, b1, x_ic, u_ic, X_ref, U_ref, T_ref, bound_left, bound_right, curvatures, vel_ref, ss_x, ss_j,
-                          X_optm, U_optm, dU_optm, lambda_out, status, iters, kkt, 0, NULL, NULL);
+                          X_optm, U_optm, dU_optm, lambda_out, status, iters, kkt, 0, NULL, NULL, NULL);
 }
 
 /* lmpc_solve_batch_warm: (X_ref, U_ref) is the previous optimal plan, shifted (see ipm_solve) */
@@ -1650,7 +1683,7 @@ int lmpc_oracle_solve_range_warm(const lmpc_config* cfg, const lmpc_vehicle* veh
                                  double* X_optm, double* U_optm, double* dU_optm, double* lambda_out,
                                  int32_t* status, int32_t* iters, double* kkt) {
   return solve_range_impl(cfg, veh, batch, b0, b1, x_ic, u_ic, X_ref, U_ref, T_ref, bound_left, bound_right, curvatures, vel_ref, ss_x, ss_j,
-                          X_optm, U_optm, dU_optm, lambda_out, status, iters, kkt, 1, X_ref, U_ref);
+                          X_optm, U_optm, dU_optm, lambda_out, status, iters, kkt, 1, X_ref, U_ref, NULL);
 }
 
 /* lmpc_solve_batch_warm with its own plan arguments: linearised along (X_ref, U_ref), started from (X_plan, U_plan) */
@@ -1664,7 +1697,22 @@ int lmpc_oracle_solve_range_warm_plan(const lmpc_config* cfg, const lmpc_vehicle
                                       int32_t* status, int32_t* iters, double* kkt) {
   if (!X_plan || !U_plan) return LMPC_ERR_ARGUMENT;
   return solve_range_impl(cfg, veh, batch, b0, b1, x_ic, u_ic, X_ref, U_ref, T_ref, bound_left, bound_right, curvatures, vel_ref, ss_x, ss_j,
-                          X_optm, U_optm, dU_optm, lambda_out, status, iters, kkt, 1, X_plan, U_plan);
+                          X_optm, U_optm, dU_optm, lambda_out, status, iters, kkt, 1, X_plan, U_plan, NULL);
+}
+
+/* lmpc_solve_batch_warm_ss: the learning problem's warm start -- the plan AND the simplex weights of its terminal point,
+ * lam_plan [S][B] (the reference's convex_combi_optm_ref, racing_mpc.cpp:281), aligned with THIS call's safe-set points */
+int lmpc_oracle_solve_range_warm_lam(const lmpc_config* cfg, const lmpc_vehicle* veh, int32_t batch, int32_t b0,
+                                     int32_t b1, const double* x_ic, const double* u_ic, const double* X_ref,
+                                     const double* U_ref, const double* T_ref, const double* bound_left,
+                                     const double* bound_right, const double* curvatures,
+                                     const double* vel_ref, const double* ss_x, const double* ss_j,
+                                     const double* X_plan, const double* U_plan, const double* lam_plan,
+                                     double* X_optm, double* U_optm, double* dU_optm, double* lambda_out,
+                                     int32_t* status, int32_t* iters, double* kkt) {
+  if (!X_plan || !U_plan) return LMPC_ERR_ARGUMENT;
+  return solve_range_impl(cfg, veh, batch, b0, b1, x_ic, u_ic, X_ref, U_ref, T_ref, bound_left, bound_right, curvatures, vel_ref, ss_x, ss_j,
+                          X_optm, U_optm, dU_optm, lambda_out, status, iters, kkt, 1, X_plan, U_plan, lam_plan);
 }
 
 static int solve_range_impl(const lmpc_config* cfg, const lmpc_vehicle* veh, int32_t batch, int32_t b0,
@@ -1673,7 +1721,8 @@ static int solve_range_impl(const lmpc_config* cfg, const lmpc_vehicle* veh, int
                             const double* bound_right, const double* curvatures,
                             const double* vel_ref, const double* ss_x, const double* ss_j,
                             double* X_optm, double* U_optm, double* dU_optm, double* lambda_out,
-                            int32_t* status, int32_t* iters, double* kkt, int warm, const double* X_plan, const double* U_plan) {
+                            int32_t* status, int32_t* iters, double* kkt, int warm, const double* X_plan, const double* U_plan,
+                            const double* lam_plan) {
   const int N = cfg->N, B = batch;
   if (N < 3 || N > NMAX) return LMPC_ERR_ARGUMENT;
   if (cfg->learning && (cfg->num_ss_pts < 1 || cfg->num_ss_pts > SMAX)) return LMPC_ERR_ARGUMENT;
@@ -1691,6 +1740,10 @@ static int solve_range_impl(const lmpc_config* cfg, const lmpc_vehicle* veh, int
                   curvatures, vel_ref, ss_x, ss_j);
     p->warm = warm;
     if (warm) set_plan(p, B, b, X_plan, U_plan);
+    if (warm && lam_plan && p->S) {
+      p->has_lamw = 1;
+      for (int j = 0; j < p->S; ++j) p->lamw[j] = lam_plan[(size_t)p->ss_map[j] * B + b];
+    }
     int it = 0, st;
     double kk[4] = {0, 0, 0, 0};
     if (!knot0_feasible(p, cfg)) {

@@ -84,7 +84,8 @@ def _c(a):
 def solve_batch(cfg: MPCConfig, veh: Vehicle, inp: dict, ss_x=None, ss_j=None, b0=0, b1=None,
                 max_iter: int = 0, tol: float = 0.0, polish: int = 0, warm: bool = False, warm_plan: dict | None = None, warm_rounds: int = 0) -> dict:
     """inp as produced by oracle.scenario.cold_start_inputs (batch axis last).  warm: the active-set warm start of
-    lmpc_solve_batch_warm; the plan is warm_plan's (X_ref, U_ref) when given, else the linearisation trajectory itself."""
+    lmpc_solve_batch_warm; the plan is warm_plan's (X_ref, U_ref) when given, else the linearisation trajectory itself.  The
+    learning problem's warm start (lmpc_solve_batch_warm_ss) also takes warm_plan["lam"] [S][B], the plan's simplex weights."""
     N = cfg.N
     B = inp["x_ic"].shape[-1]
     b1 = B if b1 is None else b1
@@ -106,6 +107,10 @@ def solve_batch(cfg: MPCConfig, veh: Vehicle, inp: dict, ss_x=None, ss_j=None, b
         fn = lib().lmpc_oracle_solve_range_warm_plan
         plan = [_c(warm_plan["X_ref"]), _c(warm_plan["U_ref"])]
         assert plan[0].shape == (6, N, B) and plan[1].shape == (2, N - 1, B)
+        if warm_plan.get("lam") is not None:
+            fn = lib().lmpc_oracle_solve_range_warm_lam
+            plan.append(_c(warm_plan["lam"]))
+            assert plan[2].shape == (cfg.num_ss_pts, B)
     rc = fn(C.byref(cc), C.byref(cv), C.c_int32(B), C.c_int32(b0), C.c_int32(b1),
             *[_p(a) for a in arrs], _p(ss_x), _p(ss_j), *[_p(a) for a in plan], _p(X), _p(U), _p(dU),
             _p(lam), _p(status), _p(iters), _p(kkt))

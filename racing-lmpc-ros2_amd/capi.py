@@ -22,7 +22,8 @@ _ABI_SYMBOLS = ("lmpc_create", "lmpc_destroy", "lmpc_last_error", "lmpc_set_stre
                 "lmpc_plant_step_batch", "lmpc_solve_full_dynamics_batch", "lmpc_solve_full_dynamics_host", "lmpc_set_regression_laps", "lmpc_regress_batch", "lmpc_ss_query_host", "lmpc_solve_batch_f32",
                 "lmpc_solve_batch_mixed", "lmpc_prepare_failed_batch", "lmpc_set_launch_order", "lmpc_set_warm_rounds", "lmpc_loop_advance_batch", "lmpc_launch_order_from_iters", "lmpc_set_output_layout",
                 "lmpc_ss_query_idx_batch", "lmpc_solve_batch_ss_idx", "lmpc_solve_batch_warm", "lmpc_solve_host_warm",
-                "lmpc_last_solve_precision")
+                "lmpc_last_solve_precision", "lmpc_solve_batch_warm_ss", "lmpc_solve_host_warm_ss", "lmpc_shift_lambda_batch",
+                "lmpc_get_warm_accepted")
 
 
 class LmpcError(RuntimeError):
@@ -363,6 +364,22 @@ class Solver:
         if warm is not None and mixed:
             # (this combination used to run the fp64 warm solve and say nothing)
             raise ValueError("Solver.solve: warm start and mixed precision do not combine (lmpc_solve_batch_warm is the fp64 entry)")
+        if warm is not None and bool(self.config["learning"]):
+            # lmpc_solve_batch_warm_ss: the plan AND its simplex weights (convex_combi_optm_ref, aligned with this call's points)
+            wx = a[2] if warm is True else self._t(warm["X_optm_ref"])
+            wu = a[3] if warm is True else self._t(warm["U_optm_ref"])
+            wl = None if warm is True or warm.get("convex_combi_optm_ref") is None else self._t(warm["convex_combi_optm_ref"])
+            sx = None if (ss_x is None or ss_idx is not None) else self._t(ss_x)
+            sj = None if (ss_j is None or ss_idx is not None) else self._t(ss_j)
+            rc = self.lib.lmpc_solve_batch_warm_ss(self._h, C.c_int32(B), *[_ptr(t) for t in a], C.c_double(float(inp["L"])), _ptr(sx), _ptr(sj),
+                                                   _ptr(ss_idx), _ptr(wx), _ptr(wu), _ptr(wl), _ptr(out["X_optm"]), _ptr(out["U_optm"]),
+                                                   _ptr(out["dU_optm"]), _ptr(out.get("convex_combi_optm")), _ptr(out["status"]), _ptr(out["iters"]),
+                                                   _ptr(out.get("kkt")))
+            self._check(rc, "lmpc_solve_batch_warm_ss")
+            out["_inputs_keepalive"] = a + [wx, wu, wl, sx, sj, ss_idx]
+            return out
+        if warm is not None and ss_idx is not None:
+            raise ValueError("Solver.solve: ss_idx goes with a learning handle")
         if warm is not None:
             # lmpc_solve_batch_warm: warm = True takes (X_ref, U_ref) as the plan (what the node does), or a dict with X_optm_ref / U_optm_ref
             wx = a[2] if warm is True else self._t(warm["X_optm_ref"])
@@ -392,11 +409,32 @@ class Solver:
         out["_inputs_keepalive"] = a
         return out
 
+    def shift_lambda(self, idx_prev, lam_prev, idx, advance: int = 1, out=None):
+        """lmpc_shift_lambda_batch: the previous solution's simplex weights carried onto this period's safe-set codes."""
+        torch = self._torch
+        self.use_current_stream()
+        S, B = idx.shape
+        if out is None:
+            out = torch.empty((S, B), dtype=torch.float64, device=self.device)
+        self._check(self.lib.lmpc_shift_lambda_batch(self._h, C.c_int32(B), _ptr(idx_prev), _ptr(lam_prev), _ptr(idx), C.c_int32(int(advance)), _ptr(out)),
+                    "lmpc_shift_lambda_batch")
+        return out
+
+    def warm_accepted(self, B: int, out=None):
+        """lmpc_get_warm_accepted: int32 [B], 1 where the last warm solve's active-set attempt was accepted."""
+        torch = self._torch
+        self.use_current_stream()
+        if out is None:
+            out = torch.empty((B,), dtype=torch.int32, device=self.device)
+        self._check(self.lib.lmpc_get_warm_accepted(self._h, C.c_int32(B), _ptr(out)), "lmpc_get_warm_accepted")
+        return out
+
     def last_solve_precision(self) -> str:
         """lmpc_last_solve_precision: "f64", "f32" or "mixed" -- what the most recent batched solve ran in (solve(mixed=True) falls
         back to fp64 where no reduced-precision kernel exists for this (N, num_ss_pts): include/lmpc_hip.h)."""
         p = C.c_int32(-1)
-        self._check(self.lib.lmpc_last_solve_precision(self._h, C.byref(p)), "lmpc_last_solve_precision")
+        self._check(self.lib.lmpc_last_solve_precision(self._h, C.byref(p)), "lmpc_last_solve_precision", "lmpc_solve_batch_warm_ss", "lmpc_solve_host_warm_ss", "lmpc_shift_lambda_batch",
+                "lmpc_get_warm_accepted")
         return {0: "f64", 1: "f32", 2: "mixed"}[p.value]
 
     # ---- single precision (BASELINE configs[3]) ----

@@ -148,11 +148,17 @@ def record_laps(solver, track: dict, speed_scales=(0.80, 0.85, 0.90, 0.95, 1.0),
 
 
 def run_lmpc(tracker, learner, track: dict, x0, u0, warm_laps: int = 2, learn_laps: int = 4, dt: float = 0.025,
-             n_sub: int = 2, warm_speed_scale: float = 0.7, max_steps: int = 20000, debug: bool = False):
+             n_sub: int = 2, warm_speed_scale: float = 0.7, max_steps: int = 20000, debug: bool = False, warm: bool = False,
+             advance: int = 1):
     """The LMPC experiment of the reference (sim_barc_lmpc): `warm_laps` laps under the tracking MPC fill the safe
     set, then the learning MPC drives and every completed lap of car 0 is added to the set (SafeSetRecorder ->
     SafeSetManager -> device store).  All B cars share car 0's safe set.  Returns car 0's lap times (tracking laps
-    first) and per-car statistics.  x0 [6][B], u0 [2][B] on the device."""
+    first) and per-car statistics.  x0 [6][B], u0 [2][B] on the device.
+
+    warm=True (round 6): the learning solves go through lmpc_solve_batch_warm_ss -- the shifted previous plan and the previous
+    solution's simplex weights (racing_mpc.cpp:281, 293-305), the safe set by reference, the weights carried onto the new period's
+    points by lmpc_shift_lambda_batch (`advance` samples along the lap); the tracking laps through lmpc_solve_batch_warm.  Returns
+    the share of the learning solves whose active-set attempt was accepted as "warm_hit_rate"."""
     import numpy as np
     import torch
 
@@ -180,6 +186,8 @@ def run_lmpc(tracker, learner, track: dict, x0, u0, warm_laps: int = 2, learn_la
     # following problem infeasible.  The harness hands the controller the measured state projected onto the box.
     x_lo = torch.as_tensor(learner.config["x_min"], dtype=torch.float64, device=x.device)[:, None]
     x_hi = torch.as_tensor(learner.config["x_max"], dtype=torch.float64, device=x.device)[:, None]
+    idx_prev, have_prev, n_warm, n_hit = None, False, 0, 0
+    acc = torch.zeros(B, dtype=torch.int32, device=x.device)
     for k in range(max_steps):
         inp["x_ic"], inp["u_ic"] = (torch.minimum(torch.maximum(x, x_lo), x_hi) if learning else x), u_prev
         # car 0 feeds the recorder (RacingMPC::solve, racing_mpc.cpp:246): state, applied input, curvature, time
@@ -189,6 +197,7 @@ def run_lmpc(tracker, learner, track: dict, x0, u0, warm_laps: int = 2, learn_la
             lap_times.append(t - t_lap_start)
             lap_kind.append("lmpc" if learning else "tracking")
             man.sync(learner)
+            have_prev = False   # (the store was replaced: the previous period's codes no longer name its rows)
             if not learning and len(man.laps) >= warm_laps:
                 solver, learning = learner, True
                 out = solver.alloc_outputs(B)
@@ -202,12 +211,27 @@ def run_lmpc(tracker, learner, track: dict, x0, u0, warm_laps: int = 2, learn_la
             s_last, s0 = inp["X_ref"][0, -1], x[0]
             kk = (s0 - s_last).abs() + L / 2
             q = torch.stack([s_last + (kk - torch.fmod(kk, L)) * torch.sign(s0 - s_last), inp["X_ref"][1, -1]]).contiguous()
-            ss_x, ss_j, _ = solver.ss_query(q)
-            solver.solve(inp, out, ss_x=ss_x, ss_j=ss_j)
+            if warm:
+                idx, _ = solver.ss_query_idx(q)
+                idx = idx.clone()  # (kept for the next period's weight transfer)
+                if have_prev:
+                    lam_ref = solver.shift_lambda(idx_prev, lam, idx, advance)
+                    solver.solve(inp, out, ss_idx=idx, warm={"X_optm_ref": inp["X_ref"], "U_optm_ref": inp["U_ref"], "convex_combi_optm_ref": lam_ref})
+                    solver.warm_accepted(B, acc)
+                    n_warm += B
+                    n_hit += int(acc.sum())
+                else:
+                    solver.solve(inp, out, ss_idx=idx)
+                idx_prev = idx
+            else:
+                ss_x, ss_j, _ = solver.ss_query(q)
+                solver.solve(inp, out, ss_x=ss_x, ss_j=ss_j)
         else:
-            solver.solve(inp, out)
+            solver.solve(inp, out, warm=True if (warm and k > 0) else None)
         ok = out["status"] == 0
         n_fail += (~ok).to(torch.int64)
+        if learning and warm:
+            have_prev = bool(ok.all()) or True   # (a failed car's weights are stale; its attempt is refused by the KKT test, nothing else)
         if debug and learning and not bool(ok[0]) and debug_left[0] > 0:
             debug_left[0] -= 1
             print("step", k, "t %.3f" % t, "car0 status", int(out["status"][0]), "iters", int(out["iters"][0]), "x", x[:, 0].cpu().numpy().round(3),
@@ -220,4 +244,4 @@ def run_lmpc(tracker, learner, track: dict, x0, u0, warm_laps: int = 2, learn_la
         inp = solver.shift(trk, inp, out, dt, speed_scale=warm_speed_scale if not learning else 1.0)
         t += dt
     return {"lap_times": lap_times, "lap_kind": lap_kind, "worst_excess": worst_excess, "n_fail": n_fail, "steps": k + 1,
-            "laps_in_set": len(man.laps)}
+            "laps_in_set": len(man.laps), "x": x, "warm_hit_rate": (n_hit / n_warm) if n_warm else None}

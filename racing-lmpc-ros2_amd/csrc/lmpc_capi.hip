@@ -59,6 +59,8 @@ struct lmpc_handle {
   int warm_resident = 0;  // problems the device holds at once in the warm kernel (CUs x workgroups per CU); 0: no warm kernel for this handle
   double* ws = nullptr;  // [cap][N-1][LMPC_LIN_RECORD]
   int* unverified = nullptr;  // [cap + 1]: the problems a mixed first pass could not verify, and their number
+  int* warm_flag = nullptr;   // [cap]: 1 where the last warm solve's attempt was accepted (written by the warm kernels)
+  int warm_flag_n = 0;        // the batch of the solve that wrote it (0: no warm solve since)
   void* save = nullptr;       // [save_cap][10 N - 4] elements of save_elem bytes: the polish's save area (grown by reserve_save)
   size_t save_cap = 0, save_elem = 0;
   size_t ws_cap = 0;
@@ -142,6 +144,7 @@ struct solve_args {
   bool aos;  // results [batch][knot][component]
   const int* ss_idx;  // learning: the safe set by reference (lmpc_solve_batch_ss_idx) instead of ss_x / ss_j
   const double *warm_X, *warm_U;  // lmpc_solve_batch_warm: the plan of the active-set attempt (null: cold)
+  const double* warm_lam;         // ... and, learning, the plan's simplex weights [S][B]
 };
 
 template <int KQ, int KS, typename real = double>
@@ -229,6 +232,8 @@ void set_ss_reference(const lmpc_handle* h, lmpc_params& P, const solve_args& a)
   P.ss_L = h->ss_L;
   P.warm_X = a.warm_X;
   P.warm_U = a.warm_U;
+  P.warm_lam = a.warm_lam;
+  P.warm_flag = nullptr;
 }
 
 int launch_cleanup(lmpc_handle* h, const void* fn, const solve_args& a) {
@@ -257,21 +262,39 @@ int launch_cleanup(lmpc_handle* h, const void* fn, const solve_args& a) {
   return LMPC_OK;
 }
 
-// the warm-start kernels (fp64 tracking): one per KQ
-const void* pick_warm_fn(int kq) {
+// the warm-start kernels (fp64): one per KQ for the tracking problem; the learning problem up to N = 60 (KQ = 11)
+const void* pick_warm_fn(int kq, int ks = 0) {
+  if (ks == 2) {
+    switch (kq) {
+      case 2:
+      case 4: return reinterpret_cast<const void*>(&lmpc_solve_warm_kernel<4, 2>);
+      case 7: return reinterpret_cast<const void*>(&lmpc_solve_warm_kernel<7, 2>);
+      case 11: return reinterpret_cast<const void*>(&lmpc_solve_warm_kernel<11, 2>);
+    }
+    return nullptr;
+  }
+  if (ks == 3) {
+    switch (kq) {
+      case 2:
+      case 4: return reinterpret_cast<const void*>(&lmpc_solve_warm_kernel<4, 3>);
+      case 7: return reinterpret_cast<const void*>(&lmpc_solve_warm_kernel<7, 3>);
+      case 11: return reinterpret_cast<const void*>(&lmpc_solve_warm_kernel<11, 3>);
+    }
+    return nullptr;
+  }
   switch (kq) {
-    case 2: return reinterpret_cast<const void*>(&lmpc_solve_warm_kernel<2>);
-    case 4: return reinterpret_cast<const void*>(&lmpc_solve_warm_kernel<4>);
-    case 7: return reinterpret_cast<const void*>(&lmpc_solve_warm_kernel<7>);
-    case 11: return reinterpret_cast<const void*>(&lmpc_solve_warm_kernel<11>);
-    case 14: return reinterpret_cast<const void*>(&lmpc_solve_warm_kernel<14>);
+    case 2: return reinterpret_cast<const void*>(&lmpc_solve_warm_kernel<2, 0>);
+    case 4: return reinterpret_cast<const void*>(&lmpc_solve_warm_kernel<4, 0>);
+    case 7: return reinterpret_cast<const void*>(&lmpc_solve_warm_kernel<7, 0>);
+    case 11: return reinterpret_cast<const void*>(&lmpc_solve_warm_kernel<11, 0>);
+    case 14: return reinterpret_cast<const void*>(&lmpc_solve_warm_kernel<14, 0>);
   }
   return nullptr;
 }
 
 int launch_solve_warm(lmpc_handle* h, const solve_args& a) {
-  const void* fn = pick_warm_fn(kq_for(h->P.N));
-  if (!fn) return fail(h, LMPC_ERR_UNSUPPORTED, "no warm-start kernel for this N");
+  const void* fn = pick_warm_fn(kq_for(h->P.N), ks_for(h->P.S));
+  if (!fn) return fail(h, LMPC_ERR_UNSUPPORTED, "no warm-start kernel for this (N, num_ss_pts)");
   HIP_TRY(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)a.lds_bytes));
   lmpc_params P = h->P;
   P.out_aos = a.aos ? 1 : 0;
@@ -286,8 +309,11 @@ int launch_solve_warm(lmpc_handle* h, const solve_args& a) {
   P.launch_order = (h->order && a.B == h->order_n) ? h->order : nullptr;
   int B = a.B;
   const double* ws = h->ws;
+  P.warm_flag = h->warm_flag;  // (reserved with the workspace: at least a.B entries)
+  h->warm_flag_n = a.B;
   void* args[] = {(void*)&P, (void*)&B, (void*)&ws, (void*)&a.x_ic, (void*)&a.u_ic, (void*)&a.T_ref, (void*)&a.bl, (void*)&a.br,
-                  (void*)&a.vref, (void*)&a.X, (void*)&a.U, (void*)&a.dU, (void*)&a.status, (void*)&a.iters, (void*)&a.kkt};
+                  (void*)&a.vref, (void*)&a.ss_x, (void*)&a.ss_j, (void*)&a.lam, (void*)&a.X, (void*)&a.U, (void*)&a.dU, (void*)&a.status,
+                  (void*)&a.iters, (void*)&a.kkt};
   HIP_TRY(h, hipLaunchKernel(fn, dim3(8 * ((a.B + 7) / 8)), dim3(64), args, a.lds_bytes, h->stream));
   return LMPC_OK;
 }
@@ -430,7 +456,7 @@ int lmpc_create(const lmpc_config* cfg, const lmpc_vehicle* veh, int device, lmp
   for (auto& e : h->ev) HIP_TRY(h, hipEventCreate(&e));
   {  // staging of the single-problem host path, once
     const size_t N = (size_t)P.N, S = (size_t)P.S;
-    h->stage_doubles = 8 + 6 * N + 2 * (N - 1) + (N - 1) + 4 * N + 7 * S + 6 * N + 4 * (N - 1) + S + 2 + 6 * N + 2 * (N - 1);  // (+ a warm plan)
+    h->stage_doubles = 8 + 6 * N + 2 * (N - 1) + (N - 1) + 4 * N + 7 * S + 6 * N + 4 * (N - 1) + S + 2 + 6 * N + 2 * (N - 1) + S;  // (+ a warm plan and its simplex weights)
     HIP_TRY(h, hipMalloc(&h->stage_dev, h->stage_doubles * sizeof(double)));
     HIP_TRY(h, hipHostMalloc(&h->stage_host, h->stage_doubles * sizeof(double)));
     HIP_TRY(h, hipMalloc(&h->stage_int, 3 * sizeof(int)));
@@ -446,9 +472,9 @@ int lmpc_create(const lmpc_config* cfg, const lmpc_vehicle* veh, int device, lmp
     if (rc == LMPC_OK) rc = reserve_sqp(h, 1);
     if (rc != LMPC_OK) return rc;
   }
-  if (!P.learning) {  // what the device holds of the warm kernel at once (the default of lmpc_set_warm_rounds goes by it)
-    if (const void* fn = pick_warm_fn(kq_for(P.N))) {
-      const size_t lds = lmpc_lds_bytes(P.N, 0, 0, 8);
+  {  // what the device holds of the warm kernel at once (the default of lmpc_set_warm_rounds goes by it)
+    if (const void* fn = pick_warm_fn(kq_for(P.N), ks_for(P.S))) {
+      const size_t lds = lmpc_lds_bytes(P.N, P.learning, P.S, 8);
       int per_cu = 0, cus = 0;
       HIP_TRY(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64, lds));
@@ -465,6 +491,7 @@ void lmpc_destroy(lmpc_handle* h) {
   (void)hipStreamSynchronize(h->stream);
   if (h->ws) (void)hipFree(h->ws);
   if (h->unverified) (void)hipFree(h->unverified);
+  if (h->warm_flag) (void)hipFree(h->warm_flag);
   if (h->save) (void)hipFree(h->save);
   if (h->ws_f32) (void)hipFree(h->ws_f32);
   if (h->ss_npts) (void)hipFree(h->ss_npts);
@@ -516,6 +543,10 @@ int lmpc_reserve(lmpc_handle* h, int32_t max_batch) {
   if (h->unverified) HIP_TRY(h, hipFree(h->unverified));
   h->unverified = nullptr;
   HIP_TRY(h, hipMalloc(&h->unverified, ((size_t)max_batch + 1) * sizeof(int)));
+  if (h->warm_flag) HIP_TRY(h, hipFree(h->warm_flag));
+  h->warm_flag = nullptr;
+  h->warm_flag_n = 0;
+  HIP_TRY(h, hipMalloc(&h->warm_flag, (size_t)max_batch * sizeof(int)));
   // the polish's save area first: a batch counts as reserved only when everything a solve of that size touches exists
   // (with ws_cap set before a failed reserve_save a later solve skipped the reservation and wrote through a null save)
   const int rc = reserve_save(h, (size_t)max_batch, sizeof(double));
@@ -610,7 +641,8 @@ int solve_batch_fp64_arrays(lmpc_handle* h, bool mixed, bool aos, int32_t batch,
                             const double* bound_right, const double* curvatures, const double* vel_ref,
                             double total_length, const double* ss_x, const double* ss_j, double* X_optm, double* U_optm,
                             double* dU_optm, double* convex_combi_optm, int32_t* status, int32_t* iters, double* kkt,
-                            const int32_t* ss_idx = nullptr, const double* warm_X = nullptr, const double* warm_U = nullptr) {
+                            const int32_t* ss_idx = nullptr, const double* warm_X = nullptr, const double* warm_U = nullptr,
+                            const double* warm_lam = nullptr) {
   if (!h) return LMPC_ERR_ARGUMENT;
   (void)total_length;  // abscissa alignment (racing_mpc.cpp:219-223) shifts s only; the QP is invariant to it
   if (batch < 0 || !x_ic || !u_ic || !X_ref || !U_ref || !T_ref || !bound_left || !bound_right || !curvatures ||
@@ -655,9 +687,13 @@ int solve_batch_fp64_arrays(lmpc_handle* h, bool mixed, bool aos, int32_t batch,
   a.x_ic = x_ic; a.u_ic = u_ic; a.T_ref = T_ref; a.bl = bound_left; a.br = bound_right; a.vref = vel_ref;
   a.ss_x = (h->P.learning && !ss_idx) ? ss_x : nullptr; a.ss_j = (h->P.learning && !ss_idx) ? ss_j : nullptr;
   a.ss_idx = h->P.learning ? ss_idx : nullptr;
-  // the warm start is built into the fp64 tracking kernels; everywhere else the call is the cold solve it would fall back to
-  a.warm_X = (!mixed && !h->P.learning) ? warm_X : nullptr;
-  a.warm_U = (!mixed && !h->P.learning) ? warm_U : nullptr;
+  // the warm start is built into fp64 kernels of its own -- the tracking problem at every horizon, the learning problem (with the
+  // plan's simplex weights) up to N = 60; everywhere else the call is the cold solve it would fall back to
+  const bool warm_built = !mixed && (!h->P.learning || warm_lam) && pick_warm_fn(kq_for(N), ks_for(h->P.S)) != nullptr;
+  a.warm_X = warm_built ? warm_X : nullptr;
+  a.warm_U = warm_built ? warm_U : nullptr;
+  a.warm_lam = (warm_built && h->P.learning) ? warm_lam : nullptr;
+  h->warm_flag_n = 0;  // (a cold solve: nothing was attempted)
   a.lam = h->P.learning ? convex_combi_optm : nullptr;
   a.X = X_optm; a.U = U_optm; a.dU = dU_optm; a.status = status; a.iters = iters; a.kkt = kkt;
   a.aos = aos;
@@ -717,10 +753,52 @@ int lmpc_solve_batch_warm(lmpc_handle* h, int32_t batch, const double* x_ic, con
                           double* U_optm, double* dU_optm, int32_t* status, int32_t* iters, double* kkt) {
   if (!h) return LMPC_ERR_ARGUMENT;
   if (!X_optm_ref || !U_optm_ref) return fail(h, LMPC_ERR_ARGUMENT, "lmpc_solve_batch_warm: X_optm_ref / U_optm_ref is null");
-  if (h->P.learning) return fail(h, LMPC_ERR_UNSUPPORTED, "lmpc_solve_batch_warm: the tracking problem only (learning handles: lmpc_solve_batch)");
+  if (h->P.learning) return fail(h, LMPC_ERR_UNSUPPORTED, "lmpc_solve_batch_warm: the tracking problem only (learning handles: lmpc_solve_batch_warm_ss)");
   return solve_batch_fp64_arrays(h, false, h->out_aos, batch, x_ic, u_ic, X_ref, U_ref, T_ref, bound_left, bound_right, curvatures, vel_ref,
                                  total_length, nullptr, nullptr, X_optm, U_optm, dU_optm, nullptr, status, iters, kkt, nullptr, X_optm_ref,
                                  U_optm_ref);
+}
+
+int lmpc_solve_batch_warm_ss(lmpc_handle* h, int32_t batch, const double* x_ic, const double* u_ic, const double* X_ref, const double* U_ref,
+                             const double* T_ref, const double* bound_left, const double* bound_right, const double* curvatures,
+                             const double* vel_ref, double total_length, const double* ss_x, const double* ss_j, const int32_t* ss_idx,
+                             const double* X_optm_ref, const double* U_optm_ref, const double* convex_combi_optm_ref, double* X_optm,
+                             double* U_optm, double* dU_optm, double* convex_combi_optm, int32_t* status, int32_t* iters, double* kkt) {
+  if (!h) return LMPC_ERR_ARGUMENT;
+  if (!X_optm_ref || !U_optm_ref) return fail(h, LMPC_ERR_ARGUMENT, "lmpc_solve_batch_warm_ss: X_optm_ref / U_optm_ref is null");
+  if (!h->P.learning) return fail(h, LMPC_ERR_ARGUMENT, "lmpc_solve_batch_warm_ss: a learning handle (the tracking problem: lmpc_solve_batch_warm)");
+  if (ss_idx && h->ss_idx_gen != h->ss_gen)
+    return fail(h, LMPC_ERR_ARGUMENT, "lmpc_solve_batch_warm_ss: the safe set was replaced (lmpc_set_safe_set) after the lmpc_ss_query_idx_batch these "
+                                      "codes come from, or no such query ran on this handle");
+  return solve_batch_fp64_arrays(h, false, h->out_aos, batch, x_ic, u_ic, X_ref, U_ref, T_ref, bound_left, bound_right, curvatures, vel_ref,
+                                 total_length, ss_x, ss_j, X_optm, U_optm, dU_optm, convex_combi_optm, status, iters, kkt, ss_idx, X_optm_ref,
+                                 U_optm_ref, convex_combi_optm_ref);
+}
+
+int lmpc_get_warm_accepted(lmpc_handle* h, int32_t batch, int32_t* accepted) {
+  if (!h || !accepted || batch < 0) return h ? fail(h, LMPC_ERR_ARGUMENT, "lmpc_get_warm_accepted: null pointer or negative batch") : LMPC_ERR_ARGUMENT;
+  if (batch == 0) return LMPC_OK;
+  HIP_TRY(h, hipSetDevice(h->device));
+  if (h->warm_flag_n != batch) {  // the last solve of this size was not a warm one (or the kernel for it is not built): nothing was attempted
+    HIP_TRY(h, hipMemsetAsync(accepted, 0, (size_t)batch * sizeof(int32_t), h->stream));
+    return LMPC_OK;
+  }
+  HIP_TRY(h, hipMemcpyAsync(accepted, h->warm_flag, (size_t)batch * sizeof(int32_t), hipMemcpyDeviceToDevice, h->stream));
+  return LMPC_OK;
+}
+
+int lmpc_shift_lambda_batch(lmpc_handle* h, int32_t batch, const int32_t* ss_idx_prev, const double* lambda_prev, const int32_t* ss_idx,
+                            int32_t advance, double* lambda_ref) {
+  if (!h) return LMPC_ERR_ARGUMENT;
+  if (batch < 0 || !ss_idx_prev || !lambda_prev || !ss_idx || !lambda_ref || advance < 0)
+    return fail(h, LMPC_ERR_ARGUMENT, "lmpc_shift_lambda_batch: null pointer, negative batch or negative advance");
+  if (!h->P.learning || h->ss_laps < 1) return fail(h, LMPC_ERR_ARGUMENT, "lmpc_shift_lambda_batch: a learning handle with a safe set stored");
+  if (batch == 0) return LMPC_OK;
+  HIP_TRY(h, hipSetDevice(h->device));
+  hipLaunchKernelGGL(lmpc_shift_lambda_kernel, dim3((batch + 63) / 64), dim3(64), 0, h->stream, batch, h->P.S, h->ss_laps, h->ss_npts, h->ss_off,
+                     ss_idx_prev, lambda_prev, ss_idx, advance, lambda_ref);
+  HIP_TRY(h, hipGetLastError());
+  return LMPC_OK;
 }
 
 int lmpc_solve_batch_ss_idx(lmpc_handle* h, int32_t batch, int32_t precision, const double* x_ic, const double* u_ic, const double* X_ref,
@@ -898,7 +976,7 @@ int solve_host_impl(lmpc_handle* h, const double* x_ic, const double* u_ic, cons
                     const double* vel_ref, double total_length, const double* ss_x, const double* ss_j, double* X_optm,
                     double* U_optm, double* dU_optm, double* convex_combi_optm, int32_t* status, int32_t* iters,
                     int max_sqp, double step_tol, int32_t* sqp_iters, double* sqp_move, double* defect,
-                    const double* X_warm = nullptr, const double* U_warm = nullptr) {
+                    const double* X_warm = nullptr, const double* U_warm = nullptr, const double* lam_warm = nullptr) {
   if (!h) return LMPC_ERR_ARGUMENT;
   if (!x_ic || !u_ic || !X_ref || !U_ref || !T_ref || !bound_left || !bound_right || !curvatures || !vel_ref ||
       !X_optm || !U_optm || !dU_optm || !status || !iters)
@@ -908,7 +986,7 @@ int solve_host_impl(lmpc_handle* h, const double* x_ic, const double* u_ic, cons
   const size_t o_x = 0, o_u = 6, o_X = 8, o_U = o_X + 6 * N, o_T = o_U + 2 * NS, o_bl = o_T + NS, o_br = o_bl + N,
                o_k = o_br + N, o_v = o_k + N, o_sx = o_v + N, o_sj = o_sx + 6 * (size_t)S, o_Xo = o_sj + S,
                o_Uo = o_Xo + 6 * N, o_dUo = o_Uo + 2 * NS, o_lam = o_dUo + 2 * NS, o_mv = o_lam + S, o_wX = o_mv + 2, o_wU = o_wX + 6 * N,
-               total = o_wU + 2 * NS;
+               o_wL = o_wU + 2 * NS, total = o_wL + S;
   HIP_TRY(h, hipSetDevice(h->device));
   if (total != h->stage_doubles || !h->stage_dev || !h->stage_host) return fail(h, LMPC_ERR_RUNTIME, "lmpc_solve_host: staging not allocated");
   double* const host = h->stage_host;  // pinned: the two copies below are asynchronous DMA transfers
@@ -934,12 +1012,14 @@ int solve_host_impl(lmpc_handle* h, const double* x_ic, const double* u_ic, cons
     }
   double* d = h->stage_dev;
   HIP_TRY(h, hipMemcpyAsync(d, host, o_Xo * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  const bool warm = X_warm && U_warm && max_sqp <= 0 && !h->P.learning;
-  if (warm) {  // the plan, column-major -> [6][N] / [2][N-1]
+  const bool warm = X_warm && U_warm && max_sqp <= 0 && (!h->P.learning || lam_warm);
+  if (warm) {  // the plan, column-major -> [6][N] / [2][N-1] (and, learning, its simplex weights)
     for (int i = 0; i < N; ++i)
       for (int k = 0; k < 6; ++k) host[o_wX + (size_t)k * N + i] = X_warm[(size_t)i * 6 + k];
     for (int i = 0; i < NS; ++i)
       for (int k = 0; k < 2; ++k) host[o_wU + (size_t)k * NS + i] = U_warm[(size_t)i * 2 + k];
+    if (S && lam_warm)
+      for (int j = 0; j < S; ++j) host[o_wL + j] = lam_warm[j];
     HIP_TRY(h, hipMemcpyAsync(d + o_wX, host + o_wX, (total - o_wX) * sizeof(double), hipMemcpyHostToDevice, h->stream));
   }
   const int rc = max_sqp > 0
@@ -950,7 +1030,7 @@ int solve_host_impl(lmpc_handle* h, const double* x_ic, const double* u_ic, cons
       : solve_batch_fp64_arrays(h, false, false, 1, d + o_x, d + o_u, d + o_X, d + o_U, d + o_T, d + o_bl, d + o_br, d + o_k, d + o_v,
                                 total_length, S ? d + o_sx : nullptr, S ? d + o_sj : nullptr, d + o_Xo, d + o_Uo,
                                 d + o_dUo, S ? d + o_lam : nullptr, h->stage_int, h->stage_int + 1, nullptr,  // (the staging buffer is unpacked as [6][N])
-                                nullptr, warm ? d + o_wX : nullptr, warm ? d + o_wU : nullptr);
+                                nullptr, warm ? d + o_wX : nullptr, warm ? d + o_wU : nullptr, (warm && S) ? d + o_wL : nullptr);
   if (rc != LMPC_OK) return rc;
   int* const si = h->stage_int_host;
   HIP_TRY(h, hipMemcpyAsync(host + o_Xo, d + o_Xo, (o_wX - o_Xo) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -987,9 +1067,22 @@ int lmpc_solve_host_warm(lmpc_handle* h, const double* x_ic, const double* u_ic,
                          const double* vel_ref, double total_length, const double* X_optm_ref, const double* U_optm_ref, double* X_optm,
                          double* U_optm, double* dU_optm, int32_t* status, int32_t* iters) {
   if (h && (!X_optm_ref || !U_optm_ref)) return fail(h, LMPC_ERR_ARGUMENT, "lmpc_solve_host_warm: X_optm_ref / U_optm_ref is null");
-  if (h && h->P.learning) return fail(h, LMPC_ERR_UNSUPPORTED, "lmpc_solve_host_warm: the tracking problem only");
+  if (h && h->P.learning) return fail(h, LMPC_ERR_UNSUPPORTED, "lmpc_solve_host_warm: the tracking problem only (learning handles: lmpc_solve_host_warm_ss)");
   return solve_host_impl(h, x_ic, u_ic, X_ref, U_ref, T_ref, bound_left, bound_right, curvatures, vel_ref, total_length, nullptr, nullptr,
                          X_optm, U_optm, dU_optm, nullptr, status, iters, 0, 0.0, nullptr, nullptr, nullptr, X_optm_ref, U_optm_ref);
+}
+
+int lmpc_solve_host_warm_ss(lmpc_handle* h, const double* x_ic, const double* u_ic, const double* X_ref, const double* U_ref,
+                            const double* T_ref, const double* bound_left, const double* bound_right, const double* curvatures,
+                            const double* vel_ref, double total_length, const double* ss_x, const double* ss_j, const double* X_optm_ref,
+                            const double* U_optm_ref, const double* convex_combi_optm_ref, double* X_optm, double* U_optm, double* dU_optm,
+                            double* convex_combi_optm, int32_t* status, int32_t* iters) {
+  if (h && (!X_optm_ref || !U_optm_ref || !convex_combi_optm_ref))
+    return fail(h, LMPC_ERR_ARGUMENT, "lmpc_solve_host_warm_ss: X_optm_ref / U_optm_ref / convex_combi_optm_ref is null");
+  if (h && !h->P.learning) return fail(h, LMPC_ERR_ARGUMENT, "lmpc_solve_host_warm_ss: a learning handle (the tracking problem: lmpc_solve_host_warm)");
+  return solve_host_impl(h, x_ic, u_ic, X_ref, U_ref, T_ref, bound_left, bound_right, curvatures, vel_ref, total_length, ss_x, ss_j,
+                         X_optm, U_optm, dU_optm, convex_combi_optm, status, iters, 0, 0.0, nullptr, nullptr, nullptr, X_optm_ref, U_optm_ref,
+                         convex_combi_optm_ref);
 }
 
 int lmpc_solve_full_dynamics_host(lmpc_handle* h, const double* x_ic, const double* u_ic, const double* X_ref,
@@ -1089,7 +1182,9 @@ int lmpc_loop_advance_batch(lmpc_handle* h, int32_t batch, const lmpc_track* tra
   if (batch == 0) return LMPC_OK;
   HIP_TRY(h, hipSetDevice(h->device));
   static_assert(sizeof(long long) == sizeof(int64_t) && sizeof(unsigned long long) == sizeof(uint64_t), "counter types");
-  hipLaunchKernelGGL(lmpc_loop_advance_kernel, dim3((batch + 63) / 64), dim3(64 * LMPC_LOOP_WAVES), 0, h->stream, h->P, batch, *track, status, iters, X_optm,
+  lmpc_params PL = h->P;
+  PL.warm_flag = (h->warm_flag && h->warm_flag_n == batch) ? h->warm_flag : nullptr;  // the last solve of this batch was a warm one
+  hipLaunchKernelGGL(lmpc_loop_advance_kernel, dim3((batch + 63) / 64), dim3(64 * LMPC_LOOP_WAVES), 0, h->stream, PL, batch, *track, status, iters, X_optm,
                      U_optm, x, u_prev, dt, dt_sim, n_sub, speed_scale, speed_limit, restart_failed ? 1 : 0, X_ref, U_ref, T_ref, bound_left,
                      bound_right, curvatures, vel_ref, distance, worst_excess, reinterpret_cast<long long*>(n_fail),
                      reinterpret_cast<unsigned long long*>(n_accepted));

@@ -50,6 +50,8 @@ struct lmpc_params {
   // warm start (lmpc_solve_batch_warm): the plan the active-set attempt starts from, [6][N][B] and [2][N-1][B]; null: a cold solve
   const double* warm_X;
   const double* warm_U;
+  const double* warm_lam;  // learning: the plan's simplex weights [S][B] (convex_combi_optm_ref, racing_mpc.cpp:281), aligned with this call's points
+  int* warm_flag;          // device [B] or null: 1 where the warm attempt was accepted, 0 where the cold solve ran (written by the warm kernels)
   lmpc_vehicle veh;
 };
 

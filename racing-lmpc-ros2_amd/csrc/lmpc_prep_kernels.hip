@@ -61,7 +61,11 @@ __global__ __launch_bounds__(256, W) void lmpc_linearize_kernel(lmpc_params P, i
     xp[r] = x[r] + (wgt[0] * ks[0][r] + wgt[1] * ks[1][r] + wgt[2] * ks[2][r] + wgt[3] * ks[3][r]);
     gacc[r] = xp[r];
   }
-#pragma unroll
+  // (ONE column at a time since round 6 -- `unroll 1`: unrolled, the compiler interleaved the eight columns' chains and the kernel
+  //  held 378 + 122 registers, or 256 with 612 B of spills in the W = 2 build; now 256 + 66 / 256 with 268 B, same arithmetic per
+  //  column, same bits.  A stage-major form -- one point's partials live at a time, seven columns travelling together -- was built
+  //  and is worse: 728 B)
+#pragma unroll 1
   for (int c = 0; c < 8; ++c) {
     double tu[2] = {c == 6 ? 1.0 : 0.0, c == 7 ? 1.0 : 0.0};
     double e[6], tx[6], kc[6], acc[6];
@@ -80,7 +84,10 @@ __global__ __launch_bounds__(256, W) void lmpc_linearize_kernel(lmpc_params P, i
         if (s < 3) tx[r] = e[r] + cs[s + 1] * dt * kc[r];
       }
     }
-    const double xu = (c < 6) ? x[c] : u[c - 6];
+    double xu = x[0];  // (x[c] / u[c - 6] by selects: c is a run-time index now, and an indexed register array would live in scratch)
+#pragma unroll
+    for (int k = 1; k < 6; ++k) xu = (c == k) ? x[k] : xu;
+    xu = (c == 6) ? u[0] : ((c == 7) ? u[1] : xu);
 #pragma unroll
     for (int r = 0; r < 6; ++r) {
       const double d = e[r] + acc[r];  // [A B][r][c]
@@ -281,8 +288,11 @@ __global__ __launch_bounds__(64 * LMPC_LOOP_WAVES) void lmpc_loop_advance_kernel
   const int N = P.N, NS = N - 1;
   const bool live = b < B;
   const bool ok = live && status[b] == 0;
-  if (n_accepted && w == 0) {  // warm attempts accepted: at most LMPC_WARM_ROUNDS_MAX rounds; a cold solve takes more iterations than that
-    const unsigned long long m = __ballot(ok && iters[b] <= LMPC_WARM_ROUNDS_MAX);
+  if (n_accepted && w == 0) {
+    // warm attempts accepted: the warm kernel's own flag (P.warm_flag, set by the host layer when the last solve of this batch was a
+    // warm one).  Until round 6 this was inferred -- "at most LMPC_WARM_ROUNDS_MAX iterations: a cold solve takes more" -- which
+    // miscounts any cold solve that finishes in four; kept only for a caller that solved cold (flag absent: count nothing).
+    const unsigned long long m = __ballot(ok && P.warm_flag != nullptr && P.warm_flag[live ? b : 0] != 0);
     if (lane == 0 && m) atomicAdd(n_accepted, (unsigned long long)__popcll(m));
   }
   if (!live) return;
@@ -456,4 +466,71 @@ __global__ __launch_bounds__(1024) void lmpc_collect_unverified_kernel(int B, co
     if (status[b] == LMPC_SOLVE_UNVERIFIED) list[atomicAdd(&n, 1)] = b;
   __syncthreads();
   if (threadIdx.x == 0) list[B] = n;
+}
+
+
+// convex_combi_optm_ref for the learning problem's warm start when the safe set goes BY REFERENCE (lmpc_shift_lambda_batch): the
+// previous solution's simplex weights carried onto this period's points by the IDENTITY of the points, not by their position in the
+// set (the query returns its neighbours nearest first: positions are scrambled from one period to the next).  A point of the
+// previous set with weight lam > 0 and code c is looked for in the new set as the sample `advance` steps further along the same
+// lap copy (the plan's terminal state moves forward about one sample per control period: the optimum's support moves with it);
+// where that sample is not among the new neighbours, the point itself.  One thread per problem: the support is <= 6 points.
+__device__ __forceinline__ int lmpc_advance_code(int code, int adv, int n_laps, const int* __restrict__ npts, const int* __restrict__ off) {
+  if (code < 0) return -1;
+  int row = code >> 2, rep = code & 3, l = 0;
+  for (int t = 1; t < n_laps; ++t) l = (row >= off[t]) ? t : l;
+  int jj = row - off[l] + adv;
+  const int n = npts[l];
+  while (jj >= n) {  // past the end of a copy: the start of the next one (x + L e_0: SSTrajectory::process_lap_data, safe_set.cpp:123-125)
+    jj -= n;
+    ++rep;
+  }
+  return rep > 2 ? -1 : ((off[l] + jj) << 2) | rep;
+}
+
+__global__ __launch_bounds__(64) void lmpc_shift_lambda_kernel(int B, int S, int n_laps, const int* __restrict__ npts, const int* __restrict__ off,
+                                                               const int* __restrict__ idx_prev, const double* __restrict__ lam_prev,
+                                                               const int* __restrict__ idx, int advance, double* __restrict__ lam_ref) {
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  if (b >= B) return;
+  constexpr int MAXSUP = 8, MAXFREE = 6;  // (the terminal block keeps at most six weights explicit: MA_MAX of lmpc_solve_kernel.hip)
+  int sup_code[MAXSUP], n = 0;
+  double sup_lam[MAXSUP];
+  for (int i = 0; i < S; ++i) {
+    const double l = lam_prev[(size_t)i * B + b];
+    if (l > 1e-9 && n < MAXSUP) {
+      sup_code[n] = idx_prev[(size_t)i * B + b];
+      sup_lam[n] = l;
+      ++n;
+    }
+  }
+  for (int j = 0; j < S; ++j) lam_ref[(size_t)j * B + b] = 0.0;
+  // position of a code in the new set (its first occurrence: the padding of a short set repeats the last point), -1: not among the neighbours
+  auto find = [&](int want) {
+    if (want < 0) return -1;
+    for (int j = 0; j < S; ++j)
+      if (idx[(size_t)j * B + b] == want) return j;
+    return -1;
+  };
+  // Where the support goes is not smooth (measured in the LMPC experiment, scratch/r6/lmpc_warm_probe.py, profiles/r06_lmpc_warm.txt):
+  // from one period to the next a support point stays, moves one sample along its lap, or two; now and then a far point enters.  Each
+  // support point takes ONE candidate -- `advance` samples on, else the point itself, else `advance` + 1 samples on.  (Proposing all
+  // three as free weights -- a superset of the likely support, for the attempt's repair rounds to prune -- was built and measured:
+  // acceptance fell from 12 % to 0.5 %.  Neighbouring samples of a lap are nearly collinear, the free weights' system C_A loses
+  // rank, and the multiplier steps are noise.)
+  int nfree = 0;
+  for (int k = 0; k < n; ++k) {
+    const int order[3] = {advance, 0, advance + 1};
+    for (int t = 0; t < 3; ++t) {
+      const int j = find(lmpc_advance_code(sup_code[k], order[t], n_laps, npts, off));
+      if (j < 0) continue;
+      double& cell = lam_ref[(size_t)j * B + b];
+      if (cell == 0.0) {
+        if (nfree >= MAXFREE) continue;
+        ++nfree;
+      }
+      cell += sup_lam[k];
+      break;
+    }
+  }
 }

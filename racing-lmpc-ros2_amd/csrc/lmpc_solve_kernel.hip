@@ -2428,6 +2428,7 @@ __device__ __forceinline__ void lmpc_solve_problem(
   // all sums below then run over O(1) offsets instead of absolute abscissae.
   const int S = P.S;
   SimplexRows<treal, KS> sx;
+  treal lm_cold = 0.0;  // the cold start's simplex weight, 1 / (points kept)
   if constexpr (KS > 0) {
     treal* const UL = TT + TL_UL;
     sx.ul = UL;
@@ -2511,6 +2512,7 @@ __device__ __forceinline__ void lmpc_solve_problem(
       n_on += sx.on[q] ? real(1) : real(0);
     }
     const treal inv_on = treal(1) / treal(uni(wave_sum(n_on)));
+    lm_cold = inv_on;
 #pragma unroll
     for (int q = 0; q < KS; ++q) {
       sx.lm[q] = sx.on[q] ? inv_on : treal(0);
@@ -2663,8 +2665,13 @@ __device__ __forceinline__ void lmpc_solve_problem(
   // most.  Accepted: the optimum for about two iterations' worth of sweeps -- 92 .. 96 % of the periods of a closed loop at
   // N = 20 .. 60 on the serial twin (scratch/r5/warm_loop.py), iterations 6.5 -> 1.5 in the mean, answers those of the cold
   // solve to 1e-11.  Refused: attempt 1, the cold start, as if nothing had happened (the rounds spent are counted in `iters`).
-  constexpr bool WARM_BUILT = WARMK && sizeof(real) == 8 && KS == 0 && sizeof(io) == 8;
-  const bool warm = WARM_BUILT && P.warm_X != nullptr && polish_on && feasible;
+  // The learning problem (round 6) takes the route with one more piece of the plan: the simplex weights of its terminal point --
+  // the reference's convex_combi_optm_ref (set_initial(convex_combi_, ...), racing_mpc.cpp:281), P.warm_lam [S][B], aligned with
+  // THIS call's safe-set points.  Their support is the working set of the simplex rows -- free where the plan's weight is positive,
+  // held at zero elsewhere --, the weights themselves start the multiplier steps.  Without them there is nothing to start from
+  // (all S weights free is more than the terminal block keeps explicit): the solve is cold.
+  constexpr bool WARM_BUILT = WARMK && sizeof(real) == 8 && sizeof(io) == 8;
+  const bool warm = WARM_BUILT && P.warm_X != nullptr && polish_on && feasible && (KS == 0 || P.warm_lam != nullptr);
   bool warm_done = false;
   for (int attempt = warm ? 0 : 1; attempt < 2 && !warm_done; ++attempt) {
 #pragma unroll
@@ -2730,8 +2737,32 @@ __device__ __forceinline__ void lmpc_solve_problem(
           s_tu[q] = (f & F_UP) ? s_tu[q] : real(1);
           s_tl[q] = (f & F_LO) ? s_tl[q] : real(1);
         }
+        bool lam_ok = true;
+        if constexpr (KS > 0) {  // the simplex rows' working set and start from the plan's weights (copies of a dropped run: ignored)
+          treal lw[KS], lsum = 0.0;
+#pragma unroll
+          for (int q = 0; q < KS; ++q) {
+            const int j = lane + 64 * q;
+            lw[q] = sx.on[q] ? fmax(treal(P.warm_lam[(size_t)(j < S ? j : 0) * B + b]), treal(0)) : treal(0);
+            lsum += lw[q];
+          }
+          lsum = uni(wave_sum(lsum));
+          lam_ok = lsum > treal(0);
+          const treal inv = lam_ok ? treal(1) / lsum : treal(0);
+#pragma unroll
+          for (int q = 0; q < KS; ++q) {
+            const treal lm = lw[q] * inv;
+            const bool fr = sx.on[q] && lm > treal(WARM_ACT);
+            sx.lm[q] = lm;
+            sx.t[q] = sx.on[q] ? (fr ? lm : treal(0)) : treal(1);  // (the polish classifies by l > t: held)
+            sx.l[q] = sx.on[q] ? (fr ? treal(0) : treal(1)) : treal(0);
+            sx.p[q] = 0.0;
+            sx.dl[q] = 0.0;
+            sx.aidx[q] = -1;
+          }
+        }
         wave_sync();
-        if (polish_attempt(P.warm_rounds > 0 ? P.warm_rounds : WARM_ROUNDS)) {
+        if (lam_ok && polish_attempt(P.warm_rounds > 0 ? P.warm_rounds : WARM_ROUNDS)) {
           polished = true;
           status = LMPC_SOLVE_OPTIMAL;
           warm_done = true;
@@ -2741,6 +2772,18 @@ __device__ __forceinline__ void lmpc_solve_problem(
           for (int q = 0; q < KQ; ++q) {
             s_tu[q] = s_tl[q] = 1.0;
             s_lu[q] = s_ll[q] = 0.0;
+          }
+          if constexpr (KS > 0) {
+#pragma unroll
+            for (int q = 0; q < KS; ++q) {
+              sx.lm[q] = sx.on[q] ? lm_cold : treal(0);
+              sx.t[q] = sx.on[q] ? lm_cold : treal(1);
+              sx.l[q] = 0.0;
+              sx.p[q] = 0.0;
+              sx.dl[q] = 0.0;
+              sx.aidx[q] = -1;
+            }
+            sx.m = 0;
           }
         }
         continue;
@@ -3473,6 +3516,9 @@ __device__ __forceinline__ void lmpc_solve_problem(
   if (lane == 0) {
     status_out[b] = status;
     iters_out[b] = it;
+    if constexpr (WARMK) {
+      if (P.warm_flag) P.warm_flag[b] = warm_done ? 1 : 0;  // (explicit: until round 6 callers inferred it from iters <= 4)
+    }
 #ifdef LMPC_PHASE_TIMING
     if (kkt_out) {
       for (int k = 0; k < 16; ++k) kkt_out[k * (size_t)B + b] = (io)pf.acc[k];
@@ -3565,10 +3611,11 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(sizeof(real), KQ, KS)) void
 // The warm-start solve (lmpc_solve_batch_warm) is a kernel of its own: compiled into lmpc_solve_kernel, the attempt's code changed
 // the register allocation of the cold path -- 992 -> 1296 B of scratch per lane at KQ = 11, 1796 -> 2128 B at KQ = 14, 132 more
 // spilled scalars in the headline kernel -- for callers that never pass a plan.  Same body, WARMK = true.
-template <int KQ>
-__global__ __launch_bounds__(64, lmpc_waves_per_simd(8, KQ, 0)) void lmpc_solve_warm_kernel(
+template <int KQ, int KS>
+__global__ __launch_bounds__(64, lmpc_waves_per_simd(8, KQ, KS)) void lmpc_solve_warm_kernel(
     lmpc_params P, int B, const double* __restrict__ ws_lin, const double* __restrict__ x_ic, const double* __restrict__ u_ic,
     const double* __restrict__ T_ref, const double* __restrict__ bl, const double* __restrict__ br, const double* __restrict__ vref,
+    const double* __restrict__ ss_x, const double* __restrict__ ss_j, double* __restrict__ lam_out,
     double* __restrict__ X_out, double* __restrict__ U_out, double* __restrict__ dU_out, int* __restrict__ status_out,
     int* __restrict__ iters_out, double* __restrict__ kkt_out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -3578,8 +3625,8 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(8, KQ, 0)) void lmpc_solve_
     b = (int)blockIdx.x < n ? P.launch_order[blockIdx.x] : B;
   }
   if (b >= B) return;
-  lmpc_solve_problem<double, KQ, 0, double, false, true>(P, B, b, lds_raw, ws_lin, x_ic, u_ic, T_ref, bl, br, vref, nullptr, nullptr, nullptr, X_out,
-                                                         U_out, dU_out, status_out, iters_out, kkt_out);
+  lmpc_solve_problem<double, KQ, KS, double, false, true>(P, B, b, lds_raw, ws_lin, x_ic, u_ic, T_ref, bl, br, vref, ss_x, ss_j, lam_out, X_out,
+                                                          U_out, dU_out, status_out, iters_out, kkt_out);
 }
 
 #define LMPC_INSTANTIATE(REAL, KQ, KS, IO)                                                                              \
@@ -3593,14 +3640,23 @@ LMPC_INSTANTIATE_X(LMPC_SINGLE_INSTANCE)
 LMPC_INSTANTIATE(float, 4, 2, double)
 LMPC_INSTANTIATE(float, 4, 3, double)
 #else
-#define LMPC_INSTANTIATE_WARM(KQ)                                                                                        \
-  template __global__ void lmpc_solve_warm_kernel<KQ>(lmpc_params, int, const double*, const double*, const double*, const double*,   \
-                                                      const double*, const double*, const double*, double*, double*, double*, int*, int*, double*);
-LMPC_INSTANTIATE_WARM(2)
-LMPC_INSTANTIATE_WARM(4)
-LMPC_INSTANTIATE_WARM(7)
-LMPC_INSTANTIATE_WARM(11)
-LMPC_INSTANTIATE_WARM(14)
+#define LMPC_INSTANTIATE_WARM(KQ, KS)                                                                                    \
+  template __global__ void lmpc_solve_warm_kernel<KQ, KS>(lmpc_params, int, const double*, const double*, const double*, const double*,   \
+                                                          const double*, const double*, const double*, const double*, const double*, double*, \
+                                                          double*, double*, double*, int*, int*, double*);
+LMPC_INSTANTIATE_WARM(2, 0)
+LMPC_INSTANTIATE_WARM(4, 0)
+LMPC_INSTANTIATE_WARM(7, 0)
+LMPC_INSTANTIATE_WARM(11, 0)
+LMPC_INSTANTIATE_WARM(14, 0)
+// the learning problem's warm start (round 6): the horizons the reference ships for it (barc_lmpc N = 40, iac_car_lmpc N = 60) and
+// BASELINE's N = 20, with 96 (KS = 2) and 160 (KS = 3) points
+LMPC_INSTANTIATE_WARM(4, 2)
+LMPC_INSTANTIATE_WARM(4, 3)
+LMPC_INSTANTIATE_WARM(7, 2)
+LMPC_INSTANTIATE_WARM(7, 3)
+LMPC_INSTANTIATE_WARM(11, 2)
+LMPC_INSTANTIATE_WARM(11, 3)
 LMPC_INSTANTIATE(double, 2, 0, double)
 LMPC_INSTANTIATE(double, 4, 0, double)
 LMPC_INSTANTIATE(double, 7, 0, double)

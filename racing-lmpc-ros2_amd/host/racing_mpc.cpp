@@ -1,6 +1,7 @@
 // racing_mpc.cpp -- see racing_mpc.hpp.  Plain C++17, links liblmpc_hip.so only.
 #include "racing_mpc.hpp"
 
+#include <algorithm>
 #include <cmath>
 #include <iostream>
 #include <stdexcept>
@@ -68,8 +69,9 @@ void RacingMPC::solve(const DMDict& in, DMDict& out, Dict& stats) {
   // Warm start (racing_mpc.cpp:287-327).  With the keys: all four are required (upstream reads them with at()), and
   // T_optm_ref replaces T_ref.  Without them upstream restarts from its own previous solution -- and throws when there is
   // none.  Since round 5 the plan is USED by the tracking QP (lmpc_solve_host_warm: an active-set solve on it before any
-  // interior point; refused, the cold solve -- the same optimum either way); the learning problem and the sequential-QP solve
-  // keep the contract only: the keys are checked, and a controller that has never run its solver refuses a call without them.
+  // interior point; refused, the cold solve -- the same optimum either way); since round 6 by the learning QP too, when
+  // `convex_combi_optm_ref` is among the inputs (racing_mpc.cpp:281: lmpc_solve_host_warm_ss); the sequential-QP solve keeps the
+  // contract only: the keys are checked, and a controller that has never run its solver refuses a call without them.
   const bool warm = in.count("X_optm_ref") > 0;
   const DM* X_warm = nullptr;
   const DM* U_warm = nullptr;
@@ -137,13 +139,38 @@ void RacingMPC::solve(const DMDict& in, DMDict& out, Dict& stats) {
     if (status == LMPC_SOLVE_OPTIMAL && !(move <= 1e-8)) status = LMPC_SOLVE_MAX_ITER;
   } else {
     // a plan is worth trying once the controller has a solution behind it (the node's first call hands the zero-input rollout)
-    const bool use_plan = warm && ran_ && !S && X_warm->rows == 6 && X_warm->cols == N && U_warm->rows == 2 && U_warm->cols == N - 1;
+    // (the learning problem also needs the plan's simplex weights and the set they were solved on)
+    const bool have_lam = S && in.count("convex_combi_optm_ref") > 0 && in.at("convex_combi_optm_ref").data.size() == S && ss_x_prev_.size() == 6 * S;
+    const bool use_plan = warm && ran_ && (!S || have_lam) && X_warm->rows == 6 && X_warm->cols == N && U_warm->rows == 2 && U_warm->cols == N - 1;
     DM Xw;
     if (use_plan) {  // the same abscissa alignment as X_ref (racing_mpc.cpp:297-301)
       Xw = *X_warm;
       for (std::size_t i = 0; i < N; ++i) Xw(0, i) = align_abscissa(Xw(0, i), x_ic(0, 0), total_length);
     }
-    const int rc = use_plan
+    std::vector<double> lam_ref;
+    if (use_plan && S) {
+      // Upstream hands convex_combi_optm_ref to OSQP by POSITION (racing_mpc.cpp:281), but the query returns its neighbours nearest
+      // first, so the same safe-set point sits at another position from one call to the next.  The weights are carried over by the
+      // identity of the points: entry j of this call's set takes the weight of the previous call's point with the same coordinates
+      // (its first occurrence: the padding repeats the last point); a point that has left the set drops its weight.
+      const DM& lp = in.at("convex_combi_optm_ref");
+      lam_ref.assign(S, 0.0);
+      std::vector<char> used(S, 0);
+      for (std::size_t j = 0; j < S; ++j) {
+        if (j > 0 && std::equal(ss_x_.begin() + 6 * j, ss_x_.begin() + 6 * j + 6, ss_x_.begin() + 6 * (j - 1))) continue;
+        for (std::size_t i = 0; i < S; ++i)
+          if (!used[i] && lp.data[i] > 0.0 && std::equal(ss_x_.begin() + 6 * j, ss_x_.begin() + 6 * j + 6, ss_x_prev_.begin() + 6 * i)) {
+            lam_ref[j] += lp.data[i];
+            used[i] = 1;
+          }
+      }
+    }
+    const int rc = (use_plan && S)
+        ? lmpc_solve_host_warm_ss(h_, x_ic.data.data(), u_ic.data.data(), X_ref.data.data(), U_ref.data.data(), T.data.data(),
+                                  bound_left.data.data(), bound_right.data.data(), curvatures.data.data(), vel_ref.data.data(), total_length,
+                                  ss_x_.data(), ss_j_.data(), Xw.data.data(), U_warm->data.data(), lam_ref.data(), X.data.data(), U.data.data(),
+                                  dU.data.data(), lam.data.data(), &status, &iters)
+        : use_plan
         ? lmpc_solve_host_warm(h_, x_ic.data.data(), u_ic.data.data(), X_ref.data.data(), U_ref.data.data(), T.data.data(),
                                bound_left.data.data(), bound_right.data.data(), curvatures.data.data(), vel_ref.data.data(), total_length,
                                Xw.data.data(), U_warm->data.data(), X.data.data(), U.data.data(), dU.data.data(), &status, &iters)
@@ -172,7 +199,10 @@ void RacingMPC::solve(const DMDict& in, DMDict& out, Dict& stats) {
   out["X_optm"] = X;
   out["U_optm"] = U;
   out["dU_optm"] = dU;
-  if (S) out["convex_combi_optm"] = lam;
+  if (S) {
+    out["convex_combi_optm"] = lam;
+    ss_x_prev_ = ss_x_;  // the set these weights belong to (the next call's convex_combi_optm_ref is matched against it)
+  }
 }
 
 void RacingMPC::create_warm_start(const DMDict& in, DMDict& out) {

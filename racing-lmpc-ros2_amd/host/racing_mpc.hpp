@@ -88,6 +88,7 @@ class RacingMPC {
   std::unique_ptr<lmpc::vehicle_model::racing_trajectory::SafeSetRecorder> ss_recorder_;
   bool ss_loaded_ = false;
   std::vector<double> ss_x_, ss_j_;  // last non-empty query, padded (the parameter keeps its value upstream)
+  std::vector<double> ss_x_prev_;    // the set the last returned convex_combi_optm weighs (warm start: weights carried over by point identity)
 };
 
 }  // namespace racing_mpc

@@ -80,6 +80,25 @@ int main(int argc, char** argv) {
   std::printf("iter_count %g  ss_x %.1e  ss_j %.1e  err_x %.3e  err_u %.3e  sum lambda %.12f\n", stats["iter_count"], es, ej, ex, eu, sl);
   bool ok = es == 0.0 && ej == 0.0 && ex < 1e-6 && eu < 1e-6 && std::fabs(sl - 1.0) < 1e-9;
 
+  // the warm start of the learning controller (round 6; racing_mpc.cpp:281, 293-305): the same problem again with the solution as the
+  // plan and its simplex weights as convex_combi_optm_ref -> the active-set attempt is accepted (a handful of rounds, not an
+  // interior-point run) and returns the same optimum
+  {
+    DMDict inw = in, ow;
+    inw["X_optm_ref"] = out["X_optm"];
+    inw["U_optm_ref"] = out["U_optm"];
+    inw["dU_optm_ref"] = out["dU_optm"];
+    inw["convex_combi_optm_ref"] = out["convex_combi_optm"];
+    Dict sw;
+    mpc.solve(inw, ow, sw);
+    double dw = 0;
+    if (ow.count("X_optm"))
+      for (std::size_t i = 0; i < (std::size_t)N; ++i)
+        for (int k = 0; k < 6; ++k) dw = std::fmax(dw, std::fabs(ow["X_optm"](k, i) - out["X_optm"](k, i)) / sx[k]);
+    std::printf("warm: warm_start %g  iter_count %g (cold %g)  distance from the cold answer %.2e\n", sw["warm_start"], sw["iter_count"], stats["iter_count"], dw);
+    ok = ok && ow.count("X_optm") && sw["warm_start"] == 1.0 && sw["iter_count"] <= 4.0 && dw < 1e-9;
+  }
+
   // recorder: drive the abscissa over the line twice; the first (partial) lap is dropped, the second is stored and saved
   DMDict o2;
   const int per_lap = 40;

@@ -53,3 +53,34 @@ def test_twin_warm_from_the_dense_optimum_and_from_noise(pkg, name):
     exu, ed = per_problem_err(n, cold)
     assert exu.max() < 1e-8 and ed.max() < 1e-8
     assert (n["iters"] >= cold["iters"]).all()
+
+
+@pytest.mark.parametrize("case", ["barc_lmpc_n20_s160", "barc_lmpc_spec_n20_s160", "barc_lmpc_n20_s96"])
+def test_twin_learning_warm_start_from_the_optimum(pkg, case):
+    """The learning problem's warm start on the serial twin (lmpc_oracle_solve_range_warm_lam; the kernel's lmpc_solve_batch_warm_ss
+    follows it line for line): the optimum as the plan, its simplex weights as convex_combi_optm_ref (racing_mpc.cpp:281) ->
+    accepted by the active-set attempt within two rounds on >= 90 %, the cold solve's answer to 1e-8; a plan with noise on it is
+    refused and costs the cold solve plus its rounds; without weights the call is the cold solve."""
+    import dense_cases as DC
+    from oracle import cbind, params as OP
+
+    cfg, veh, inp, ss_x, ss_j = DC.build(pkg, case)
+    n = 96
+    inp = {k: (v[..., :n] if hasattr(v, "shape") and np.ndim(v) >= 1 and np.shape(v)[-1] >= n else v) for k, v in inp.items()}
+    ss_x, ss_j = ss_x[..., :n], ss_j[..., :n]
+    cold = cbind.solve_batch(cfg, veh, inp, ss_x, ss_j)
+    ok = cold["status"] == 0
+    assert ok.all()
+    plan = {"X_ref": cold["X_optm"], "U_ref": cold["U_optm"], "lam": cold["convex_combi_optm"]}
+    warm = cbind.solve_batch(cfg, veh, inp, ss_x, ss_j, warm=True, warm_plan=plan)
+    e = np.abs((warm["X_optm"] - cold["X_optm"]) / OP.SCALE_X[:, None, None]).max(axis=(0, 1))
+    print("%s: accepted %.3f, iterations warm %.2f cold %.2f, worst %.1e" % (case, (warm["iters"] <= 4).mean(), warm["iters"].mean(), cold["iters"].mean(), e.max()))
+    assert (warm["status"] == 0).all() and (warm["iters"] <= 4).mean() >= 0.9 and e.max() < 1e-8
+    assert np.abs(warm["convex_combi_optm"] - cold["convex_combi_optm"]).max() < 1e-6
+    rng = np.random.default_rng(0)
+    noisy = {"X_ref": cold["X_optm"] + rng.normal(0, 1e-3, cold["X_optm"].shape) * OP.SCALE_X[:, None, None],
+             "U_ref": cold["U_optm"] + rng.normal(0, 1e-3, cold["U_optm"].shape) * OP.SCALE_U[:, None, None], "lam": cold["convex_combi_optm"]}
+    w2 = cbind.solve_batch(cfg, veh, inp, ss_x, ss_j, warm=True, warm_plan=noisy)
+    assert np.array_equal(w2["status"], cold["status"]) and np.abs(w2["X_optm"] - cold["X_optm"]).max() < 1e-9 and (w2["iters"] >= cold["iters"]).all()
+    w3 = cbind.solve_batch(cfg, veh, inp, ss_x, ss_j, warm=True, warm_plan={"X_ref": cold["X_optm"], "U_ref": cold["U_optm"]})
+    assert np.array_equal(w3["X_optm"], cold["X_optm"]) and np.array_equal(w3["iters"], cold["iters"])
