@@ -530,6 +530,13 @@ int lmpc_query_residency(lmpc_handle* h, int32_t* problems_per_cu);
 #define LMPC_PRECISION_MIXED 2
 int lmpc_query_launch_for(lmpc_handle* h, int32_t precision, int32_t* lds_bytes_per_problem, int32_t* problems_per_cu);
 
+/* Wavefronts per problem of the cold fp64 tracking solve (lmpc_solve_batch; no counterpart upstream): 0 (default) the library's choice
+ * by horizon, 1 one wavefront per problem (every configuration), 2 two wavefronts per problem on one LDS record -- the inequality
+ * rows dealt to 128 lanes, the Riccati chains on the first wave (csrc/lmpc_solve_w2.hip.h): built for N >= 24; where it is not
+ * built (N <= 23, the learning problem, reduced precision, the warm start) the setting is ignored.  Same algorithm, same
+ * contract; the answers differ from the one-wave kernel's by the order of a few wave-wide sums (1e-12). */
+int lmpc_set_waves_per_problem(lmpc_handle* h, int32_t waves);
+
 /* The precision the most recent batched solve on this handle ran in: LMPC_PRECISION_MIXED after lmpc_solve_batch_mixed (or
  * lmpc_solve_batch_ss_idx with that precision) where a reduced-precision kernel exists for the handle's (N, num_ss_pts),
  * LMPC_PRECISION_F64 where the entry fell back to the fp64 kernels (above), LMPC_PRECISION_F32 after lmpc_solve_batch_f32. */

@@ -903,7 +903,9 @@ static void primal_update(prob_t* p, double alpha) {
 #define POLISH_RD 1e-6
 #endif
 #define POLISH_ROUNDS 4
-#define POLISH_STEPS 4 /* at most; the loop stops after the second when that one moved the iterate by <= POLISH_STEP_OK */
+#define POLISH_EXIT 256        /* flag in polish_rounds' max_rounds: the attempt at the interior point's exit */
+#define POLISH_EXIT_GAMMA 1e-2 /* ... holds a row from lam > 1e-2 t on (the early and the warm attempts: lam > t) */
+#define POLISH_STEPS 6 /* at most (round 6: 4 until then; polish_limits<double>::steps of the kernel says why); the loop stops after the second when that one moved the iterate by <= POLISH_STEP_OK */
 #define POLISH_STEP_OK 1e-7
 #ifndef WARM_ROUNDS
 #define WARM_ROUNDS 2       /* repairs a warm start may spend before the cold start takes over */
@@ -935,14 +937,31 @@ typedef struct {
 __attribute__((optimize("no-tree-vectorize"))) static int polish_rounds(prob_t* p, work_t* w, polish_t* q, int m_rows, int* rounds_out,
                                                                          double* mu_out, int max_rounds) {
   const int N = p->N, S = p->S;
+  /* POLISH_EXIT in max_rounds marks the attempt at the interior point's EXIT (round 6).  There a row with lam ~ t is a weakly
+   * active one (lam t = mu <= 1e-9: both ~ 1e-5 .. 1e-7, where an inactive row has lam / t = mu / t^2 <= 1e-3 unless its slack is
+   * itself below 1e-3), and which side of lam = t it falls on is rounding: the kernel with the fused factorisation put one such row of
+   * one problem of tests/dispatch_sweep.py (BARC tracking, N = 51) on the free side where this twin held it -- the free row was then
+   * violated by the equality-constrained solve, its neighbours' multipliers went negative, the repairs released THEM, and the
+   * interior point's own iterate (3e-6 from the dense optimum) stood as OPTIMAL.  In doubt a row is HELD: a weakly active row that is
+   * held costs nothing (multiplier ~ 0 >= -POLISH_DUAL), one that should be free comes out with a negative multiplier and is released
+   * by the next round.  The early attempt (mu <= 1e-8) keeps lam > t: there the ratio of an inactive row is still 1e-2 .. 1. */
+  const double gam = (max_rounds & POLISH_EXIT) ? POLISH_EXIT_GAMMA : 1.0;
+  max_rounds &= ~POLISH_EXIT;
   memcpy(q->z, p->z, sizeof(q->z));
   memcpy(q->v, p->v, sizeof(q->v));
   memcpy(q->lmb, p->lmb, sizeof(q->lmb));
   q->sigma = p->sigma;
   for (int i = 0; i < N; ++i)
     for (int sl = 0; sl < NSLOT; ++sl)
-      for (int sd = 0; sd < 2; ++sd) q->held[i][sl][sd] = p->act[i][sl][sd] && p->lam[i][sl][sd] > p->t[i][sl][sd];
+      for (int sd = 0; sd < 2; ++sd) q->held[i][sl][sd] = p->act[i][sl][sd] && p->lam[i][sl][sd] > gam * p->t[i][sl][sd];
   for (int j = 0; j < S; ++j) q->heldl[j] = p->ll[j] > p->tl[j];
+  if (getenv("LMPC_ORACLE_POLISH_TRACE")) {
+    for (int i = 0; i < N; ++i)
+      for (int sl = 0; sl < NSLOT; ++sl)
+        for (int sd = 0; sd < 2; ++sd)
+          if (p->act[i][sl][sd] && p->lam[i][sl][sd] > 1e-3 * p->t[i][sl][sd] && p->lam[i][sl][sd] < 1e3 * p->t[i][sl][sd])
+            fprintf(stderr, "   borderline row (%d,%d,%d): lam %.3e t %.3e held %d\n", i, sl, sd, p->lam[i][sl][sd], p->t[i][sl][sd], q->held[i][sl][sd]);
+  }
   int ok = 0;
   q->noise = 0;
   for (int round = 0; round < max_rounds && !ok; ++round) {
@@ -1099,7 +1118,7 @@ __attribute__((optimize("no-tree-vectorize"))) static int polish_rounds(prob_t* 
 }
 
 static int polish(prob_t* p, work_t* w, polish_t* q, int m_rows, int* rounds_out, double* mu_out) {
-  return polish_rounds(p, w, q, m_rows, rounds_out, mu_out, POLISH_ROUNDS);
+  return polish_rounds(p, w, q, m_rows, rounds_out, mu_out, POLISH_ROUNDS | POLISH_EXIT);
 }
 
 /* Solve the QP with a Mehrotra predictor-corrector interior-point method.  The iteration

@@ -23,7 +23,7 @@ _ABI_SYMBOLS = ("lmpc_create", "lmpc_destroy", "lmpc_last_error", "lmpc_set_stre
                 "lmpc_solve_batch_mixed", "lmpc_prepare_failed_batch", "lmpc_set_launch_order", "lmpc_set_warm_rounds", "lmpc_loop_advance_batch", "lmpc_launch_order_from_iters", "lmpc_set_output_layout",
                 "lmpc_ss_query_idx_batch", "lmpc_solve_batch_ss_idx", "lmpc_solve_batch_warm", "lmpc_solve_host_warm",
                 "lmpc_last_solve_precision", "lmpc_solve_batch_warm_ss", "lmpc_solve_host_warm_ss", "lmpc_shift_lambda_batch",
-                "lmpc_get_warm_accepted")
+                "lmpc_get_warm_accepted", "lmpc_set_waves_per_problem")
 
 
 class LmpcError(RuntimeError):
@@ -429,12 +429,15 @@ class Solver:
         self._check(self.lib.lmpc_get_warm_accepted(self._h, C.c_int32(B), _ptr(out)), "lmpc_get_warm_accepted")
         return out
 
+    def set_waves_per_problem(self, waves: int):
+        """lmpc_set_waves_per_problem: 0 the library's choice, 1 / 2 wavefronts per problem (2: fp64 tracking, N >= 24, cold solves)."""
+        self._check(self.lib.lmpc_set_waves_per_problem(self._h, C.c_int32(int(waves))), "lmpc_set_waves_per_problem")
+
     def last_solve_precision(self) -> str:
         """lmpc_last_solve_precision: "f64", "f32" or "mixed" -- what the most recent batched solve ran in (solve(mixed=True) falls
         back to fp64 where no reduced-precision kernel exists for this (N, num_ss_pts): include/lmpc_hip.h)."""
         p = C.c_int32(-1)
-        self._check(self.lib.lmpc_last_solve_precision(self._h, C.byref(p)), "lmpc_last_solve_precision", "lmpc_solve_batch_warm_ss", "lmpc_solve_host_warm_ss", "lmpc_shift_lambda_batch",
-                "lmpc_get_warm_accepted")
+        self._check(self.lib.lmpc_last_solve_precision(self._h, C.byref(p)), "lmpc_last_solve_precision")
         return {0: "f64", 1: "f32", 2: "mixed"}[p.value]
 
     # ---- single precision (BASELINE configs[3]) ----

@@ -77,6 +77,7 @@ struct lmpc_handle {
   unsigned ss_gen = 0;      // bumped by every lmpc_set_safe_set: the store the codes of lmpc_ss_query_idx_batch point into
   unsigned ss_idx_gen = 0;  // the generation the last lmpc_ss_query_idx_batch ran against (0: none yet)
   int last_precision = LMPC_PRECISION_F64;  // what the last batched solve ran in (lmpc_last_solve_precision)
+  int waves = 0;  // lmpc_set_waves_per_problem: 0 the library's choice, 1 / 2 forced (2: fp64 tracking problem, N >= 24, cold solves)
   // regression store (device): lap samples, one-step residuals of the nominal model, end-of-lap flags
   bool reg_on = false;
   int reg_total = 0;
@@ -111,6 +112,13 @@ struct lmpc_handle {
 };
 
 namespace {
+
+// which cold fp64 tracking solves take the two-wave kernels: forced by lmpc_set_waves_per_problem, else by measurement (LMPC_W2_AUTO_KQ:
+// the smallest one-wave slot count from which two waves are the default)
+#ifndef LMPC_W2_AUTO_KQ
+#define LMPC_W2_AUTO_KQ 14  // N >= 65: 11.4 -> 9.6 ms per 4096 at N = 80; parity at N = 60, -3 % at N <= 40 (csrc/lmpc_solve_w2.hip.h)
+#endif
+inline bool lmpc_use_two_waves(int waves, int kq) { return waves == 2 || (waves == 0 && kq >= LMPC_W2_AUTO_KQ); }
 
 int fail(lmpc_handle* h, int code, const std::string& msg) {
   if (h) h->err = msg;
@@ -315,6 +323,30 @@ int launch_solve_warm(lmpc_handle* h, const solve_args& a) {
                   (void*)&a.vref, (void*)&a.ss_x, (void*)&a.ss_j, (void*)&a.lam, (void*)&a.X, (void*)&a.U, (void*)&a.dU, (void*)&a.status,
                   (void*)&a.iters, (void*)&a.kkt};
   HIP_TRY(h, hipLaunchKernel(fn, dim3(8 * ((a.B + 7) / 8)), dim3(64), args, a.lds_bytes, h->stream));
+  return LMPC_OK;
+}
+
+// two wavefronts per problem (csrc/lmpc_solve_w2.hip.h): the fp64 tracking problem from N = 24 on
+const void* pick_w2_fn(int kq) {
+  switch (kq) {
+    case 7: return reinterpret_cast<const void*>(&lmpc_solve_kernel_w2<7>);
+    case 11: return reinterpret_cast<const void*>(&lmpc_solve_kernel_w2<11>);
+    case 14: return reinterpret_cast<const void*>(&lmpc_solve_kernel_w2<14>);
+  }
+  return nullptr;
+}
+
+int launch_solve_w2(lmpc_handle* h, const void* fn, const solve_args& a) {
+  HIP_TRY(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)a.lds_bytes));
+  lmpc_params P = h->P;
+  P.out_aos = a.aos ? 1 : 0;
+  set_ss_reference(h, P, a);
+  P.launch_order = (h->order && a.B == h->order_n) ? h->order : nullptr;
+  int B = a.B;
+  const double* ws = h->ws;
+  void* args[] = {(void*)&P, (void*)&B, (void*)&ws, (void*)&a.x_ic, (void*)&a.u_ic, (void*)&a.T_ref, (void*)&a.bl, (void*)&a.br,
+                  (void*)&a.vref, (void*)&a.X, (void*)&a.U, (void*)&a.dU, (void*)&a.status, (void*)&a.iters, (void*)&a.kkt};
+  HIP_TRY(h, hipLaunchKernel(fn, dim3(8 * ((a.B + 7) / 8)), dim3(128), args, a.lds_bytes, h->stream));
   return LMPC_OK;
 }
 
@@ -558,7 +590,8 @@ int lmpc_reserve(lmpc_handle* h, int32_t max_batch) {
 int lmpc_query_launch(const lmpc_handle* h, int32_t* lds_bytes_per_problem, int32_t* threads_per_problem) {
   if (!h) return LMPC_ERR_ARGUMENT;
   if (lds_bytes_per_problem) *lds_bytes_per_problem = (int32_t)lmpc_lds_bytes(h->P.N, h->P.learning, h->P.S, 8);
-  if (threads_per_problem) *threads_per_problem = 64;
+  if (threads_per_problem)  // (two wavefronts per problem where the cold fp64 tracking solve takes those kernels: lmpc_set_waves_per_problem)
+    *threads_per_problem = (!h->P.learning && lmpc_use_two_waves(h->waves, kq_for(h->P.N)) && kq_for(h->P.N) >= 7) ? 128 : 64;
   return LMPC_OK;
 }
 
@@ -582,7 +615,12 @@ int lmpc_query_launch_for(lmpc_handle* h, int32_t precision, int32_t* lds_bytes_
   HIP_TRY(h, hipSetDevice(h->device));
   const int kq = kq_for(h->P.N), ks = ks_for(h->P.S);
   const void* fn = nullptr;
+  int threads = 64;
   if (precision == LMPC_PRECISION_F64) fn = pick_solve_fn(kq, ks);
+  if (precision == LMPC_PRECISION_F64 && !h->P.learning && lmpc_use_two_waves(h->waves, kq) && pick_w2_fn(kq)) {
+    fn = pick_w2_fn(kq);  // (what lmpc_solve_batch launches for this handle: two wavefronts per problem)
+    threads = 128;
+  }
   if (precision == LMPC_PRECISION_MIXED) fn = pick_mixed_fn(kq, ks);
   if (precision == LMPC_PRECISION_F32 && !h->P.learning) fn = pick_f32_fn(kq);
   if (!fn) return fail(h, LMPC_ERR_UNSUPPORTED, "no kernel for this (N, num_ss_pts) at this precision");
@@ -591,9 +629,16 @@ int lmpc_query_launch_for(lmpc_handle* h, int32_t precision, int32_t* lds_bytes_
   if (problems_per_cu) {
     int n = 0;
     HIP_TRY(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, 64, lds));
+    HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, threads, lds));
     *problems_per_cu = n;
   }
+  return LMPC_OK;
+}
+
+int lmpc_set_waves_per_problem(lmpc_handle* h, int32_t waves) {
+  if (!h) return LMPC_ERR_ARGUMENT;
+  if (waves < 0 || waves > 2) return fail(h, LMPC_ERR_ARGUMENT, "lmpc_set_waves_per_problem: 0 (the library's choice), 1 or 2");
+  h->waves = waves;
   return LMPC_OK;
 }
 
@@ -712,6 +757,8 @@ int solve_batch_fp64_arrays(lmpc_handle* h, bool mixed, bool aos, int32_t batch,
     HIP_TRY(h, hipMemsetD32Async((hipDeviceptr_t)status, LMPC_SOLVE_UNVERIFIED, (size_t)batch, h->stream));
   else if (a.warm_X && a.warm_U)
     rc = launch_solve_warm(h, a);
+  else if (!mixed && !h->P.learning && lmpc_use_two_waves(h->waves, kq_for(N)) && pick_w2_fn(kq_for(N)))
+    rc = launch_solve_w2(h, pick_w2_fn(kq_for(N)), a);
   else
     rc = launch_solve(h, fn, a, (mixed && h->P.polish >= 0) ? 1 : 0);
   if (rc != LMPC_OK) return rc;

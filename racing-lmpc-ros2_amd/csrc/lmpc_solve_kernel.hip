@@ -140,7 +140,12 @@ struct Prof {};
 #define F_MOVE 16
 #define F_EY 32
 #define F_SCH 64
-#define MROW 10  // padded row stride of the 8x8 work matrices (conflict-free b128 row reads)
+// Row r of the 8x8 work matrices P, W, Y starts at MROWS(r) = 8 r + 2 (r >> 1) -- the stage records' skew (ST_ROW): the eight rows
+// sit on eight different 4-bank groups (conflict-free b128 row reads, as with the stride of 10 doubles used until round 5), AND the
+// rows of a 16-lane store group (r = 2g, 2g + 1) are 16 banks apart, so the element stores of W, Y, P -- ds_write_b64: contiguous
+// 16-lane groups, 32 banks -- are conflict-free too; with the stride of 10 rows 2g and 2g + 1 overlapped in four banks: every one of
+// the four stores per factor stage took 8 LDS cycles instead of 4 (40 % of the headline kernel's SQ_LDS_BANK_CONFLICT, round 6).
+#define MROWS(r) (8 * (r) + 2 * ((r) >> 1))
 
 // The workgroup is a single wavefront and the LDS executes one wave's DS instructions in issue order, so cross-lane
 // exchange through LDS needs no s_barrier and no wait for the write to retire: only the compiler must not move memory
@@ -383,8 +388,14 @@ template <> struct polish_limits<double> {
   // N = 80) and 2e-5 (learning, N = 60) from the dense optimum; an attempt accepted at 1e-5 with that rate is itself 1e-6 off.
   // Measured on the serial twin against the dense optimum over the bench distributions (scratch/r5/cmp_cache.py): worst 2e-7
   // at every horizon, mean iterations -0.3 %, the slowest problem of the N = 20 batch 18 -> 14 iterations.
+  // Round 6: up to SIX steps.  The fused factorisation (riccati_factor<.., FUSE>) changes the last bits of every sweep, and one problem of
+  // tests/dispatch_sweep.py's 323 584 (BARC tracking, N = 51) fell on the other side of the limit: its exit attempt's steps go 2.1e-5,
+  // 5.9e-6, 1.9e-6, 2.2e-7 on the twin (accepted) and ended just above step_tol in the kernel -- refused, and the interior point's own
+  // iterate (mu 5e-12, a degenerate problem: 3.4e-6 from the twin in dU) stood with status OPTIMAL.  A consistent set whose steps are
+  // still CONVERGING is not a reason to give the optimum up: two more steps cost two sweeps on the few problems that need them (the
+  // loop leaves after any step <= step_ok) and nothing on the others.
   static constexpr double theta = 1e8, feas = 1e-9, dual = 1e-7, mu_early = 1e-8, rd_early = 1e-6, step_ok = 1e-7, step_tol = 1e-6;
-  static constexpr int rounds = 4, steps = 4;
+  static constexpr int rounds = 4, steps = 6;
 };
 template <> struct polish_limits<float> {
   // theta: 1e7 needs the stabilised factor and the fp64 2x2 pivot; with 1e5 chains of held input rows (u_i = u_{i-1} + t v_i,
@@ -402,6 +413,11 @@ __device__ __forceinline__ float slot_inv_scale(int sl) {
 }
 #define POLISH_THETA_L 1e8  // the simplex rows (always fp64)
 #define POLISH_STRONG 1e3   // a row with lam >= POLISH_STRONG t is one the interior point holds firmly
+#define POLISH_EXIT 256         // flag in PolishArgs::max_rounds: the attempt at the interior point's exit
+#ifndef POLISH_EXIT_GAMMA
+#define POLISH_EXIT_GAMMA 1e-2
+#endif
+// ... holds a row from lam > 1e-2 t on (early and warm attempts: lam > t)
 #define WARM_ROUNDS 2       // repairs a warm start may spend before the cold start takes over
 static_assert(polish_limits<double>::rounds == LMPC_WARM_ROUNDS_MAX, "lmpc_set_warm_rounds' upper limit is the polish's");
 #define WARM_ACT 1e-9       // a box row of the plan counts as active within this slack (a polished plan sits on its bounds to ~1e-16)
@@ -903,6 +919,34 @@ __device__ __forceinline__ real qz_entry(const real* ct, bool terminal, int r, i
 // with a per-site mask, profiles/r04_d70_bisect.md.)
 #define FRESH_LANE(l, site) do { if (L.fresh) asm volatile("" : "+v"(l)); } while (0)
 
+// Lane K of every 16-lane row to the whole row (DPP row_newbcast, gfx90a+; v_mov_b64_dpp for doubles): a register-to-
+// register broadcast.  bound_ctrl:1 with full row / bank masks tells the compiler that the tied "old" operand is never
+// read, so it is not materialised (with bound_ctrl:0 every broadcast costs a v_mov of a constant first -- a fifth of the
+// sweeps' VALU instructions).  (An inline-asm form of the same instructions measured the same speed and was NOT safe: in
+// the most register-starved instantiation, KQ = 14 with KS = 3, it gave wrong and run-to-run different results that wider
+// wait states did not cure, while this builtin form is bitwise reproducible there -- the compiler has to see DPP.)
+template <int K>
+__device__ __forceinline__ double row_bcast(double v) { return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + K, 0xf, 0xf, true); }
+template <int K>
+__device__ __forceinline__ float row_bcast(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150 + K, 0xf, 0xf, true));
+}
+template <typename real>
+__device__ __forceinline__ void row_bcast6(real v, real (&o)[6]) {
+  o[0] = row_bcast<0>(v); o[1] = row_bcast<1>(v); o[2] = row_bcast<2>(v);
+  o[3] = row_bcast<3>(v); o[4] = row_bcast<4>(v); o[5] = row_bcast<5>(v);
+}
+template <typename real>
+__device__ __forceinline__ void row_bcast8(real v, real (&o)[8]) {
+  o[0] = row_bcast<0>(v); o[1] = row_bcast<1>(v); o[2] = row_bcast<2>(v); o[3] = row_bcast<3>(v);
+  o[4] = row_bcast<4>(v); o[5] = row_bcast<5>(v); o[6] = row_bcast<6>(v); o[7] = row_bcast<7>(v);
+}
+template <typename real>
+__device__ __forceinline__ void row_bcast67(real v, real& a, real& b) {  // lanes 6 and 7
+  a = row_bcast<6>(v);
+  b = row_bcast<7>(v);
+}
+
 // Backward Riccati sweep for the barrier weights currently in the knots' rhs0 region
 // (Thz @ +10..17, Thv @ +18,19, boundary weight @ KN_EY).  Leaves K (columns 6,7 of M) and Hinv in
 // the stage records.
@@ -919,8 +963,19 @@ __device__ __forceinline__ real qz_entry(const real* ct, bool terminal, int r, i
 // cancellation happens inside Phi, before the multiplication by P.  It costs a second pair of 8x8 products (8-term,
 // Phi has no identity block), so the iteration uses it only once mu <= JOSEPH_MU: about two factorisations per solve.
 #define JOSEPH_MU 1e-8
-template <bool HAS_PT, bool JOSEPH, typename real, typename ptreal>
-__device__ __forceinline__ void riccati_factor(const Lds<real>& L, int lane, const ptreal* PT) {
+//
+// FUSE (round 6): the factorisation carries the BACKWARD sweep of the predictor's two right-hand sides along.  Both recursions run
+// from the last knot to the first, the sweep's stage i needs nothing but what the factor's stage i holds in registers at its end --
+// K_i[:, c], H_i^-1, dt_i, column c of [A B]_i (lane (r, c) of the factor IS lane (s, c) of the sweep: s = DPP row parity) -- and the
+// right-hand side, and its ~30 instructions sit in the shadows of the factor's LDS exchanges: an iteration is four dependent chains
+// over the horizon instead of five.  The right-hand side must then exist BEFORE the factorisation: the iteration assembles the
+// predictor's gradient first (it depends on the iterate only) into the rhs0 cells, and the barrier weights the factor reads move
+// to the rhs1 cells (`th_off` = KN_R1, the boundary row's weight to `tey_off` = KN_TEY) -- the Schur vector that used to sit there
+// is one number per knot (c_sigma on e_y: KN_CSIG), generated on the fly.  The arithmetic of either recursion is the unfused one's,
+// operation for operation.  riccati_solve<2, true> then runs the forward half only.
+#define KN_TEY 35  // (the knot record's spare cell)
+template <bool HAS_PT, bool JOSEPH, bool FUSE = false, typename real, typename ptreal>
+__device__ __forceinline__ void riccati_factor(const Lds<real>& L, int lane, const ptreal* PT, const int th_off = KN_R0, const int tey_off = KN_EY) {
   FRESH_LANE(lane, 0);
   CHAIN_PRIO_ENTER();
   const int N = L.N, r = lane >> 3, c = lane & 7;
@@ -938,26 +993,34 @@ __device__ __forceinline__ void riccati_factor(const Lds<real>& L, int lane, con
   {
     const real* kn = L.kn(N - 1);
     real e = qz_entry(ct, true, r, c);
-    const real th = kn[KN_R0 + r] + (r == 1 ? kn[KN_EY] : real(0));
+    const real th = kn[th_off + r] + (r == 1 ? kn[tey_off] : real(0));
     if (diag) e += th;
     // LMPC: safe-set block condensed onto x_T; its upper triangle is the block (see the symmetry note in the loop)
     if (HAS_PT && r < 6 && c < 6) e += real(PT[r <= c ? r * 6 + c : c * 6 + r]);
     pown = e;
-    MP[r * MROW + c] = e;
+    MP[MROWS(r) + c] = e;
   }
+  // fused backward sweep: lane (s, c), s = parity of the DPP row; rhs0 = the knots' rhs0 cells, rhs1 = c_sigma e_y (knots >= 1)
+  const int fs = (lane >> 4) & 1;
+  const bool f_own = FUSE && (lane & 8) == 0 && lane < 32 && c < 2;
+  const int f_oq = fs == 0 ? KN_R0 + c : KN_CSIG;                       // where the sweep's q_z comes from ...
+  const real f_mq = (fs == 0 || c == 1) ? real(1) : real(0);            // ... and whether it counts
+  const real f_m6 = (c >= 6) ? real(1) : real(0);
+  real fp = 0.0, fws = 0.0, fw6 = 0.0, fw7 = 0.0, fqz = 0.0, fqv0 = 0.0, fqv1 = 0.0;
+  if constexpr (FUSE) fp = f_mq * L.kn(N - 1)[f_oq];
   // The upper triangle (lanes r <= c) is the cost-to-go; those lanes store their element at (r, c) AND (c, r), the others
   // store to a dead cell.  Why: the two computed halves differ by rounding, and that antisymmetric part is not contracted by
   // the recursion -- it is multiplied by Abar'(.)Abar, the OPEN-loop dynamics, whose RK4 map has |eig| up to ~15-25 below
   // 1 m/s, so within twenty stages it reaches 1e17 and the Newton directions are noise (every low-speed cold start at
   // N >= 40 was lost to this).  An exactly symmetric P only carries symmetric error, which the closed loop damps.
   const bool upper = r <= c;
-  real* const p_dst0 = upper ? MP + r * MROW + c : MW + r * MROW + c;
-  real* const p_dst1 = upper ? MP + c * MROW + r : MW + r * MROW + c;
+  real* const p_dst0 = upper ? MP + MROWS(r) + c : MW + MROWS(r) + c;
+  real* const p_dst1 = upper ? MP + MROWS(c) + r : MW + MROWS(r) + c;
   // where this lane's share of the stage results goes: lanes 0..15 K_j[c] (j = r), 16..18 Hinv, the
   // rest to their own (dead) W cell
   const int res_off = lane < 16 ? ST_ROW(c) + 6 + r : (lane == 18 ? ST_HI11 : ST_HI + (lane - 16));
   const bool res_on = lane < 19;
-  real* const res_junk = MW + r * MROW + c;
+  real* const res_junk = MW + MROWS(r) + c;
   // phase-1/2 operands of stage N-2 (later stages: fetched during phase 3 of the stage before)
   real ar[6], ac[6];
   {
@@ -971,35 +1034,57 @@ __device__ __forceinline__ void riccati_factor(const Lds<real>& L, int lane, con
   // the input-rate weights are the same at every stage: scalar registers, not an LDS read per stage
   const real sv00 = uni(ct[CT_SV + 0]), sv01 = uni(ct[CT_SV + 1]), sv11 = uni(ct[CT_SV + 3]);
   wave_sync();
+  real pr[6];
+  if constexpr (FUSE) {  // (fused: the P row of a stage is requested at the end of the stage before, ahead of the sweep's share of it)
+#pragma unroll
+    for (int k = 0; k < 6; ++k) pr[k] = MP[MROWS(c) + k];
+    pown = MP[MROWS(r) + c];
+    ISSUE_ORDER();
+  }
   for (int i = N - 2; i >= 0; --i) {
     real* st = L.st(i);
     const real* kn = L.kn(i);
     // W = Abar' P : W[r][c] = sum_k Abar[k][r] P[k][c]  (+ P[r][c] for the u rows); P[k][c] read as P[c][k]
-    real pr[6];
+    if constexpr (!FUSE) {
 #pragma unroll
-    for (int k = 0; k < 6; ++k) pr[k] = MP[c * MROW + k];
-    pown = MP[r * MROW + c];  // the symmetrised element (lanes below the diagonal did not compute it)
-    ISSUE_ORDER();
+      for (int k = 0; k < 6; ++k) pr[k] = MP[MROWS(c) + k];
+      pown = MP[MROWS(r) + c];  // the symmetrised element (lanes below the diagonal did not compute it)
+      ISSUE_ORDER();
+    }
     // phase-3 operands of this stage, queued behind the P row
-    const real t = st[ST_DT], thr = kn[KN_R0 + r], ey = kn[KN_EY], thv0 = kn[KN_R0 + 8], thv1 = kn[KN_R0 + 9];
+    const real t = st[ST_DT], thr = kn[th_off + r], ey = kn[tey_off], thv0 = kn[th_off + 8], thv1 = kn[th_off + 9];
+    if constexpr (FUSE) {
+      fqz = kn[f_oq];
+      fqv0 = kn[KN_R0 + 8];
+      fqv1 = kn[KN_R0 + 9];
+    }
     ISSUE_ORDER();
     real w = m_r6 * pown;
 #pragma unroll
     for (int k = 0; k < 6; ++k) w += ar[k] * pr[k];
-    MW[r * MROW + c] = w;
+    MW[MROWS(r) + c] = w;
     wave_sync();
     // Y = W Abar
     real wr[6];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) wr[k] = MW[r * MROW + k];
+    for (int k = 0; k < 6; ++k) wr[k] = MW[MROWS(r) + k];
+    if constexpr (FUSE) {  // the sweep's w = Abar' p (+ p_u on the input rows), while the W row is on its way; ac = [A B](:, c)
+      ISSUE_ORDER();
+      real pb[6];
+      row_bcast6(fp, pb);
+      fws = f_m6 * fp;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) fws = rfma(ac[k], pb[k], fws);
+      row_bcast67(fws, fw6, fw7);
+    }
     real y = m_c6 * w;
 #pragma unroll
     for (int k = 0; k < 6; ++k) y += wr[k] * ac[k];
-    MY[r * MROW + c] = y;
+    MY[MROWS(r) + c] = y;
     wave_sync();
     // H = Sv + Thv + t^2 Y_uu, K = H^-1 t Y[6:8,:], P <- Qz + Thz + Y - t^2 Y[6:8,r]' H^-1 Y[6:8,c]
-    const real y6r = MY[6 * MROW + r], y7r = MY[7 * MROW + r];
-    const real y6c = MY[6 * MROW + c], y7c = MY[7 * MROW + c];
+    const real y6r = MY[MROWS(6) + r], y7r = MY[MROWS(7) + r];
+    const real y6c = MY[MROWS(6) + c], y7c = MY[MROWS(7) + c];
     AFTER_VALUE(y);
     if constexpr (!JOSEPH) {  // phase-1/2 operands of the next stage (their registers are dead by now), queued behind the Y rows
       const real* stn = L.st(i > 0 ? i - 1 : 0);
@@ -1055,18 +1140,18 @@ __device__ __forceinline__ void riccati_factor(const Lds<real>& L, int lane, con
       {
         real pc[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) pc[k] = MP[c * MROW + k];
+        for (int k = 0; k < 8; ++k) pc[k] = MP[MROWS(c) + k];
 #pragma unroll
         for (int k = 0; k < 6; ++k) w2 += ar[k] * pc[k];
         w2 += fr6 * pc[6] + fr7 * pc[7];
       }
-      MW[r * MROW + c] = w2;
+      MW[MROWS(r) + c] = w2;
       wave_sync();
       real y2 = 0.0;
       {
         real w2r[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) w2r[k] = MW[r * MROW + k];
+        for (int k = 0; k < 8; ++k) w2r[k] = MW[MROWS(r) + k];
 #pragma unroll
         for (int k = 0; k < 6; ++k) y2 += w2r[k] * ac[k];
         y2 += w2r[6] * fc6 + w2r[7] * fc7;
@@ -1091,36 +1176,25 @@ __device__ __forceinline__ void riccati_factor(const Lds<real>& L, int lane, con
     const real res = lane < 8 ? k0c : (lane < 16 ? k1c : (lane == 16 ? hi00 : (lane == 17 ? hi01 : hi11)));
     *(res_on ? st + res_off : res_junk) = res;
     wave_sync();
+    if constexpr (FUSE) {
+      if (i > 0) {  // the next stage's P row, behind the stores above
+#pragma unroll
+        for (int k = 0; k < 6; ++k) pr[k] = MP[MROWS(c) + k];
+        pown = MP[MROWS(r) + c];
+      }
+      ISSUE_ORDER();
+      // the sweep's stage i: p_i = q_i + Abar' p_{i+1} - K' (q_v + Bbar' p_{i+1}),  kff_i = H^-1 (q_v + Bbar' p_{i+1})
+      const real qv0 = fs == 0 ? fqv0 : real(0), qv1 = fs == 0 ? fqv1 : real(0);
+      const real hv0 = rfma(t, fw6, qv0);
+      const real hv1 = rfma(t, fw7, qv1);
+      fp = f_mq * fqz + fws - (k0c * hv0 + k1c * hv1);
+      const real ha = c == 0 ? hi00 : hi01, hb = c == 0 ? hi01 : hi11;
+      const real kff = ha * hv0 + hb * hv1;
+      *(f_own ? st + ST_KFF(fs) + c : res_junk) = kff;
+    }
   }
+  if constexpr (FUSE) wave_sync();
   CHAIN_PRIO_LEAVE();
-}
-
-// Lane K of every 16-lane row to the whole row (DPP row_newbcast, gfx90a+; v_mov_b64_dpp for doubles): a register-to-
-// register broadcast.  bound_ctrl:1 with full row / bank masks tells the compiler that the tied "old" operand is never
-// read, so it is not materialised (with bound_ctrl:0 every broadcast costs a v_mov of a constant first -- a fifth of the
-// sweeps' VALU instructions).  (An inline-asm form of the same instructions measured the same speed and was NOT safe: in
-// the most register-starved instantiation, KQ = 14 with KS = 3, it gave wrong and run-to-run different results that wider
-// wait states did not cure, while this builtin form is bitwise reproducible there -- the compiler has to see DPP.)
-template <int K>
-__device__ __forceinline__ double row_bcast(double v) { return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + K, 0xf, 0xf, true); }
-template <int K>
-__device__ __forceinline__ float row_bcast(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150 + K, 0xf, 0xf, true));
-}
-template <typename real>
-__device__ __forceinline__ void row_bcast6(real v, real (&o)[6]) {
-  o[0] = row_bcast<0>(v); o[1] = row_bcast<1>(v); o[2] = row_bcast<2>(v);
-  o[3] = row_bcast<3>(v); o[4] = row_bcast<4>(v); o[5] = row_bcast<5>(v);
-}
-template <typename real>
-__device__ __forceinline__ void row_bcast8(real v, real (&o)[8]) {
-  o[0] = row_bcast<0>(v); o[1] = row_bcast<1>(v); o[2] = row_bcast<2>(v); o[3] = row_bcast<3>(v);
-  o[4] = row_bcast<4>(v); o[5] = row_bcast<5>(v); o[6] = row_bcast<6>(v); o[7] = row_bcast<7>(v);
-}
-template <typename real>
-__device__ __forceinline__ void row_bcast67(real v, real& a, real& b) {  // lanes 6 and 7
-  a = row_bcast<6>(v);
-  b = row_bcast<7>(v);
 }
 
 // Riccati vector solve for NRHS (1 or 2) right-hand sides held in the knots' rhs regions
@@ -1133,7 +1207,7 @@ __device__ __forceinline__ void row_bcast67(real v, real& a, real& b) {  // lane
 // nothing on the chain goes through LDS (it did until round 2: one write + broadcast reads per stage, and a ds_swizzle
 // for the condensed 2-vector; ~400 cycles per stage under load).  Stage operands are fetched one stage ahead; the
 // results a stage leaves behind (kff, dz, dv) are stored off the chain.
-template <int NRHS, typename real>
+template <int NRHS, bool FWD_ONLY = false, typename real>  // (FWD_ONLY: the backward half ran inside the factorisation, riccati_factor<.., FUSE>)
 __device__ __forceinline__ void riccati_solve(const Lds<real>& L, int lane, Prof& pf) {
   FRESH_LANE(lane, 2);
   CHAIN_PRIO_ENTER();
@@ -1148,14 +1222,14 @@ __device__ __forceinline__ void riccati_solve(const Lds<real>& L, int lane, Prof
   // kff = H^-1 hv: lane r = 0 takes row (h00, h01), the others row (h01, h11) -- picked by the address, not by a select
   const int o_ha = r == 0 ? ST_HI : ST_HI + 1, o_hb = r == 0 ? ST_HI + 1 : ST_HI11;
   // ---- backward: p_i = q_i + Abar' p_{i+1} - K' (q_v + Bbar' p_{i+1});  kff_i = H^-1 (q_v + Bbar' p_{i+1})
-  real p = L.kn(N - 1)[reg + r];
+  real p = FWD_ONLY ? real(0) : L.kn(N - 1)[reg + r];
   real row[6];  // [A B](:, r), fetched one stage ahead
-  {
+  if constexpr (!FWD_ONLY) {
     const real* st = L.st(N - 2);
 #pragma unroll
     for (int k = 0; k < 6; ++k) row[k] = st[ST_ROW(r) + k];
   }
-  for (int i = N - 2; i >= 0; --i) {
+  for (int i = FWD_ONLY ? -1 : N - 2; i >= 0; --i) {
     real* st = L.st(i);
     const real* kn = L.kn(i);
     const real k0r = st[ST_ROW(r) + 6], k1r = st[ST_ROW(r) + 7], t = st[ST_DT];
@@ -1277,8 +1351,9 @@ __device__ __forceinline__ void feedback_rollout(const Lds<real>& L, int lane) {
 // is fetched and waited for, the one below it is fetched at once; the stage that reads ahead into the next chunk waits for
 // it first and, the chunk just left being dead by then, fetches the one after into its buffer.  Upwards (forward sweep,
 // rollout) the mirror image.  One fetch is in flight at a time; a chunk is 8 stages of work ahead of its first use.
-template <bool HAS_PT, bool JOSEPH, typename real, typename ptreal>
-__device__ __forceinline__ void riccati_factor_lean(const Lds<real>& L, ModelStream<real>& M, int lane, const ptreal* PT) {
+template <bool HAS_PT, bool JOSEPH, bool FUSE = false, typename real, typename ptreal>
+__device__ __forceinline__ void riccati_factor_lean(const Lds<real>& L, ModelStream<real>& M, int lane, const ptreal* PT, const int th_off = KN_R0,
+                                                    const int tey_off = KN_EY) {
   FRESH_LANE(lane, 1);
   const int N = L.N, r = lane >> 3, c = lane & 7;
   real* T = L.tail();
@@ -1296,20 +1371,28 @@ __device__ __forceinline__ void riccati_factor_lean(const Lds<real>& L, ModelStr
     M.ensure(ch);
     const real* kn = L.kn(N - 1);
     real e = qz_entry(ct, true, r, c);
-    const real th = kn[KN_R0 + r] + (r == 1 ? kn[KN_EY] : real(0));
+    const real th = kn[th_off + r] + (r == 1 ? kn[tey_off] : real(0));
     if (diag) e += th;
     if (HAS_PT && r < 6 && c < 6) e += real(PT[r <= c ? r * 6 + c : c * 6 + r]);
     pown = e;
-    MP[r * MROW + c] = e;
+    MP[MROWS(r) + c] = e;
     M.wait();
     if (ch > 0) M.ensure(ch - 1);
   }
+  // fused backward sweep of the predictor's right-hand sides (see riccati_factor)
+  const int fs = (lane >> 4) & 1;
+  const bool f_own = FUSE && (lane & 8) == 0 && lane < 32 && c < 2;
+  const int f_oq = fs == 0 ? KN_R0 + c : KN_CSIG;
+  const real f_mq = (fs == 0 || c == 1) ? real(1) : real(0);
+  const real f_m6 = (c >= 6) ? real(1) : real(0);
+  real fp = 0.0, fws = 0.0, fw6 = 0.0, fw7 = 0.0, fqz = 0.0, fqv0 = 0.0, fqv1 = 0.0;
+  if constexpr (FUSE) fp = f_mq * L.kn(N - 1)[f_oq];
   const bool upper = r <= c;
-  real* const p_dst0 = upper ? MP + r * MROW + c : MW + r * MROW + c;
-  real* const p_dst1 = upper ? MP + c * MROW + r : MW + r * MROW + c;
+  real* const p_dst0 = upper ? MP + MROWS(r) + c : MW + MROWS(r) + c;
+  real* const p_dst1 = upper ? MP + MROWS(c) + r : MW + MROWS(r) + c;
   const int res_off = lane < 16 ? 2 * c + r : (lane == 18 ? LN_HI11 : LN_HI + (lane - 16));
   const bool res_on = lane < 19;
-  real* const res_junk = MW + r * MROW + c;
+  real* const res_junk = MW + MROWS(r) + c;
   real ar[6], ac[6];
   {
     const real* ab = M.stage(N - 2);
@@ -1321,33 +1404,55 @@ __device__ __forceinline__ void riccati_factor_lean(const Lds<real>& L, ModelStr
   }
   const real sv00 = uni(ct[CT_SV + 0]), sv01 = uni(ct[CT_SV + 1]), sv11 = uni(ct[CT_SV + 3]);
   wave_sync();
+  real pr[6];
+  if constexpr (FUSE) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) pr[k] = MP[MROWS(c) + k];
+    pown = MP[MROWS(r) + c];
+    ISSUE_ORDER();
+  }
   for (int i = N - 2; i >= 0; --i) {
     real* st = L.st(i);
     const real* kn = L.kn(i);
     const real* ab = M.stage(i);
     const bool cross = (i % LN_CHUNK) == 0 && i > 0;  // the read-ahead of this stage is the first read of the chunk below
-    real pr[6];
+    if constexpr (!FUSE) {
 #pragma unroll
-    for (int k = 0; k < 6; ++k) pr[k] = MP[c * MROW + k];
-    pown = MP[r * MROW + c];
-    ISSUE_ORDER();
-    const real t = st[LN_DT], thr = kn[KN_R0 + r], ey = kn[KN_EY], thv0 = kn[KN_R0 + 8], thv1 = kn[KN_R0 + 9];
+      for (int k = 0; k < 6; ++k) pr[k] = MP[MROWS(c) + k];
+      pown = MP[MROWS(r) + c];
+      ISSUE_ORDER();
+    }
+    const real t = st[LN_DT], thr = kn[th_off + r], ey = kn[tey_off], thv0 = kn[th_off + 8], thv1 = kn[th_off + 9];
+    if constexpr (FUSE) {
+      fqz = kn[f_oq];
+      fqv0 = kn[KN_R0 + 8];
+      fqv1 = kn[KN_R0 + 9];
+    }
     ISSUE_ORDER();
     real w = m_r6 * pown;
 #pragma unroll
     for (int k = 0; k < 6; ++k) w += ar[k] * pr[k];
-    MW[r * MROW + c] = w;
+    MW[MROWS(r) + c] = w;
     wave_sync();
     real wr[6];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) wr[k] = MW[r * MROW + k];
+    for (int k = 0; k < 6; ++k) wr[k] = MW[MROWS(r) + k];
+    if constexpr (FUSE) {
+      ISSUE_ORDER();
+      real pb[6];
+      row_bcast6(fp, pb);
+      fws = f_m6 * fp;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) fws = rfma(ac[k], pb[k], fws);
+      row_bcast67(fws, fw6, fw7);
+    }
     real y = m_c6 * w;
 #pragma unroll
     for (int k = 0; k < 6; ++k) y += wr[k] * ac[k];
-    MY[r * MROW + c] = y;
+    MY[MROWS(r) + c] = y;
     wave_sync();
-    const real y6r = MY[6 * MROW + r], y7r = MY[7 * MROW + r];
-    const real y6c = MY[6 * MROW + c], y7c = MY[7 * MROW + c];
+    const real y6r = MY[MROWS(6) + r], y7r = MY[MROWS(7) + r];
+    const real y6c = MY[MROWS(6) + c], y7c = MY[MROWS(7) + c];
     AFTER_VALUE(y);
     if constexpr (!JOSEPH) {
       if (cross) M.wait();
@@ -1397,18 +1502,18 @@ __device__ __forceinline__ void riccati_factor_lean(const Lds<real>& L, ModelStr
       {
         real pc[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) pc[k] = MP[c * MROW + k];
+        for (int k = 0; k < 8; ++k) pc[k] = MP[MROWS(c) + k];
 #pragma unroll
         for (int k = 0; k < 6; ++k) w2 += ar[k] * pc[k];
         w2 += fr6 * pc[6] + fr7 * pc[7];
       }
-      MW[r * MROW + c] = w2;
+      MW[MROWS(r) + c] = w2;
       wave_sync();
       real y2 = 0.0;
       {
         real w2r[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) w2r[k] = MW[r * MROW + k];
+        for (int k = 0; k < 8; ++k) w2r[k] = MW[MROWS(r) + k];
 #pragma unroll
         for (int k = 0; k < 6; ++k) y2 += w2r[k] * ac[k];
         y2 += w2r[6] * fc6 + w2r[7] * fc7;
@@ -1438,10 +1543,27 @@ __device__ __forceinline__ void riccati_factor_lean(const Lds<real>& L, ModelStr
     const real res = lane < 8 ? k0c : (lane < 16 ? k1c : (lane == 16 ? hi00 : (lane == 17 ? hi01 : hi11)));
     *(res_on ? st + res_off : res_junk) = res;
     wave_sync();
+    if constexpr (FUSE) {
+      if (i > 0) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) pr[k] = MP[MROWS(c) + k];
+        pown = MP[MROWS(r) + c];
+      }
+      ISSUE_ORDER();
+      const real qv0 = fs == 0 ? fqv0 : real(0), qv1 = fs == 0 ? fqv1 : real(0);
+      const real hv0 = rfma(t, fw6, qv0);
+      const real hv1 = rfma(t, fw7, qv1);
+      fp = f_mq * fqz + fws - (k0c * hv0 + k1c * hv1);
+      const real ha = c == 0 ? hi00 : hi01, hb = c == 0 ? hi01 : hi11;
+      const real kff = ha * hv0 + hb * hv1;
+      *(f_own ? st + LN_KFF(fs) + c : res_junk) = kff;
+    }
   }
-  // what follows is a vector solve, whose backward sweep starts at the top again: its first chunks are on their way while
-  // the gradient is assembled (both buffers are free: the factor is done with them)
-  if ((N - 2) / LN_CHUNK >= 2) {
+  if constexpr (FUSE) {
+    wave_sync();  // (what follows is the forward half of the solve: chunks 0 and 1 are what the factor ended on)
+  } else if ((N - 2) / LN_CHUNK >= 2) {
+    // what follows is a vector solve, whose backward sweep starts at the top again: its first chunks are on their way while
+    // the gradient is assembled (both buffers are free: the factor is done with them)
     M.fetch((N - 2) / LN_CHUNK);
     M.fetch((N - 2) / LN_CHUNK - 1);
   }
@@ -1451,7 +1573,7 @@ __device__ __forceinline__ void riccati_factor_lean(const Lds<real>& L, ModelStr
 // trip per stage: at one wave per SIMD a sweep stage costs what its instruction count costs (~4.5 cycles each, nothing to
 // overlap with), and the exchange through LDS was a third of the lean stage's instructions (the LDS-exchange form of rounds 2-3,
 // bit for bit the same results, is scratch/r5/experiment_switches.patch); lane (s, r) = ((lane >> 4) % NRHS, lane & 7), lanes 8..15 of a row mirror 0..7.
-template <int NRHS, typename real>
+template <int NRHS, bool FWD_ONLY = false, typename real>
 __device__ __forceinline__ void riccati_solve_lean_dpp(const Lds<real>& L, ModelStream<real>& M, int lane, Prof& pf) {
   FRESH_LANE(lane, 5);
   const int N = L.N;
@@ -1464,20 +1586,20 @@ __device__ __forceinline__ void riccati_solve_lean_dpp(const Lds<real>& L, Model
   const real m6 = (r >= 6) ? real(1) : real(0);
   const int o_ha = r == 0 ? LN_HI : LN_HI + 1, o_hb = r == 0 ? LN_HI + 1 : LN_HI11;
   // ---- backward
-  {
+  if constexpr (!FWD_ONLY) {
     const int ch = (N - 2) / LN_CHUNK;
     M.ensure(ch);
     M.wait();
     if (ch > 0) M.ensure(ch - 1);
   }
-  real p = L.kn(N - 1)[reg + r];
+  real p = FWD_ONLY ? real(0) : L.kn(N - 1)[reg + r];
   real row[6];
-  {
+  if constexpr (!FWD_ONLY) {
     const real* ab = M.stage(N - 2);
 #pragma unroll
     for (int k = 0; k < 6; ++k) row[k] = ab[6 * r + k];
   }
-  for (int i = N - 2; i >= 0; --i) {
+  for (int i = FWD_ONLY ? -1 : N - 2; i >= 0; --i) {
     real* st = L.st(i);
     const real* kn = L.kn(i);
     if ((i % LN_CHUNK) == 0 && i > 0) {  // (chunk boundary: the next chunk must have landed)
@@ -1748,9 +1870,14 @@ __device__ __forceinline__ PolishResult<real, KS> lmpc_polish(const PolishArgs<r
       if (i >= 1 || o >= 8) L.kn(i)[o] = real(keep[e]);
     }
   };
+  // (bit 8 of max_rounds: the attempt at the interior point's EXIT, fp64: in doubt -- lam ~ t, a weakly active row -- a row is held,
+  //  from lam > 1e-2 t on; held wrongly it comes out with a negative multiplier and the next round releases it, free wrongly it is
+  //  violated, drags its neighbours' multipliers below zero and the repairs release THEM.  oracle/c/lmpc_oracle.c, POLISH_EXIT, has
+  //  the problem this was found on.)
+  const real gam = (sizeof(real) == 8 && (uni(a.max_rounds) & POLISH_EXIT)) ? real(POLISH_EXIT_GAMMA) : real(1);
   int held = 0;  // (per lane) bit 2q / 2q + 1: upper / lower row of slot q held; bit 28 + q: simplex row q held
 #pragma unroll
-  for (int q = 0; q < KQ; ++q) held |= (s_lu[q] > s_tu[q] ? 1 << (2 * q) : 0) | (s_ll[q] > s_tl[q] ? 2 << (2 * q) : 0);
+  for (int q = 0; q < KQ; ++q) held |= (s_lu[q] > gam * s_tu[q] ? 1 << (2 * q) : 0) | (s_ll[q] > gam * s_tl[q] ? 2 << (2 * q) : 0);
   if constexpr (KS > 0) {
 #pragma unroll
     for (int q = 0; q < KS; ++q) {
@@ -1761,7 +1888,7 @@ __device__ __forceinline__ PolishResult<real, KS> lmpc_polish(const PolishArgs<r
   const real sigma_keep = sigma;
   put_keep();
   bool accepted = false, noise = false;
-  const int max_rounds = min((int)pol::rounds, uni(a.max_rounds));
+  const int max_rounds = min((int)pol::rounds, uni(a.max_rounds) & ~POLISH_EXIT);
   for (int round = 0; round < max_rounds; ++round) {
     if (round > 0) {  // every round starts from the interior point's iterate
       wave_sync();
@@ -2108,6 +2235,9 @@ __device__ __forceinline__ PolishResult<real, KS> lmpc_polish(const PolishArgs<r
         }
         wave_fence();
       }
+#ifdef LMPC_POLISH_TRACE
+      if (blockIdx.x == 0 && lane == 0) printf("      step %d: %.3e\n", k, (double)last_step);
+#endif
       if (k >= 1 && last_step <= real(pol::step_ok)) break;  // (converged: the remaining steps would move nothing)
     }
     // ---- KKT test of the point reached; repair of the held set ----
@@ -2153,6 +2283,14 @@ __device__ __forceinline__ PolishResult<real, KS> lmpc_polish(const PolishArgs<r
     const bool anybad = nan_step || !(last_step <= real(pol::step_tol)) || __ballot(bad) != 0;
     const bool anyneg = __ballot(neg) != 0, anyweak = __ballot(weakneg) != 0;
     const bool anyviol = __ballot(viol) != 0;
+#ifdef LMPC_POLISH_TRACE  // (diagnostics: workgroup 0 prints what each round's KKT test saw)
+    {
+      const real tr_held = wave_sum(real(__popc(held & 0x0fffffff))), tr_ymin = wave_min(ymin), tr_worst = wave_max(worst);
+      if (blockIdx.x == 0 && lane == 0)
+        printf("polish round %d: held %d last_step %.3e bad %d (rows %d nan %d) neg %d weak %d viol %d ymin %.3e worst %.3e\n", pol_rounds, (int)tr_held,
+               (double)last_step, (int)anybad, (int)(__ballot(bad) != 0), (int)nan_step, (int)anyneg, (int)anyweak, (int)anyviol, (double)tr_ymin, (double)tr_worst);
+    }
+#endif
     if (!anybad && !anyneg && !anyviol) {  // the optimum for the held set, and the held set passes the KKT test
       mu = uni(wave_sum(comp) * inv_m);
       rdmax = wave_max(worst);
@@ -2236,6 +2374,32 @@ __host__ __device__ constexpr int lmpc_row_chunk(int real_bytes, int kq, int ks)
 }
 __host__ __device__ constexpr bool lmpc_opaque_slots(int real_bytes, int kq, int ks) { return (real_bytes == 8 && kq >= 11) || ks > 0; }
 __host__ __device__ constexpr int lmpc_opaque_sites(int real_bytes, int kq, int ks) { return (real_bytes == 8 && kq <= 4 && ks == 0) ? 15 : 0; }
+// the predictor's backward sweep fused into the factorisation (riccati_factor<.., FUSE>): per instantiation, by measurement
+// (MI355X, 4096 problems, kernel ms five chains -> four; profiles/r06_fuse_ab.txt):
+//   fp64 tracking  N = 20 0.859 -> 0.835, N = 24 1.639 -> 1.565, N = 40 2.461 -> 2.351, N = 60 5.368 -> 4.957, IAC N = 40 4.322 -> 4.052
+//   fp64 learning  N = 20 / 160 points 2.072 -> 2.028 (on); N = 40 5.388 -> 5.646 (off: KQ >= 7 with KS > 0 is the most register-starved family)
+//   fp32 / mixed   IAC N = 40 3.275 -> 3.203 / 6.091 -> 5.850 (on); learning N = 20 mixed 3.385 -> 3.239, but OFF: which ill-conditioned blends
+//                  of safe-set points pass the fp32 KKT test 1e-3 .. 5e-3 from the fp64 answer is decided by the last bits of the fp32
+//                  sweeps -- 3 of configs[4]'s 32768 before, 5 fused (tests/test_gpu_spec_workload.py holds the 99.99 % quantile to 1e-3);
+//                  tracking N <= 23 (KQ <= 4, three waves per SIMD): OFF -- the <float, 4, 0, double> instance of the fused build
+//                  took a memory access fault in the mixed entry (the polish's flat store of the iterate to the save area with a
+//                  clobbered address register; the fp32-array instance of the same source is fine): another of the
+//                  compiler-sensitive corners of DESIGN.md section 4, found by tests/dispatch_sweep.py on its first run.
+//   fp64 tracking N <= 23 (KQ <= 4, two waves per SIMD): OFF as well.  It gained 2.7 % (0.859 -> 0.835 ms) and passed every test -- until an
+//                  unrelated edit of the polish (a multiplier in its classification) changed the register allocation: the fused
+//                  <double, 4, 0, double> then returned garbage statuses in a pattern that follows the workgroup's XCD (same source with a
+//                  printf compiled in: correct) -- the family of failure of round 4's bisect (profiles/r04_d70_bisect.md): DPP row
+//                  broadcasts next to spilled registers at 256 VGPRs.  The one-wave-per-SIMD kernels and the two-wave-per-problem kernels
+//                  have the registers, and that is where the chain saved is worth 5 .. 18 %.
+#ifndef LMPC_FUSE_MASK
+#define LMPC_FUSE_MASK 0x56
+#endif
+__host__ __device__ constexpr bool lmpc_fuse_bwd(int real_bytes, int kq, int ks) {
+  // bit 0: fp64 tracking KQ <= 4 (two waves per SIMD), 1: fp64 tracking KQ = 7, 2: fp64 tracking lean (KQ >= 11), 3: fp64 learning KQ >= 7,
+  // 4: fp32 / mixed tracking KQ >= 7, 5: fp32 / mixed tracking KQ <= 4, 6: fp64 learning KQ <= 4, 7: fp32 / mixed learning
+  return real_bytes == 8 ? (ks == 0 ? (kq <= 4 ? (LMPC_FUSE_MASK & 1) : (kq <= 7 ? (LMPC_FUSE_MASK & 2) : (LMPC_FUSE_MASK & 4))) : (kq <= 4 ? (LMPC_FUSE_MASK & 64) : (LMPC_FUSE_MASK & 8))) != 0
+                         : (ks == 0 ? (kq <= 4 ? (LMPC_FUSE_MASK & 32) : (LMPC_FUSE_MASK & 16)) : (LMPC_FUSE_MASK & 128)) != 0;
+}
 
 // SECOND: the fp64 second pass of a mixed solve -- a handful of problems a whole batch waits for, sharing the chip with the next batch's
 // first pass: its waves run at the top issue priority throughout (and do not drop it between chains).
@@ -2262,6 +2426,11 @@ __device__ __forceinline__ void lmpc_solve_problem(
   // state per slot do not fit 512 registers, and what the allocator spills is the row state)
   constexpr int QC = lmpc_row_chunk(sizeof(real), KQ, KS);
   constexpr int SITES = lmpc_opaque_sites(sizeof(real), KQ, KS);
+  // the predictor's backward sweep inside the factorisation (riccati_factor<.., FUSE>): the barrier weights then go to the rhs1 cells
+  // and the predictor's gradient is assembled ahead of the factorisation.  Problems without the shared slack have one right-hand
+  // side and keep the five-chain iteration (no shipped configuration: q_boundary > 0 everywhere).
+  constexpr bool FUSEK = !WARMK && lmpc_fuse_bwd(sizeof(real), KQ, KS);
+  const bool fuse = FUSEK && P.has_sigma != 0;
   Lds<real> L{lds, N, LEAN ? LMPC_LEAN_STAGE_STRIDE : LMPC_STAGE_STRIDE, lmpc_fresh_lane(sizeof(real), KQ, KS),
               !SECOND && lmpc_waves_per_simd(sizeof(real), KQ, KS) >= 2};
   if constexpr (SECOND && LMPC_CHAIN_PRIO) __builtin_amdgcn_s_setprio(3);
@@ -2825,6 +2994,107 @@ __device__ __forceinline__ void lmpc_solve_problem(
                       // 3 out of iterations but close (single precision): a last attempt
   for (; it <= max_iter; ++it) {
     const bool ipm = it >= 0;
+    // ======== gradient: cost gradient + row coefficients, written by the component owner (into the rhs0 cells) ========
+    // (a function of the iterate and of (sigma_c mu, pm) only: with the fused factorisation the predictor's is assembled BEFORE the
+    //  factorisation, which consumes it; the rhs1 cells then hold the barrier weights and are not cleared here)
+    treal eeps[6] = {0, 0, 0, 0, 0, 0};  // E eps of this iterate (safe-set block), in scalar registers
+    auto load_eeps = [&]() {
+      if constexpr (KS > 0) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) eeps[k] = uni(TT[TL_E + k] * TT[TL_EPS + k]);
+      }
+    };
+    real sgsum0 = 0.0;
+    auto gradient = [&](const int pass, const real smu, const real pm) -> real {
+      const bool fused = FUSEK && fuse && ipm;
+      real sgsum = 0.0;
+      if constexpr (KS > 0) {
+        if (ipm) {
+          PT_MARK(12)
+          // right-hand side r_j = -bl_j (dx = 0): sums over the eliminated points, the explicit ones through LDS
+          treal bs[7] = {0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+          for (int q = 0; q < KS; ++q) {
+            treal itf, uq[6];
+            sx.load_u(q, lane, uq);
+            const treal rj = sx.on[q] ? -simplex_bl(sx.lm[q], sx.t[q], sx.l[q], sx.p[q], sx.j[q], uq, treal(smu), treal(pm), eeps, itf) : treal(0);
+            if (sx.aidx[q] >= 0) TT[TL_RA + sx.aidx[q]] = rj;
+            const treal w = (sx.on[q] && sx.aidx[q] < 0) ? rj * itf : treal(0);
+            bs[6] += w;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) bs[k] += uq[k] * w;
+          }
+          wave_sum_split<7>(bs, lane);
+          wave_fence();
+          PT_MARK(13)
+          treal beta[6], h[6], nu;
+#pragma unroll
+          for (int k = 0; k < 6; ++k) beta[k] = bs[k];
+          term_solve_u(TT, lane, sx.m, beta, bs[6], sx.r1, h, nu);
+          PT_MARK(14)
+          if (lane < 6) {  // terminal gradient onto x_T: E eps + pT, pT = -h
+            treal hs = h[0];
+#pragma unroll
+            for (int k = 1; k < 6; ++k) hs = (lane == k) ? h[k] : hs;
+            TT[TL_TG + lane] = TT[TL_E + lane] * TT[TL_EPS + lane] - hs;
+          }
+          wave_fence();
+          PT_MARK(15)
+        }
+      }
+#pragma unroll
+      for (int q0 = 0; q0 < KQ; q0 += QC) {
+        real val[QC], par[QC], ca[QC], cb[QC], ql[QC];
+        real2 hl[QC];
+        SlotRef sr[QC];
+#pragma unroll
+        for (int qq = 0; qq < QC; ++qq) {
+          const int q = q0 + qq;
+          if (q >= KQ) continue;
+          sr[qq] = slot(q);
+          const int gr = sr[qq].gf, ov = sr[qq].ov;
+          val[qq] = lds[ov];
+          hl[qq] = r_bounds(sr[qq]);
+          par[qq] = lds[ov + ((gr >> 16) & 3) - 1];
+          ca[qq] = lds[CTB + (gr & 0xff)];
+          cb[qq] = lds[CTB + ((gr >> 8) & 0xff)];
+          ql[qq] = lds[ov + (KN_QLIN - 3)];
+        }
+#pragma unroll
+        for (int qq = 0; qq < QC; ++qq) {
+          const int q = q0 + qq;
+          if (q >= KQ) continue;
+          const int f = r_flags(sr[qq]);
+          const real sg = (f & F_SIG) ? sigma : 0.0;
+          const real itu = frcp(s_tu[q]), itl = frcp(s_tl[q]);
+          real cu = s_lu[q] * itu * (val[qq] - sg + s_tu[q] - hl[qq].x) + (smu - pm * s_pu[q]) * itu;
+          real cd = s_ll[q] * itl * (-val[qq] - sg + s_tl[q] + hl[qq].y) + (smu - pm * s_pl[q]) * itl;
+          cu = (ipm && (f & F_UP)) ? cu : 0.0;
+          cd = (ipm && (f & F_LO)) ? cd : 0.0;
+          const real g = ca[qq] * val[qq] + cb[qq] * par[qq] + ((f & F_QLIN) ? ql[qq] : real(0));  // (zero coefficients on a boundary slot)
+          lds[r_w(sr[qq])] = g + cu - cd;
+          if (pass == 0 && !fused) {
+            const SlotRef sz = ((SITES & 2) && !lmpc_opaque_slots(sizeof(real), KQ, KS)) ? slot_at(q, 1) : sr[qq];
+            lds[(r_flags(sz) & F_EY) ? JB + KN_EY : r_w(sz) + 10] = 0.0;
+          }
+          sgsum += (f & F_SIG) ? (cu + cd) : real(0);
+        }
+        if constexpr (QC < KQ) ISSUE_ORDER();
+      }
+      wave_sync();
+      PT_MARK(12)
+      for (int i = lane; i < N; i += 64) {
+        real* kn = L.kn(i);
+        kn[KN_R0 + 1] += kn[KN_EY];
+        if (pass == 0 && !fused) kn[KN_R1 + 1] = (i >= 1) ? kn[KN_CSIG] : 0.0;
+      }
+      if constexpr (KS > 0) {  // terminal gradient of the safe-set block onto x_T (lanes 0..5 != EY lanes' cells)
+        wave_sync();
+        if (lane < 6) L.kn(N - 1)[KN_R0 + lane] += real(TT[TL_TG + lane]);
+      }
+      wave_sync();
+      return sgsum;
+    };
     // ======== rows: complementarity, residual, barrier weights ========
     if (ipm) {
       real musum = 0.0, rdl = 0.0, eysum = 0.0;
@@ -2851,7 +3121,7 @@ __device__ __forceinline__ void lmpc_solve_problem(
           musum += s_lu[q] * s_tu[q] + s_ll[q] * s_tl[q];
           rdl = fmax(rdl, (f & F_UP) ? fabs(val[qq] - sg + s_tu[q] - hl[qq].x) : real(0));
           rdl = fmax(rdl, (f & F_LO) ? fabs(-val[qq] - sg + s_tl[q] + hl[qq].y) : real(0));
-          lds[r_w(sr[qq])] = thu + thd;
+          lds[r_w(sr[qq]) + (fuse ? ((f & F_EY) ? KN_TEY - KN_EY : KN_R1 - KN_R0) : 0)] = thu + thd;
           lds[r_csig(((SITES & 1) && !lmpc_opaque_slots(sizeof(real), KQ, KS)) ? slot_at(q, 0) : sr[qq])] = (f & F_SIG) ? (thd - thu) : 0.0;
           eysum += (f & F_SIG) ? (thu + thd) : real(0);
         }
@@ -3024,127 +3294,67 @@ __device__ __forceinline__ void lmpc_solve_problem(
       }
       wave_sync();
       PT_MARK(2)
+      if constexpr (FUSEK) {
+        if (fuse) {
+          load_eeps();
+          sgsum0 = gradient(0, real(0), real(0));
+          PT_MARK(4)
+        }
+      }
       if constexpr (LEAN) {
-        if (mu <= real(JOSEPH_MU))
-          riccati_factor_lean<(KS > 0), true>(L, MS, lane, TT + TL_PT);
+        if (mu <= real(JOSEPH_MU)) {
+          if (FUSEK && fuse)
+            riccati_factor_lean<(KS > 0), true, FUSEK>(L, MS, lane, TT + TL_PT, KN_R1, KN_TEY);
+          else
+            riccati_factor_lean<(KS > 0), true>(L, MS, lane, TT + TL_PT);
+        } else {
+          if (FUSEK && fuse)
+            riccati_factor_lean<(KS > 0), false, FUSEK>(L, MS, lane, TT + TL_PT, KN_R1, KN_TEY);
+          else
+            riccati_factor_lean<(KS > 0), false>(L, MS, lane, TT + TL_PT);
+        }
+      } else if (sizeof(real) == 8 && mu <= real(JOSEPH_MU)) {  // (single precision stops at mu ~ 2e-6)
+        if (FUSEK && fuse)
+          riccati_factor<(KS > 0), (sizeof(real) == 8), FUSEK>(L, lane, TT + TL_PT, KN_R1, KN_TEY);
         else
-          riccati_factor_lean<(KS > 0), false>(L, MS, lane, TT + TL_PT);
-      } else if (sizeof(real) == 8 && mu <= real(JOSEPH_MU))  // (single precision stops at mu ~ 2e-6)
-        riccati_factor<(KS > 0), (sizeof(real) == 8)>(L, lane, TT + TL_PT);
-      else
-        riccati_factor<(KS > 0), false>(L, lane, TT + TL_PT);
+          riccati_factor<(KS > 0), (sizeof(real) == 8)>(L, lane, TT + TL_PT);
+      } else {
+        if (FUSEK && fuse)
+          riccati_factor<(KS > 0), false, FUSEK>(L, lane, TT + TL_PT, KN_R1, KN_TEY);
+        else
+          riccati_factor<(KS > 0), false>(L, lane, TT + TL_PT);
+      }
       PT_MARK(3)
     }
 
     real sigc = 0.0, alpha = 1.0, dsigma = 0.0;
     bool numerics_failed = false, stalled = false;
-    treal eeps[6] = {0, 0, 0, 0, 0, 0};  // E eps of this iterate (safe-set block), in scalar registers
-    if constexpr (KS > 0) {
-#pragma unroll
-      for (int k = 0; k < 6; ++k) eeps[k] = uni(TT[TL_E + k] * TT[TL_EPS + k]);
-    }
+    if (!(FUSEK && fuse && ipm)) load_eeps();
     real d_val[KQ];
     const int npass = ipm ? 2 : 1;
     for (int pass = 0; pass < npass; ++pass) {
       const real smu = (pass == 1) ? sigc * mu : 0.0, pm = (pass == 1) ? 1.0 : 0.0;
-      // ======== gradient: cost gradient + row coefficients, written by the component owner ========
-      real sgsum = 0.0;  // sum of boundary-row coefficients entering the sigma gradient
-      if constexpr (KS > 0) {
-        if (ipm) {
-          PT_MARK(12)
-          // right-hand side r_j = -bl_j (dx = 0): sums over the eliminated points, the explicit ones through LDS
-          treal bs[7] = {0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-          for (int q = 0; q < KS; ++q) {
-            treal itf, uq[6];
-            sx.load_u(q, lane, uq);
-            const treal rj = sx.on[q] ? -simplex_bl(sx.lm[q], sx.t[q], sx.l[q], sx.p[q], sx.j[q], uq, treal(smu), treal(pm), eeps, itf) : treal(0);
-            if (sx.aidx[q] >= 0) TT[TL_RA + sx.aidx[q]] = rj;
-            const treal w = (sx.on[q] && sx.aidx[q] < 0) ? rj * itf : treal(0);
-            bs[6] += w;
-#pragma unroll
-            for (int k = 0; k < 6; ++k) bs[k] += uq[k] * w;
-          }
-          wave_sum_split<7>(bs, lane);
-          wave_fence();
-          PT_MARK(13)
-          treal beta[6], h[6], nu;
-#pragma unroll
-          for (int k = 0; k < 6; ++k) beta[k] = bs[k];
-          term_solve_u(TT, lane, sx.m, beta, bs[6], sx.r1, h, nu);
-          PT_MARK(14)
-          if (lane < 6) {  // terminal gradient onto x_T: E eps + pT, pT = -h
-            treal hs = h[0];
-#pragma unroll
-            for (int k = 1; k < 6; ++k) hs = (lane == k) ? h[k] : hs;
-            TT[TL_TG + lane] = TT[TL_E + lane] * TT[TL_EPS + lane] - hs;
-          }
-          wave_fence();
-          PT_MARK(15)
-        }
+      real sgsum = sgsum0;  // sum of boundary-row coefficients entering the sigma gradient
+      if (!(FUSEK && fuse && ipm && pass == 0)) {
+        sgsum = gradient(pass, smu, pm);
+        PT_MARK(4)
       }
-#pragma unroll
-      for (int q0 = 0; q0 < KQ; q0 += QC) {
-        real val[QC], par[QC], ca[QC], cb[QC], ql[QC];
-        real2 hl[QC];
-        SlotRef sr[QC];
-#pragma unroll
-        for (int qq = 0; qq < QC; ++qq) {
-          const int q = q0 + qq;
-          if (q >= KQ) continue;
-          sr[qq] = slot(q);
-          const int gr = sr[qq].gf, ov = sr[qq].ov;
-          val[qq] = lds[ov];
-          hl[qq] = r_bounds(sr[qq]);
-          par[qq] = lds[ov + ((gr >> 16) & 3) - 1];
-          ca[qq] = lds[CTB + (gr & 0xff)];
-          cb[qq] = lds[CTB + ((gr >> 8) & 0xff)];
-          ql[qq] = lds[ov + (KN_QLIN - 3)];
-        }
-#pragma unroll
-        for (int qq = 0; qq < QC; ++qq) {
-          const int q = q0 + qq;
-          if (q >= KQ) continue;
-          const int f = r_flags(sr[qq]);
-          const real sg = (f & F_SIG) ? sigma : 0.0;
-          const real itu = frcp(s_tu[q]), itl = frcp(s_tl[q]);
-          real cu = s_lu[q] * itu * (val[qq] - sg + s_tu[q] - hl[qq].x) + (smu - pm * s_pu[q]) * itu;
-          real cd = s_ll[q] * itl * (-val[qq] - sg + s_tl[q] + hl[qq].y) + (smu - pm * s_pl[q]) * itl;
-          cu = (ipm && (f & F_UP)) ? cu : 0.0;
-          cd = (ipm && (f & F_LO)) ? cd : 0.0;
-          const real g = ca[qq] * val[qq] + cb[qq] * par[qq] + ((f & F_QLIN) ? ql[qq] : real(0));  // (zero coefficients on a boundary slot)
-          lds[r_w(sr[qq])] = g + cu - cd;
-          if (pass == 0) {
-            const SlotRef sz = ((SITES & 2) && !lmpc_opaque_slots(sizeof(real), KQ, KS)) ? slot_at(q, 1) : sr[qq];
-            lds[(r_flags(sz) & F_EY) ? JB + KN_EY : r_w(sz) + 10] = 0.0;
-          }
-          sgsum += (f & F_SIG) ? (cu + cd) : real(0);
-        }
-        if constexpr (QC < KQ) ISSUE_ORDER();
-      }
-      wave_sync();
-      PT_MARK(12)
-      for (int i = lane; i < N; i += 64) {
-        real* kn = L.kn(i);
-        kn[KN_R0 + 1] += kn[KN_EY];
-        if (pass == 0) kn[KN_R1 + 1] = (i >= 1) ? kn[KN_CSIG] : 0.0;
-      }
-      if constexpr (KS > 0) {  // terminal gradient of the safe-set block onto x_T (lanes 0..5 != EY lanes' cells)
-        wave_sync();
-        if (lane < 6) L.kn(N - 1)[KN_R0 + lane] += real(TT[TL_TG + lane]);
-      }
-      wave_sync();
       // ======== Newton step: predictor together with the Schur vector, then the corrector ========
-      PT_MARK(4)
       if constexpr (LEAN) {
-        if (pass == 0 && ipm && has_sigma)
-          riccati_solve_lean_dpp<2>(L, MS, lane, pf);
-        else
+        if (pass == 0 && ipm && has_sigma) {
+          if (FUSEK && fuse)
+            riccati_solve_lean_dpp<2, FUSEK>(L, MS, lane, pf);
+          else
+            riccati_solve_lean_dpp<2>(L, MS, lane, pf);
+        } else
           riccati_solve_lean_dpp<1>(L, MS, lane, pf);
       } else {
-        if (pass == 0 && ipm && has_sigma)
-          riccati_solve<2>(L, lane, pf);
-        else
+        if (pass == 0 && ipm && has_sigma) {
+          if (FUSEK && fuse)
+            riccati_solve<2, FUSEK>(L, lane, pf);
+          else
+            riccati_solve<2>(L, lane, pf);
+        } else
           riccati_solve<1>(L, lane, pf);
       }
       PT_MARK(5)
@@ -3462,7 +3672,7 @@ __device__ __forceinline__ void lmpc_solve_problem(
   }
   if (hand_over == 0) break;
   wave_sync();
-  if (polish_attempt(pol::rounds)) {
+  if (polish_attempt(pol::rounds | (hand_over >= 2 ? POLISH_EXIT : 0))) {
     polished = true;
     status = LMPC_SOLVE_OPTIMAL;
     break;
@@ -3629,6 +3839,11 @@ __global__ __launch_bounds__(64, lmpc_waves_per_simd(8, KQ, KS)) void lmpc_solve
                                                           U_out, dU_out, status_out, iters_out, kkt_out);
 }
 
+#include "lmpc_solve_w2.hip.h"  // two wavefronts per problem: the fp64 tracking kernels for N >= 24 (round 6)
+#define LMPC_W2_SIGNATURE(KQ)                                                                                            \
+  __global__ void lmpc_solve_kernel_w2<KQ>(lmpc_params, int, const double*, const double*, const double*, const double*, \
+                                           const double*, const double*, const double*, double*, double*, double*, int*, int*, double*);
+
 #define LMPC_INSTANTIATE(REAL, KQ, KS, IO)                                                                              \
   template __global__ void lmpc_solve_kernel<REAL, KQ, KS, IO>(lmpc_params, int, const IO*, const IO*, const IO*,        \
                                                                 const IO*, const IO*, const IO*, const IO*, const IO*,    \
@@ -3639,7 +3854,14 @@ LMPC_INSTANTIATE_X(LMPC_SINGLE_INSTANCE)
 #elif defined(LMPC_MINREG_TU)  // lmpc_lib_minreg.hip: the two kernels that translation unit exists for
 LMPC_INSTANTIATE(float, 4, 2, double)
 LMPC_INSTANTIATE(float, 4, 3, double)
+#elif defined(LMPC_W2_TU)  // lmpc_lib_w2.hip: the two-wave kernels (a translation unit of their own: they rebuild in a minute)
+template LMPC_W2_SIGNATURE(7)
+template LMPC_W2_SIGNATURE(11)
+template LMPC_W2_SIGNATURE(14)
 #else
+extern template LMPC_W2_SIGNATURE(7)
+extern template LMPC_W2_SIGNATURE(11)
+extern template LMPC_W2_SIGNATURE(14)
 #define LMPC_INSTANTIATE_WARM(KQ, KS)                                                                                    \
   template __global__ void lmpc_solve_warm_kernel<KQ, KS>(lmpc_params, int, const double*, const double*, const double*, const double*,   \
                                                           const double*, const double*, const double*, const double*, const double*, double*, \

@@ -32,6 +32,8 @@ if LMPC:
     query = torch.stack([s_last + (kk - torch.fmod(kk, L)) * torch.sign(s0 - s_last), inp["X_ref"][1, -1]]).contiguous()
     ss_x, ss_j, _ = solver.ss_query(query)
     kw = dict(ss_x=ss_x, ss_j=ss_j)
+if "w2" in sys.argv:
+    solver.set_waves_per_problem(2)   # (round 6: the two-wave kernels; the clock is the chain wave's)
 out = solver.alloc_outputs(B)
 out["kkt"] = torch.zeros((20, B), dtype=torch.float64, device="cuda")
 for _ in range(3):
