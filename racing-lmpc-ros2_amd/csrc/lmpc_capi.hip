@@ -116,7 +116,7 @@ namespace {
 // which cold fp64 tracking solves take the two-wave kernels: forced by lmpc_set_waves_per_problem, else by measurement (LMPC_W2_AUTO_KQ:
 // the smallest one-wave slot count from which two waves are the default)
 #ifndef LMPC_W2_AUTO_KQ
-#define LMPC_W2_AUTO_KQ 14  // N >= 65: 11.4 -> 9.6 ms per 4096 at N = 80; parity at N = 60, -3 % at N <= 40 (csrc/lmpc_solve_w2.hip.h)
+#define LMPC_W2_AUTO_KQ 11  // N >= 41 (with the fused factorisation in both): N = 80 9.70 -> 8.06 ms per 4096, N = 65 6.59 -> 5.32, N = 41 .. 64 -1 .. 4 %; N <= 40 +5 %: one wave (profiles/r06_fuse_ab.txt)
 #endif
 inline bool lmpc_use_two_waves(int waves, int kq) { return waves == 2 || (waves == 0 && kq >= LMPC_W2_AUTO_KQ); }
 

@@ -2429,7 +2429,7 @@ __device__ __forceinline__ void lmpc_solve_problem(
   // the predictor's backward sweep inside the factorisation (riccati_factor<.., FUSE>): the barrier weights then go to the rhs1 cells
   // and the predictor's gradient is assembled ahead of the factorisation.  Problems without the shared slack have one right-hand
   // side and keep the five-chain iteration (no shipped configuration: q_boundary > 0 everywhere).
-  constexpr bool FUSEK = !WARMK && lmpc_fuse_bwd(sizeof(real), KQ, KS);
+  constexpr bool FUSEK = lmpc_fuse_bwd(sizeof(real), KQ, KS);  // (the warm-start kernels too: their cold path is this iteration)
   const bool fuse = FUSEK && P.has_sigma != 0;
   Lds<real> L{lds, N, LEAN ? LMPC_LEAN_STAGE_STRIDE : LMPC_STAGE_STRIDE, lmpc_fresh_lane(sizeof(real), KQ, KS),
               !SECOND && lmpc_waves_per_simd(sizeof(real), KQ, KS) >= 2};

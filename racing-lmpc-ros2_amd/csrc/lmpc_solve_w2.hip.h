@@ -15,21 +15,24 @@
 // 62 % of the one-wave kernel at N = 60 -- cost what they did (measured, phase clocks of the chain wave: factor 47.0 k cycles per
 // iteration against 44.1 k, the four sweeps 118 k against 116 k); what can change is the row phases' share.
 //
-// Measured (MI355X, 4096 problems, kernel ms; profiles/r06_w2_variants.txt):
-//                           N = 24    40     60     80    IAC 40   IAC 80     scratch B / lane (KQ = 7 / 11 / 14)
-//   one wave per problem     1.63    2.47   5.37   11.44   4.28    13.53      424 / 992 / 1792
-//   two waves, as shipped    1.70    2.55   5.37    9.55   4.24    11.38      316 / 740 /  996
-//   ... slots dealt unevenly (chain wave 3 / 4 / 4, the other 4 / 7 / 10: the chain wave as light as the N = 20 kernel)
-//                            1.69    2.50   5.67   11.32   4.19    13.27      284 / 896 / 1632
-//   ... without the opaque slot tables (below)            6.23   10.64                  676 / 1276 / 1364
-//   ... the chain role by hardware placement instead of wave 0 (HW_ID: SIMD parity = wave-slot parity)   no difference (6.48 / 11.10)
-// i.e. -17 % at the horizon iac_car_tracking_mpc.param.yaml ships (N = 80), nothing at N = 60, -3 % at N <= 40: the library takes
-// these kernels from N = 65 on (lmpc_capi.hip: LMPC_W2_AUTO_KQ), lmpc_set_waves_per_problem forces either.  Answers: the one-wave
-// kernel's to 1e-11, same statuses, same iteration counts on every problem of the six batches.
-// Why not more: at 256 registers the CHAIN wave's path still carries its row state across a Riccati stage that wants ~200 registers
-// of its own (272 / 479 spilled registers at KQ = 11 / 14), and its row phases wait for those reloads; the wave WITHOUT chain code is
-// fine.  The row phases at N = 60 take what they took (gradient 24.0 k cycles per iteration against 22.1 k).  VERDICT r5's targets
-// (N = 60 <= 3.2 ms, N = 80 <= 5.5 ms) need the chain itself split over time, a second algorithm.
+// Measured (MI355X, 4096 problems, kernel ms; profiles/r06_w2_variants.txt, profiles/r06_fuse_ab.txt):
+//                                        N = 24    40     60     80    IAC 40   IAC 80     scratch B / lane (KQ = 7 / 11 / 14)
+//   one wave per problem (round 5)        1.63    2.47   5.37   11.44   4.28    13.53      424 /  992 / 1792
+//   two waves, five chains per iteration  1.70    2.55   5.37    9.55   4.24    11.38      316 /  740 /  996
+//   ... slots dealt unevenly (chain wave 3 / 4 / 4, the other 4 / 7 / 10)
+//                                         1.69    2.50   5.67   11.32   4.19    13.27      284 /  896 / 1632
+//   ... without the opaque slot tables                   6.23   10.64                      676 / 1276 / 1364
+//   ... the chain role by hardware placement (HW_ID) instead of wave 0: no difference (6.48 / 11.10)
+//   one wave, fused factorisation         1.56    2.35   5.00    9.70   4.05    11.41      424 / 1008 / 1792
+//   two waves, fused (LMPC_W2_FUSE, shipped) 1.65  2.47   4.85    8.06   4.15     9.54      316 /  644 /  820
+// (fused: the predictor's backward sweep inside the factorisation, riccati_factor<.., FUSE> -- four dependent chains per iteration
+//  instead of five.)  The library takes these kernels from N = 41 on -- every lean-layout horizon: -1 .. 4 % up to N = 64, -19 % at N = 65
+//  (6.59 -> 5.32 ms: where the one-wave kernel goes from 11 to 14 slots per lane), -17 % at N = 80 -- lmpc_capi.hip: LMPC_W2_AUTO_KQ;
+// lmpc_set_waves_per_problem forces either.  Answers: the one-wave kernel's to 1e-11, same statuses, same iteration counts on every
+// problem of the six batches.
+// Why not more: the chain wave still carries its row state across a Riccati stage that wants ~200 registers of its own, and the
+// chains are 75 % of the kernel.  VERDICT r5's targets (N = 60 <= 3.2 ms, N = 80 <= 5.5 ms) need the chain itself shortened further
+// (DESIGN.md section 8 has the arithmetic of what was considered).
 //
 // Exchange between the waves: LDS + s_barrier (wg_sync).  Every wave-wide scalar of the one-wave kernel (mu, the step lengths, the
 // Schur sums, the polish's votes) becomes a two-step reduction -- DPP inside each wave, then both partial results through two LDS

@@ -8,7 +8,10 @@ from __graft_entry__ import load_package
 from oracle import params as P
 pkg = load_package()
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-for kind, N in (("barc", 24), ("barc", 40), ("barc", 60), ("barc", 80), ("iac", 40), ("iac", 80)):
+CASES = (("barc", 24), ("barc", 40), ("barc", 60), ("barc", 80), ("iac", 40), ("iac", 80))
+if len(sys.argv) > 2:  # w2_check.py B N,N,N...
+    CASES = tuple(("barc", int(n)) for n in sys.argv[2].split(","))
+for kind, N in CASES:
     tr = pkg.workloads.synthetic_track("putnam" if kind == "iac" else "barc")
     if kind == "iac":
         sv = pkg.Solver(pkg.presets.iac_tracking_mpc(N), pkg.presets.iac_vehicle(), device=0)

@@ -5,7 +5,7 @@ same algorithm, so it is held to everything the one-wave kernel is held to:
   * the serial twin on 1024 problems per horizon: answers, statuses, iteration counts;
   * the one-wave kernel on the same batch: same statuses, same iteration counts, answers to 1e-9;
   * bitwise reproducibility from launch to launch;
-and the dispatch: the library takes these kernels from N = 65 on by itself, lmpc_set_waves_per_problem forces either."""
+and the dispatch: the library takes these kernels from N = 41 on by itself, lmpc_set_waves_per_problem forces either."""
 import numpy as np
 import pytest
 import torch
@@ -88,8 +88,8 @@ def test_two_wave_kernel_against_the_twin_and_the_one_wave_kernel(pkg, family, N
     assert_same_iterations(o2["iters"][ok], tw["iters"][ok])
 
 
-def test_dispatch_takes_two_waves_from_n65_on(pkg):
-    for N, threads in ((20, 64), (40, 64), (60, 64), (64, 64), (65, 128), (80, 128)):
+def test_dispatch_takes_two_waves_from_n41_on(pkg):
+    for N, threads in ((20, 64), (40, 64), (41, 128), (60, 128), (64, 128), (65, 128), (80, 128)):
         sv = pkg.Solver(pkg.presets.barc_tracking_mpc(N), pkg.presets.barc_vehicle(), device=0)
         assert sv.launch_info("f64")["threads_per_problem"] == threads, (N, sv.launch_info("f64"))
         sv.set_waves_per_problem(2)
