@@ -18,7 +18,8 @@ oracle against.  What pins it instead:
     solution carries a solver-independent KKT certificate (oracle/qp.py);
   * the analytic RK4 Jacobians are checked against complex-step
     differentiation of the RK4 map (oracle/dynamics.py);
-  * the k-NN query is a brute-force sort (oracle/safe_set.py);
+  * the k-NN query is a brute-force sort (ss_query in oracle/c/lmpc_oracle.c, driven by tests/lmpc_scenario.py and
+    tests/test_safe_set_oracle.py);
   * the reference's recorded BARC laps (its only data fixtures on this path,
     src/mpc/racing_mpc/test_data/barc_ss) are replayed through the dynamics as
     a plausibility check (tests/test_oracle_dynamics.py);
