@@ -29,9 +29,9 @@ ALGO_BYTES_PER_SOLVE = (13 * 20 + 5) * 8 + (10 * 20 - 4) * 8 + 8  # 3696 B at N 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
 
 
-def measured_traffic_bytes(pmc_file="r05_pmc_tracking.json", kernel="lmpc_solve_kernel<double, 4, 0"):
+def measured_traffic_bytes(pmc_file="r06_pmc_tracking.json", kernel="lmpc_solve_kernel<double, 4, 0"):
     """HBM bytes per launch of the QP kernel from the committed rocprofv3 PMC passes of this same command
-    (profiles/r05_pmc_tracking.json: FETCH_SIZE and WRITE_SIZE are reported in KiB, collected in separate --pmc runs).
+    (profiles/r06_pmc_tracking.json: FETCH_SIZE and WRITE_SIZE are reported in KiB, collected in separate --pmc runs).
     The gfx950 FETCH_SIZE x2 correction of MI355X_MICROARCH.md applies to wide coalesced streams only; this
     kernel's reads are 8-byte strided or L2/MALL-resident workspace lines, so the raw counter is reported."""
     try:
@@ -122,7 +122,7 @@ def live_engines(counters, kernel_ms):
     return e
 
 
-def engine_utilisation(kernel_ms, pmc_file="r05_pmc_tracking.json", kernel="lmpc_solve_kernel<double, 4, 0"):
+def engine_utilisation(kernel_ms, pmc_file="r06_pmc_tracking.json", kernel="lmpc_solve_kernel<double, 4, 0"):
     """What actually bounds the QP kernel: busy fractions of the FP64 VALU and of the LDS pipeline from the same
     committed PMC passes (SQ_ACTIVE_INST_VALU is in 4-cycle units summed over waves, one VALU per SIMD, 4 SIMDs x
     256 CUs; SQ_LDS_IDX_ACTIVE in cycles summed over the 256 CU-local LDS pipelines), against the kernel duration of
@@ -723,7 +723,7 @@ def main():
             #                                                  the kernel reads 4 S B of codes + the points from the L2-resident store instead, the figure is kept as SURVEY states it)
         achieved = algo_bytes * B / (sol_avg * 1e-3) / 1e9
         # committed PMC passes of this command: tracking, or the learning problem with 160 safe-set points
-        pmc_sel = ("r04_pmc_lmpc.json", "lmpc_solve_kernel<double, 4, 3") if lmpc else ("r05_pmc_tracking.json", "lmpc_solve_kernel<double, 4, 0")
+        pmc_sel = ("r04_pmc_lmpc.json", "lmpc_solve_kernel<double, 4, 3") if lmpc else ("r06_pmc_tracking.json", "lmpc_solve_kernel<double, 4, 0")
         pmc_shape = not (N != 20 or B != 4096 or iac or f32 or mixed)  # the shape the committed passes were taken on
         if lmpc and (args.lmpc_data != "near" or args.laps != 5):        # (r04_pmc_lmpc.json: the rounds-1-4 learning workload, 160 points)
             pmc_shape = False
@@ -740,6 +740,8 @@ def main():
                 wl_argv += ["--laps", str(args.laps), "--laps-npz", laps_file]
             # (SQL LIKE pattern: the learning kernels are the KS = 2 (<= 128 points) / 3 instantiations, the tracking ones KS = 0)
             kname = "lmpc_solve_kernel<%s, %%, %d, " % ("float" if (f32 or mixed) else "double", 0 if not lmpc else (2 if cfgd["num_ss_pts"] <= 128 else 3))
+            if not (lmpc or f32 or mixed) and solver.launch_info("f64")["threads_per_problem"] == 128:
+                kname = "lmpc_solve_kernel_w2<%"  # the two-wavefronts-per-problem kernels (fp64 tracking, N >= 41: csrc/lmpc_solve_w2.hip.h)
             counters = live_counters(wl_argv, kname, PMC_PASSES[:2] if args.pmc_traffic_only else PMC_PASSES)
             if laps_file:
                 os.unlink(laps_file)

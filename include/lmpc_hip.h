@@ -194,7 +194,9 @@ int lmpc_solve_batch(lmpc_handle* h, int32_t batch, const double* x_ic, const do
  * the periods of a closed loop -- the answer is the optimum the cold solve finds (same 1e-6 contract; measured 1e-11 apart) for
  * about two iterations' worth of work instead of seven; `iters` then counts the rounds (1 or 2).  Refused, the call IS
  * lmpc_solve_batch (the rounds spent are added to `iters`).  A bad plan costs time, never correctness: nothing is returned that
- * has not passed the KKT test of this problem.  fp64 tracking problem; learning handles: lmpc_solve_batch_warm_ss below. */
+ * has not passed the KKT test of this problem.  fp64 tracking problem; learning handles: lmpc_solve_batch_warm_ss below.
+ * With lmpc_config.polish < 0 (the polish switched off) there is no active-set machinery to try the plan with: the call is a cold
+ * lmpc_solve_batch, silently -- lmpc_get_warm_accepted then reports 0 for every problem. */
 int lmpc_solve_batch_warm(lmpc_handle* h, int32_t batch, const double* x_ic, const double* u_ic, const double* X_ref, const double* U_ref,
                           const double* T_ref, const double* bound_left, const double* bound_right, const double* curvatures,
                           const double* vel_ref, double total_length, const double* X_optm_ref, const double* U_optm_ref, double* X_optm,
