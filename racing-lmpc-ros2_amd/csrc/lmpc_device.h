@@ -71,7 +71,10 @@ struct lmpc_params {
 // through two chunk buffers of LMPC_LEAN_CHUNK workspace records
 #define LMPC_LEAN_STAGE_STRIDE 24
 #define LMPC_LEAN_CHUNK 8
-static inline int lmpc_is_lean(int N, int real_bytes) { return real_bytes == 8 && (11 * N + 63) / 64 > 7; }
+#ifndef LMPC_LEAN_MIN_KQ
+#define LMPC_LEAN_MIN_KQ 11
+#endif
+static inline int lmpc_is_lean(int N, int real_bytes) { return real_bytes == 8 && (11 * N + 63) / 64 > 7 && LMPC_LEAN_MIN_KQ <= 11; }
 
 // LDS bytes per problem; real_bytes = 8 (fp64 records) or 4 (fp32 records: single-precision and mixed solves)
 static inline size_t lmpc_lds_bytes(int N, int learning, int S, int real_bytes) {

@@ -837,7 +837,10 @@ struct Lds {
 #define LN_HI11 18
 #define LN_DT 19
 #define LN_KFF(s) ((s) ? 22 : 20)
-constexpr bool lmpc_lean(int real_bytes, int kq) { return real_bytes == 8 && kq >= 11; }
+#ifndef LMPC_LEAN_MIN_KQ  // (A/B switch: 99 builds every kernel on the fat layout; lmpc_device.h's lmpc_is_lean follows it)
+#define LMPC_LEAN_MIN_KQ 11
+#endif
+constexpr bool lmpc_lean(int real_bytes, int kq) { return real_bytes == 8 && kq >= LMPC_LEAN_MIN_KQ; }
 template <typename real>
 struct ModelStream {
   const real* ws;  // this problem's [N - 1][LN_REC] in the workspace (HBM / L2)
@@ -875,9 +878,18 @@ struct ModelStream {
 #undef LMPC_GLDS
   }
   // every copy issued so far has landed (vmcnt counts them), and no later LDS read moves ahead of this point
+#ifdef LMPC_PHASE_TIMING
+  mutable long long waited = 0;  // cycles spent in wait() (profiling build: reported as phase 5)
+#endif
   __device__ __forceinline__ void wait() const {
+#ifdef LMPC_PHASE_TIMING
+    const long long t0 = __builtin_readcyclecounter();
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     wave_fence();
+#ifdef LMPC_PHASE_TIMING
+    waited += __builtin_readcyclecounter() - t0;
+#endif
   }
   __device__ __forceinline__ const real* stage(int i) const {  // (i is wave-uniform: keep the slot arithmetic on the scalar unit)
     const int off = __builtin_amdgcn_readfirstlane(((i / LN_CHUNK) & 1) * LN_CHUNK * LN_REC + (i % LN_CHUNK) * LN_REC);
@@ -3731,6 +3743,7 @@ __device__ __forceinline__ void lmpc_solve_problem(
     }
 #ifdef LMPC_PHASE_TIMING
     if (kkt_out) {
+      if constexpr (LEAN) pf.acc[5] = MS.waited;  // (cycles inside ModelStream::wait of the interior point's own sweeps -- also counted in their phases)
       for (int k = 0; k < 16; ++k) kkt_out[k * (size_t)B + b] = (io)pf.acc[k];
       kkt_out[16 * (size_t)B + b] = (io)pf.w0;               // 100 MHz wall clock at start
       kkt_out[17 * (size_t)B + b] = (io)wall_clock64();      // ... at end

@@ -32,6 +32,8 @@ if LMPC:
     query = torch.stack([s_last + (kk - torch.fmod(kk, L)) * torch.sign(s0 - s_last), inp["X_ref"][1, -1]]).contiguous()
     ss_x, ss_j, _ = solver.ss_query(query)
     kw = dict(ss_x=ss_x, ss_j=ss_j)
+if "w1" in sys.argv:
+    solver.set_waves_per_problem(1)   # (since round 6 the library takes two waves from N = 41 on by itself)
 if "w2" in sys.argv:
     solver.set_waves_per_problem(2)   # (round 6: the two-wave kernels; the clock is the chain wave's)
 out = solver.alloc_outputs(B)
@@ -41,7 +43,7 @@ for _ in range(3):
 torch.cuda.synchronize()
 k = out["kkt"].cpu().numpy()
 it = out["iters"].cpu().numpy()
-names = ["load", "init(factor+rollout)", "rows+reduce(+terminal block)", "factor", "riccati_solve (all)", "-", "schur+steps", "update/exit",
+names = ["load", "init(factor+rollout)", "rows+reduce(+terminal block)", "factor", "riccati_solve (all)", "(ModelStream::wait, inside the sweeps)", "schur+steps", "update/exit",
          "  bwd sweep nrhs1", "  bwd sweep nrhs2", "  fwd sweep nrhs1", "  fwd sweep nrhs2", "gradient", "x13", "x14", "x15"]
 tot = k[:16].sum(0)
 print("mean iters %.2f; mean cycles/wave %.0f" % (it.mean(), tot.mean()))
