@@ -897,7 +897,7 @@ static void primal_update(prob_t* p, double alpha) {
  * attempted. */
 #define POLISH_THETA 1e8
 #ifndef POLISH_MU /* (scratch/r5/twin_variant.py builds variants with -D) */
-#define POLISH_MU 1e-8
+#define POLISH_MU 1e-8 /* (1e-7 was measured in round 6 and lost: polish_limits<double>::mu_early of the kernel has the numbers) */
 #endif
 #ifndef POLISH_RD
 #define POLISH_RD 1e-6

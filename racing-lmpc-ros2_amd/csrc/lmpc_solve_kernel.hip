@@ -394,6 +394,10 @@ template <> struct polish_limits<double> {
   // iterate (mu 5e-12, a degenerate problem: 3.4e-6 from the twin in dU) stood with status OPTIMAL.  A consistent set whose steps are
   // still CONVERGING is not a reason to give the optimum up: two more steps cost two sweeps on the few problems that need them (the
   // loop leaves after any step <= step_ok) and nothing on the others.
+  // mu_early stays 1e-8.  1e-7 was measured in round 6 (scratch/r6/twin_mu_early.py on the twin, then on the GPU): mean iterations
+  // 8.92 -> 8.63 (BARC N = 20), 9.41 -> 9.17 (N = 40), 12.5 -> 12.2 (learning), every answer still 1e-9 from the dense optimum, the
+  // pipelined rate +1.3 % -- and the KERNEL slower: 0.813 -> 0.861 ms (N = 20), 2.35 -> 2.48 (N = 40), 8.11 -> 8.65 (N = 80) per 4096:
+  // more early attempts are refused, those problems pay the attempt and a second one, and a launch lasts as long as its slowest waves.
   static constexpr double theta = 1e8, feas = 1e-9, dual = 1e-7, mu_early = 1e-8, rd_early = 1e-6, step_ok = 1e-7, step_tol = 1e-6;
   static constexpr int rounds = 4, steps = 6;
 };
