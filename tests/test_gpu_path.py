@@ -349,13 +349,15 @@ def test_lmpc_experiment_lap_times_improve(pkg):
     assert res["laps_in_set"] == 3                             # the ring keeps max_lap_stored laps
 
 
-def test_hard_boundary_without_slack(pkg):
+@pytest.mark.parametrize("N", [10, 30, 48])
+def test_hard_boundary_without_slack(pkg, N):
     """q_boundary = 0: no shared slack, the track boundary is a hard row pair (racing_mpc.cpp:529-543) and also
-    applies to knot 0."""
+    applies to knot 0.  (N = 30 and 48, round 6: the kernels built with the fused factorisation -- one wave, fat records; two waves,
+    lean records -- take their five-chain branch here: without the slack there is one right-hand side and nothing to fuse.)"""
     import dataclasses
 
-    veh, cfg = P.barc_vehicle(), dataclasses.replace(P.barc_tracking_mpc(10), q_boundary=0.0)
-    preset = pkg.presets.barc_tracking_mpc(10)
+    veh, cfg = P.barc_vehicle(), dataclasses.replace(P.barc_tracking_mpc(N), q_boundary=0.0)
+    preset = pkg.presets.barc_tracking_mpc(N)
     preset["q_boundary"] = 0.0
     solver = pkg.Solver(preset, pkg.presets.barc_vehicle(), device=0)
     tr = pkg.workloads.synthetic_track("barc")
@@ -365,7 +367,7 @@ def test_hard_boundary_without_slack(pkg):
     inp = S.cold_start_inputs(cfg, veh, tr, x, u, 0.025)
     out = to_np(solver.solve(inp))
     twin = cbind.solve_batch(cfg, veh, inp)
-    assert (out["status"] == twin["status"]).all() and (out["status"][:16] == 0).sum() >= 12
+    assert (out["status"] == twin["status"]).all() and (out["status"][:16] == 0).sum() >= (12 if N == 10 else 4), (out["status"], twin["status"])
     ok = out["status"] == 0
     assert np.abs((out["X_optm"] - twin["X_optm"]) / P.SCALE_X[:, None, None])[:, :, ok].max() < TOL_TWIN
     assert (out["kkt"][3] == 0).all()                       # no slack variable in this configuration
