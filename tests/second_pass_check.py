@@ -40,7 +40,7 @@ def tracking(N, B, mixed):
     tr = pkg.workloads.synthetic_track("barc")
     x, u = pkg.workloads.sample_initial_states("barc", B, tr["L"], [-0.01, -0.314159], [0.01, 0.314159], seed=0)
     sv = pkg.Solver(pkg.presets.barc_tracking_mpc(N), pkg.presets.barc_vehicle(), device=0)
-    sv.set_waves_per_problem(1)  # the second pass IS the one-wave kernel; from N = 65 on a direct solve takes the two-wave kernel by itself (round 6)
+    sv.set_waves_per_problem(1)  # the second pass IS the one-wave kernel; from N = 41 on a direct solve takes the two-wave kernel by itself (round 6)
     inp = sv.prepare(tr, x.T.copy(), 0.025)
     inp["u_ic"] = torch.as_tensor(u.T.copy(), dtype=torch.float64, device=dev)
     o = sv.solve(inp, sv.alloc_outputs(B), mixed=mixed)
