@@ -1810,7 +1810,10 @@ __device__ __forceinline__ T* uni_ptr(T* p) {
 //     kernel and changes single-precision roundings enough to lose four solves of 4096 at N = 80.
 //   * FRESH_LANE everywhere.
 // (The A/B switches behind these measurements -- never / always a call, never / always fresh -- went to scratch/r5/experiment_switches.patch.)
-constexpr bool lmpc_polish_is_call(int real_bytes, int kq, int ks) { return real_bytes == 8 && lmpc_waves_per_simd(real_bytes, kq, ks) < 2; }
+#ifndef LMPC_POLISH_CALL_2W  // (A/B switch: 1 puts the polish behind a call in the two-waves-per-SIMD fp64 kernels too)
+#define LMPC_POLISH_CALL_2W 1
+#endif
+constexpr bool lmpc_polish_is_call(int real_bytes, int kq, int ks) { return real_bytes == 8 && (LMPC_POLISH_CALL_2W || lmpc_waves_per_simd(real_bytes, kq, ks) < 2); }
 constexpr bool lmpc_fresh_lane(int real_bytes, int kq, int ks) { return true; }
 
 template <typename real, int KQ, int KS, typename io, bool SECOND = false>  // (SECOND: see lmpc_solve_problem)
@@ -2401,14 +2404,16 @@ __host__ __device__ constexpr int lmpc_opaque_sites(int real_bytes, int kq, int 
 //                  took a memory access fault in the mixed entry (the polish's flat store of the iterate to the save area with a
 //                  clobbered address register; the fp32-array instance of the same source is fine): another of the
 //                  compiler-sensitive corners of DESIGN.md section 4, found by tests/dispatch_sweep.py on its first run.
-//   fp64 tracking N <= 23 (KQ <= 4, two waves per SIMD): OFF as well.  It gained 2.7 % (0.859 -> 0.835 ms) and passed every test -- until an
-//                  unrelated edit of the polish (a multiplier in its classification) changed the register allocation: the fused
-//                  <double, 4, 0, double> then returned garbage statuses in a pattern that follows the workgroup's XCD (same source with a
-//                  printf compiled in: correct) -- the family of failure of round 4's bisect (profiles/r04_d70_bisect.md): DPP row
-//                  broadcasts next to spilled registers at 256 VGPRs.  The one-wave-per-SIMD kernels and the two-wave-per-problem kernels
-//                  have the registers, and that is where the chain saved is worth 5 .. 18 %.
+//   fp64 tracking N <= 23 (KQ <= 4, two waves per SIMD; the headline): ON, WITH THE POLISH BEHIND A CALL (LMPC_POLISH_CALL_2W).  Fused with the
+//                  polish inlined it gained 2.7 % and passed every test -- until an unrelated edit of the polish (a multiplier in its
+//                  classification) changed the register allocation: <double, 4, 0, double> then left the iteration after its first pass
+//                  (status MAX_ITER, 0 iterations; the loop's control variables read back correct; the same source with a printf, or with
+//                  one more integer assigned before each break, is correct: CHANGELOG.md, round 6).  Behind a call the polish's live state
+//                  (the spill source of this kernel since round 3) is out of the iteration's register allocation -- the form every
+//                  one-wave kernel has always had, all of them fused without incident: 0.819 -> 0.794 ms per 4096, every GPU test green
+//                  (the call form alone, unfused: 0.817).
 #ifndef LMPC_FUSE_MASK
-#define LMPC_FUSE_MASK 0x56
+#define LMPC_FUSE_MASK 0x57
 #endif
 __host__ __device__ constexpr bool lmpc_fuse_bwd(int real_bytes, int kq, int ks) {
   // bit 0: fp64 tracking KQ <= 4 (two waves per SIMD), 1: fp64 tracking KQ = 7, 2: fp64 tracking lean (KQ >= 11), 3: fp64 learning KQ >= 7,
@@ -2445,7 +2450,9 @@ __device__ __forceinline__ void lmpc_solve_problem(
   // the predictor's backward sweep inside the factorisation (riccati_factor<.., FUSE>): the barrier weights then go to the rhs1 cells
   // and the predictor's gradient is assembled ahead of the factorisation.  Problems without the shared slack have one right-hand
   // side and keep the five-chain iteration (no shipped configuration: q_boundary > 0 everywhere).
-  constexpr bool FUSEK = lmpc_fuse_bwd(sizeof(real), KQ, KS);  // (the warm-start kernels too: their cold path is this iteration)
+  // (the warm-start kernels too: their cold path is this iteration -- except at two waves per SIMD, where the fused iteration is only
+  //  trusted with the polish behind a call, lmpc_fuse_bwd's comment, and the warm kernels keep theirs inline)
+  constexpr bool FUSEK = lmpc_fuse_bwd(sizeof(real), KQ, KS) && !(WARMK && lmpc_waves_per_simd(sizeof(real), KQ, KS) >= 2);
   const bool fuse = FUSEK && P.has_sigma != 0;
   Lds<real> L{lds, N, LEAN ? LMPC_LEAN_STAGE_STRIDE : LMPC_STAGE_STRIDE, lmpc_fresh_lane(sizeof(real), KQ, KS),
               !SECOND && lmpc_waves_per_simd(sizeof(real), KQ, KS) >= 2};
@@ -2798,7 +2805,9 @@ __device__ __forceinline__ void lmpc_solve_problem(
     }
     pa.sx = sx;
     PolishResult<real, KS> pr;
-    if constexpr (lmpc_polish_is_call(sizeof(real), KQ, KS))
+    // (the warm-start kernels at two waves per SIMD keep the polish inline: their accepted attempts ARE the polish, and behind a call the
+    //  closed loop loses 3 .. 5 %: 6.65 -> 6.43 M car-steps/s at 4096 cars, 12.5 -> 11.9 M at 16384)
+    if constexpr (lmpc_polish_is_call(sizeof(real), KQ, KS) && !(WARMK && lmpc_waves_per_simd(sizeof(real), KQ, KS) >= 2))
       pr = lmpc_polish_call<real, KQ, KS, io, SECOND>(pa);
     else
       pr = lmpc_polish<real, KQ, KS, io, SECOND>(pa);
