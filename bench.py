@@ -794,7 +794,9 @@ def main():
                          "traffic_over_algorithmic": (traffic / (algo_bytes * B)) if traffic else None,
                          "algorithmic_bytes_per_solve": algo_bytes,
                          "note": "algorithmic bytes x batch / lmpc_solve_kernel time; the kernel is "
-                                 "FP64-VALU issue / LDS-pipeline bound (DESIGN.md), HBM fraction is reported as required",
+                                 "FP64-VALU issue / LDS-pipeline bound (DESIGN.md), HBM fraction is reported as required; "
+                                 "traffic beyond the algorithmic bytes is the linearisation workspace read back (34 MB per 4096 at N = 20) and "
+                                 "register spills -- since round 6 mostly the call frame of the active-set polish (DESIGN.md section 3)",
                          "engines": engines,
                          # the roofline that BINDS this kernel (it is 160 flop/B: HBM is not it) -- instruction issue: busy fractions of the FP64
                          # VALU and of the LDS pipeline over the kernel's duration, and the LDS cycles lost to bank conflicts
