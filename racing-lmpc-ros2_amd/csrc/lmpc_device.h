@@ -74,7 +74,9 @@ struct lmpc_params {
 #ifndef LMPC_LEAN_MIN_KQ
 #define LMPC_LEAN_MIN_KQ 11
 #endif
-static inline int lmpc_is_lean(int N, int real_bytes) { return real_bytes == 8 && (11 * N + 63) / 64 > 7 && LMPC_LEAN_MIN_KQ <= 11; }
+// (the kernels' slot classes: 2 / 4 / 7 / 11 / 14 slots per lane for N <= 11 / 23 / 40 / 64 / 81; lean from LMPC_LEAN_MIN_KQ slots on)
+static inline int lmpc_slot_class(int N) { return N <= 11 ? 2 : (N <= 23 ? 4 : (N <= 40 ? 7 : (N <= 64 ? 11 : 14))); }
+static inline int lmpc_is_lean(int N, int real_bytes) { return real_bytes == 8 && lmpc_slot_class(N) >= LMPC_LEAN_MIN_KQ; }
 
 // LDS bytes per problem; real_bytes = 8 (fp64 records) or 4 (fp32 records: single-precision and mixed solves)
 static inline size_t lmpc_lds_bytes(int N, int learning, int S, int real_bytes) {
