@@ -101,3 +101,32 @@ def test_dispatch_takes_two_waves_from_n41_on(pkg):
     with pytest.raises(pkg.LmpcError, match="lmpc_set_waves_per_problem"):
         lm.set_waves_per_problem(3)
     lm.close()
+
+
+def test_full_dynamics_through_the_two_wave_kernel(pkg):
+    """lmpc_solve_full_dynamics_batch (the IPOPT role: sequential QPs over the same kernels) at the horizon barc_tracking_mpc.param.yaml
+    ships: the library's choice (two waves per problem from N = 41 on) against the one-wave kernel forced -- the same first-order
+    points from the node's first-solve state (racing_mpc_node.cpp:210-235,299-314)."""
+    from oracle import scenario as S
+
+    N, B = 60, 16
+    veh, cfg = P.barc_vehicle(), P.barc_tracking_mpc(N)
+    tr = pkg.workloads.synthetic_track("barc")
+    x = np.zeros((B, 6))
+    x[:, 0] = np.linspace(0.0, tr["L"], B, endpoint=False)
+    x[:, 3] = 1.5
+    inp = S.cold_start_inputs(cfg, veh, tr, x, np.zeros((B, 2)), 0.025)
+    res = {}
+    for waves in (0, 1):
+        sv = pkg.Solver(pkg.presets.barc_tracking_mpc(N), pkg.presets.barc_vehicle(), device=0)
+        sv.set_waves_per_problem(waves)
+        assert sv.launch_info("f64")["threads_per_problem"] == (128 if waves == 0 else 64)
+        res[waves] = _np(sv.solve_full_dynamics(inp, max_sqp=40, tol=1e-9))
+        sv.close()
+    a, b = res[0], res[1]
+    conv = (a["status"] == 0) & (a["sqp_move"] <= 1e-9)
+    assert conv.all(), (np.bincount(a["status"]), a["sqp_move"])
+    assert np.array_equal(a["status"], b["status"]) and a["defect"].max() < 1e-7
+    e = np.abs((a["X_optm"] - b["X_optm"]) / P.SCALE_X[:, None, None]).max()
+    print("full dynamics, N = 60: two waves vs one wave X %.1e; QPs per problem %.1f / %.1f" % (e, a["sqp_iters"].mean(), b["sqp_iters"].mean()))
+    assert e < 1e-6
