@@ -2396,7 +2396,7 @@ __host__ __device__ constexpr int lmpc_opaque_sites(int real_bytes, int kq, int 
 // the predictor's backward sweep fused into the factorisation (riccati_factor<.., FUSE>): per instantiation, by measurement
 // (MI355X, 4096 problems, kernel ms five chains -> four; profiles/r06_fuse_ab.txt):
 //   fp64 tracking  N = 20 0.859 -> 0.835, N = 24 1.639 -> 1.565, N = 40 2.461 -> 2.351, N = 60 5.368 -> 4.957, IAC N = 40 4.322 -> 4.052
-//   fp64 learning  N = 20 / 160 points 2.072 -> 2.028 (on); N = 40 5.388 -> 5.646 (off: KQ >= 7 with KS > 0 is the most register-starved family)
+//   fp64 learning  N = 20 / 160 points 2.072 -> 2.028 (on); N = 40 5.52 -> 5.81, N = 60 14.54 -> 14.21 (off: KQ >= 7 with KS > 0 is the most register-starved family)
 //   fp32 / mixed   IAC N = 40 3.275 -> 3.203 / 6.091 -> 5.850 (on); learning N = 20 mixed 3.385 -> 3.239, but OFF: which ill-conditioned blends
 //                  of safe-set points pass the fp32 KKT test 1e-3 .. 5e-3 from the fp64 answer is decided by the last bits of the fp32
 //                  sweeps -- 3 of configs[4]'s 32768 before, 5 fused (tests/test_gpu_spec_workload.py holds the 99.99 % quantile to 1e-3);

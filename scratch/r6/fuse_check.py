@@ -32,7 +32,9 @@ def timed(sv, run):
     sv.enable_timing(False)
     return out, float(np.median(ms))
 cases = [("barc", 20, "f64"), ("barc", 24, "f64"), ("barc", 40, "f64"), ("barc", 60, "f64"), ("barc", 80, "f64"), ("iac", 40, "f64"), ("iac", 40, "f32"), ("iac", 40, "mixed"),
-         ("lmpc", 20, "f64"), ("lmpc", 20, "mixed"), ("lmpc", 40, "f64")]
+         ("lmpc", 20, "f64"), ("lmpc", 20, "mixed"), ("lmpc", 40, "f64"), ("lmpc", 60, "f64")]
+if len(sys.argv) > 2:  # fuse_check.py TAG kind:N:prec,...
+    cases = [(c.split(":")[0], int(c.split(":")[1]), c.split(":")[2]) for c in sys.argv[2].split(",")]
 for kind, N, prec in cases:
     tr = pkg.workloads.synthetic_track("putnam" if kind == "iac" else "barc")
     kw = {}
