@@ -283,6 +283,10 @@ def other_configs(steps, warmup):
     legs = [("configs[2]", ["--workload", "lmpc", "--batch", "4096", "--horizon", "20"]),
             ("configs[3], share of one GPU (8192 of 65536)", ["--workload", "iac", "--horizon", "40", "--batch", "8192", "--precision", "f32"]),
             ("configs[4], share of one GPU (32768 of 262144)", ["--workload", "lmpc", "--batch", "32768", "--horizon", "20", "--precision", "mixed", "--regression"]),
+            # configs[1]'s problem at the horizons the reference SHIPS for tracking (barc_tracking_mpc.param.yaml n = 60, iac_car_tracking_mpc.param.yaml
+            # n = 80; BASELINE quotes N = 20): the two-wavefronts-per-problem kernels of round 6, so that their numbers are in the driver's record too
+            ("configs[1]'s problem at the shipped BARC horizon (N = 60; not a BASELINE config)", ["--workload", "tracking", "--batch", "4096", "--horizon", "60"]),
+            ("configs[1]'s problem at the shipped IAC horizon (N = 80; not a BASELINE config)", ["--workload", "tracking", "--batch", "4096", "--horizon", "80"]),
             # the friendlier learning workload of rounds 1 - 4 (analytic laps, states near the last lap), reported separately
             ("configs[2] on the rounds-1-4 workload (states near the laps; not SURVEY 8d's)", ["--workload", "lmpc", "--batch", "4096", "--horizon", "20", "--lmpc-data", "near"]),
             ("configs[4] share on the rounds-1-4 workload (states near the laps; not SURVEY 8d's)",
@@ -295,9 +299,10 @@ def other_configs(steps, warmup):
         # the three BASELINE legs carry what the headline carries: HBM traffic measured in the run (the FETCH_SIZE and
         # WRITE_SIZE passes only: --pmc-traffic-only) and the CPU twin timed on the same workload (a ~4 s sample); the two legs on the
         # rounds-1-4 workload are for continuity and carry neither
-        full = "rounds-1-4" not in name
+        full = name.startswith("configs[") and "rounds-1-4" not in name and "not a BASELINE config" not in name
+        traffic_only = "not a BASELINE config" in name   # (the shipped-horizon legs: kernel time and HBM traffic, no CPU leg)
         cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", "1", "--steps", str(max(5, min(steps, 20))), "--warmup", str(max(1, min(warmup, 3))),
-               "--no-batch1", "--no-others", "--min-window", "0.3"] + (["--pmc-traffic-only", "--cpu-budget", "4"] if full else ["--no-cpu-baseline", "--no-pmc"]) + argv
+               "--no-batch1", "--no-others", "--min-window", "0.3"] + (["--pmc-traffic-only", "--cpu-budget", "4"] if full else (["--pmc-traffic-only", "--no-cpu-baseline"] if traffic_only else ["--no-cpu-baseline", "--no-pmc"])) + argv
         try:
             r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420)
             line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
