@@ -51,7 +51,9 @@ typedef enum lmpc_status {
 #define LMPC_SOLVE_MAX_ITER 1   /* the iteration cap -- or (fp64) stopped short of the stated accuracy: the interior point reached its
                                    floor and the active-set polish was refused by a consistent held set whose multiplier steps do
                                    not settle, i.e. the problem's linear algebra is noisier than the 1e-6 contract (low speed x
-                                   long horizon: the RK4 step map is unstable there); the iterate is returned, not vouched for */
+                                   long horizon: the RK4 step map is unstable there), or (round 6) it stopped at its stall rule while its
+                                   Newton step would still have moved the iterate by more than 1e-6 (scaled) and the polish did not
+                                   verify the point; the iterate is returned, not vouched for */
 #define LMPC_SOLVE_INFEASIBLE 2 /* x_ic outside [x_min, x_max] at knot 0, row residual stalls, NaN */
 #define LMPC_SOLVE_UNVERIFIED 3 /* lmpc_solve_batch_mixed with lmpc_config.polish = 1 only: the fp32 iteration did not reach an
                                    answer it could verify -- polish refused, out of iterations, or infeasible by its

@@ -433,6 +433,9 @@ static inline double slot_val(double (*z)[8], double (*v)[2], int i, int sl) {
 #endif
 /* complementarity below which a step that does not lower it ends the solve (ipm_solve) */
 #define STALL_MU 1e-9
+#ifndef STALL_STEP
+#define STALL_STEP 1e-6 /* scaled size of the last primal step above which a stalled, unpolished iterate is not vouched for (ipm_solve's exit) */
+#endif
 #define MA_MAX 6 /* four until round 5: a five-lap safe set has optima that blend one point per lap, and the fifth point then went
                   * through 1 / theta -> 1e12 (cond(F_B) with it): answers 1e-2 off, reported OPTIMAL (csrc/lmpc_solve_kernel.hip) */
 #define TAU_REL 1e-5 /* tau = TAU_REL * max_j u_j'E u_j: cond(F_B) <= ~1e5 */
@@ -870,6 +873,17 @@ static void primal_update(prob_t* p, double alpha) {
   if (p->has_sigma) p->sigma += alpha * p->dsigma;
   for (int j = 0; j < p->S; ++j) p->lmb[j] += alpha * p->dlmb[j];
 }
+/* the size of the step alpha (dz, dv) in the reference's scaled units (racing_mpc.cpp:36-37), as the kernel's slots measure it */
+static double scaled_step(const prob_t* p, double alpha) {
+  static const double isx[10] = {5e-4, 0.1, 10.0, 0.0125, 0.5, 0.5, 0.1, 1.0 / 0.3, 0.1, 1.0 / 0.3};
+  double step = 0.0;
+  for (int i = 0; i < p->N; ++i) {
+    if (i >= 1)
+      for (int r = 0; r < 8; ++r) step = fmax(step, fabs(alpha * p->dz[i][r]) * isx[r]);
+    if (i < p->N - 1) step = fmax(step, fmax(fabs(alpha * p->dv[i][0]) * isx[8], fabs(alpha * p->dv[i][1]) * isx[9]));
+  }
+  return step;
+}
 
 /* ---- active-set polish -------------------------------------------------------------------------
  * What OSQP's polish = true does for the reference (racing_mpc.cpp:90-95): guess the active rows from the interior
@@ -1305,6 +1319,7 @@ static int ipm_solve(prob_t* p, work_t* w, polish_t* pq, int* iters_out, double*
   /* ================= phase 1: interior point ================= */
   int distress = 0; /* the complementarity has gone up once: the wide-neighbourhood rule applies from then on */
   int pol_tried = 0, pol_done = 0, pol_rounds = 0; /* the early polish attempt; an accepted polish; rounds spent */
+  int stall_moving = 0;
   double mu_prev = INFINITY;
   for (it = 0; it <= p->max_iter; ++it) {
     double musum = 0.0;
@@ -1482,6 +1497,7 @@ static int ipm_solve(prob_t* p, work_t* w, polish_t* pq, int* iters_out, double*
         p->lmb[j] += alpha * p->dlmb[j];
       }
       status = LMPC_SOLVE_OPTIMAL;
+      stall_moving = scaled_step(p, alpha) > STALL_STEP; /* (round 6, below: the step the stall declines would still move the iterate) */
       break;
     }
     if (numerics_failed) {
@@ -1509,6 +1525,14 @@ static int ipm_solve(prob_t* p, work_t* w, polish_t* pq, int* iters_out, double*
      * this problem, and the interior point's iterate came from the same sweeps (csrc/lmpc_solve_kernel.hip, same place) */
     if (!pol_done && pq->noise) status = LMPC_SOLVE_MAX_ITER;
   }
+  /* Round 6: a STALL is not convergence when the Newton step it declines would still move the iterate.  The stall rule keeps the
+   * current point once the corrector would no longer lower mu (<= 1e-9, rows feasible) -- the direction has reached the accuracy of
+   * the factorisation -- and reported it OPTIMAL whatever the polish then said.  On one problem of tests/dispatch_sweep.py at 4096
+   * problems per case (learning, 160 points, N = 57) the iterate was still moving by 7.5e-4 (scaled) per step, the polish refused,
+   * and the point returned was 3.4e-4 from the optimum with status OPTIMAL.  A stalled iterate whose declined step exceeds
+   * STALL_STEP and that no polish has verified is returned as it is, with LMPC_SOLVE_MAX_ITER: stopped short of the stated
+   * accuracy (the status the noise rule above uses). */
+  if (status == LMPC_SOLVE_OPTIMAL && !pol_done && stall_moving) status = LMPC_SOLVE_MAX_ITER;
   /* ---- exit: report the reduced-gradient stationarity for the multipliers reached ---- */
   double rg = 0.0, viol = rdmax;
   if (status != LMPC_SOLVE_INFEASIBLE) {

@@ -129,6 +129,7 @@ struct Prof {};
 #define MA_MAX 6
 #define TAU_REL 1e-5   // tau = TAU_REL * max_j u_j'E u_j: cond(F_B) <= ~1e5 whatever the iteration does
 #define STALL_MU 1e-9  // complementarity below which a step that does not lower it ends the solve
+#define STALL_STEP 1e-6  // ... and the scaled size of that step above which the stalled iterate, unless the polish verifies it, is MAX_ITER
 #define NBHD_GAMMA 1e-2  // once mu has risen: no complementarity product below this fraction of their mean after a step (1e-3
                         // does not stop the cycle the rule is there for; applied to every problem 3e-2 costs 13 % more iterations)
 #define NBHD_TRIALS 3   // cuts of the step length by 0.6 at most (two are what the cycling problem needs; bounded so that a point already
@@ -2757,7 +2758,7 @@ __device__ __forceinline__ void lmpc_solve_problem(
   const int max_iter = feasible ? P.max_iter : 0;
   typedef polish_limits<real> pol;
   const bool polish_on = P.polish >= 0;
-  bool polished = false, pol_early_done = false, reentry = false;
+  bool polished = false, pol_early_done = false, reentry = false, stall_moving = false;
   int pol_rounds = 0;
   // results: layout by strides (lmpc_set_output_layout): [component][knot][batch] by default -- what batch-parallel consumers
   // read coalesced -- or [batch][knot][component], one problem's plan contiguous (the reference's DM layout).  One code
@@ -3643,7 +3644,13 @@ __device__ __forceinline__ void lmpc_solve_problem(
       break;
     }
     if (stalled) {
-      status = LMPC_SOLVE_OPTIMAL;
+      // (round 6: a stall is not convergence when the Newton step it declines would still move the iterate -- the point is kept and handed to the
+      //  polish as before, but unless the polish verifies it the status is MAX_ITER: oracle/c/lmpc_oracle.c, STALL_STEP, has the problem)
+      real cand = 0.0;  // the step the stall declines to take, in the reference's scaled units (like the polish's steps)
+#pragma unroll
+      for (int q = 0; q < KQ; ++q) cand = fmax(cand, (flags(q) & F_MOVE) ? fabs(alpha * d_val[q]) * real(slot_inv_scale((s_gf[q] >> 27) & 15)) : real(0));
+      stall_moving = sizeof(real) == 8 && wave_max(cand) > real(STALL_STEP);
+      status = (stall_moving && !polish_on) ? LMPC_SOLVE_MAX_ITER : LMPC_SOLVE_OPTIMAL;
       hand_over = polish_on ? 2 : 0;
       break;
     }
@@ -3713,7 +3720,8 @@ __device__ __forceinline__ void lmpc_solve_problem(
     // sweeps, was then 1e-6 .. 2e-3 from the dense optimum with status OPTIMAL (tests/dispatch_sweep.py, one problem of
     // 1024 at eighteen horizons).  It now says LMPC_SOLVE_MAX_ITER: stopped short of the stated accuracy.  No problem of
     // the bench distributions takes this branch (twin, 4096 / 1024 problems per family).
-    if (sizeof(real) == 8 && pol_noise) status = LMPC_SOLVE_MAX_ITER;
+    // (round 6: likewise a STALLED iterate whose declined step would still have moved it by more than STALL_STEP)
+    if (sizeof(real) == 8 && (pol_noise || stall_moving)) status = LMPC_SOLVE_MAX_ITER;
     break;
   }
   reentry = true;  // refused early: the interior point goes on from the same iterate (same `it`; the rows phase puts its

@@ -533,7 +533,7 @@ __device__ __forceinline__ void lmpc_solve_problem_w2(const lmpc_params& P, cons
   real mu = 0.0, rdmax = 0.0, rd_check = 0.0, last_step = 0.0, hsig = 0.0, ce = 0.0, mu_prev = inf;
   const int max_iter = feasible ? P.max_iter : 0;
   const bool polish_on = P.polish >= 0;
-  bool polished = false, pol_early_done = false, reentry = false, pol_noise = false, distress = false;
+  bool polished = false, pol_early_done = false, reentry = false, pol_noise = false, distress = false, stall_moving = false;
   int pol_rounds = 0;
   auto put_primal = [&]() {
     const size_t xk = P.out_aos ? 1 : (size_t)N * B, xi = P.out_aos ? 6 : (size_t)B, xb = P.out_aos ? (size_t)6 * N : 1;
@@ -892,7 +892,13 @@ __device__ __forceinline__ void lmpc_solve_problem_w2(const lmpc_params& P, cons
         break;
       }
       if (stalled) {
-        status = LMPC_SOLVE_OPTIMAL;
+        // (round 6: a stall is not convergence when the Newton step it declines would still move the iterate -- the point is kept and handed to the
+        //  polish as before, but unless the polish verifies it the status is MAX_ITER: oracle/c/lmpc_oracle.c, STALL_STEP, has the problem)
+        real cand = 0.0;
+#pragma unroll
+        for (int q = 0; q < KL; ++q) cand = fmax(cand, (flags(q) & F_MOVE) ? fabs(alpha * d_val[q]) * real(slot_inv_scale((gfq(q) >> 27) & 15)) : real(0));
+        stall_moving = wg_max(g, cand) > real(STALL_STEP);
+        status = (stall_moving && !polish_on) ? LMPC_SOLVE_MAX_ITER : LMPC_SOLVE_OPTIMAL;
         hand_over = polish_on ? 2 : 0;
         break;
       }
@@ -945,7 +951,7 @@ __device__ __forceinline__ void lmpc_solve_problem_w2(const lmpc_params& P, cons
     }
     if (hand_over == 2) {
       status = LMPC_SOLVE_OPTIMAL;
-      if (pol_noise) status = LMPC_SOLVE_MAX_ITER;
+      if (pol_noise || stall_moving) status = LMPC_SOLVE_MAX_ITER;  // (lmpc_solve_problem: the noise rule, and round 6's stall rule)
       break;
     }
     reentry = true;
