@@ -257,7 +257,9 @@ int lmpc_get_warm_accepted(lmpc_handle* h, int32_t batch, int32_t* accepted);
  * stored laps; on the learning workload of SURVEY.md 8(d) (random initial states) 1e-3 at the 99.99 % quantile and 5e-3 on every
  * problem -- a few problems per 32768 pass the single-precision KKT test with the weights of two or three nearly exchangeable
  * safe-set points off in the third digit (1.2 .. 3.4e-3 measured); away from the BASELINE shapes (every N, 96 points) 2e-3.
- * lmpc_solve_batch_f32 has no fp64 pass behind it: 1e-3 on the BASELINE shape (N = 40), 2e-3 at N >= 65.
+ * lmpc_solve_batch_f32 has no fp64 pass behind it: 1e-3 on the BASELINE shape (N = 40, every problem of 8192); over every horizon
+ * from 3 to 81 at 4096 problems each (profiles/r06_dispatch_sweep_4096.txt) the worst single problems are 2.0 .. 2.2e-3 (N = 36, 75)
+ * and at two horizons one problem of 4096 that the fp64 kernel solves is not solved.
  * Fit for well-scaled problems (IAC) and for the learning problem, NOT for the BARC
  * tracking problem at low speed, whose soft boundary needs complementarity below 1e-9.
  * polish < 0: one pass, the fp32 interior point's own answers (faster, a tail of problems up to 3e-2 away). */
