@@ -256,7 +256,8 @@ int lmpc_get_warm_accepted(lmpc_handle* h, int32_t batch, int32_t* accepted);
  * answer; tests/tolerances.py): 1e-3 on every problem of the tracking configurations and of the learning problem on states near the
  * stored laps; on the learning workload of SURVEY.md 8(d) (random initial states) 1e-3 at the 99.99 % quantile and 5e-3 on every
  * problem -- a few problems per 32768 pass the single-precision KKT test with the weights of two or three nearly exchangeable
- * safe-set points off in the third digit (1.2 .. 3.4e-3 measured); away from the BASELINE shapes (every N, 96 points) 2e-3.
+ * safe-set points off in the third digit (1.2 .. 3.4e-3 measured); away from the BASELINE shapes (every N, 96 / 160 points) 2e-3 on
+ * every problem of 1024 per horizon, single problems up to 2.9e-3 at 4096 per horizon (profiles/r06_dispatch_sweep_4096.txt).
  * lmpc_solve_batch_f32 has no fp64 pass behind it: 1e-3 on the BASELINE shape (N = 40, every problem of 8192); over every horizon
  * from 3 to 81 at 4096 problems each (profiles/r06_dispatch_sweep_4096.txt) the worst single problems are 2.0 .. 2.2e-3 (N = 36, 75)
  * and at two horizons one problem of 4096 that the fp64 kernel solves is not solved.

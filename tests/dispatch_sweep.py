@@ -36,6 +36,7 @@ dev = torch.device("cuda:0")
 SX, SU = P.SCALE_X[:, None, None], P.SCALE_U[:, None, None]
 POOL = ThreadPoolExecutor(16)
 DUMP = ""
+SEED = 0   # --seed: offset of the sampling seeds (0: the problems the test suite runs on)
 
 
 def twin_parallel(cfg, veh, inp, ss_x=None, ss_j=None, chunks=16):
@@ -72,15 +73,15 @@ def one(family, N, B, failures):
     iac, learning = family == "iac", family.startswith("lrn")
     tr = pkg.workloads.synthetic_track("putnam" if iac else "barc")
     if iac:
-        x, u = pkg.workloads.sample_initial_states("putnam", B, tr["L"], [-10.0, -0.314159], [5.0, 0.314159], seed=1)
+        x, u = pkg.workloads.sample_initial_states("putnam", B, tr["L"], [-10.0, -0.314159], [5.0, 0.314159], seed=1 + SEED)
         pc, pv, oc, ov = pkg.presets.iac_tracking_mpc(N), pkg.presets.iac_vehicle(), P.iac_tracking_mpc(N), P.iac_vehicle()
     elif learning:
         n_laps = 3 if family == "lrn96" else 5
         pc, pv, oc, ov = dict(pkg.presets.barc_lmpc(N, n_laps)), pkg.presets.barc_vehicle(), P.barc_lmpc(N, n_laps), P.barc_vehicle()
         laps = pkg.workloads.synthetic_laps(tr, n_laps)
-        x, u = pkg.workloads.sample_states_near_laps(laps, B, tr["L"], seed=0)
+        x, u = pkg.workloads.sample_states_near_laps(laps, B, tr["L"], seed=SEED)
     else:
-        x, u = pkg.workloads.sample_initial_states("barc", B, tr["L"], [-0.01, -0.314159], [0.01, 0.314159], seed=0)
+        x, u = pkg.workloads.sample_initial_states("barc", B, tr["L"], [-0.01, -0.314159], [0.01, 0.314159], seed=SEED)
         pc, pv, oc, ov = pkg.presets.barc_tracking_mpc(N), pkg.presets.barc_vehicle(), P.barc_tracking_mpc(N), P.barc_vehicle()
     sv = pkg.Solver(pc, pv, device=0)
     sv.reserve(B)
@@ -165,8 +166,10 @@ if __name__ == "__main__":
     ap.add_argument("--nmax", type=int, default=81)
     ap.add_argument("--nstep", type=int, default=1)
     ap.add_argument("--dump", default="")
+    ap.add_argument("--seed", type=int, default=0)
     a = ap.parse_args()
     DUMP = a.dump
+    SEED = a.seed
     if DUMP:
         Path(DUMP).mkdir(parents=True, exist_ok=True)
     t0 = time.time()
