@@ -928,6 +928,9 @@ static double scaled_step(const prob_t* p, double alpha) {
 #define WARM_ACT_EY 1e-3    /* boundary rows: their bounds move with the shift (the track half-width over one knot's travel) */
 #define POLISH_FEAS 1e-9
 #define POLISH_DUAL 1e-7
+#ifndef POLISH_DUAL_L
+#define POLISH_DUAL_L 1e-8 /* the same test on the simplex rows' multipliers, a decade tighter (round 6; polish_limits<double>::dual_l of the kernel says why) */
+#endif
 #define POLISH_STRONG 1e3
 #define POLISH_STEP_TOL 1e-6 /* the last multiplier step, in the reference's scaled units (racing_mpc.cpp:36-37): converged
                               * steps are 1e-7 .. 1e-10, the ones this is there to catch 1e-3 .. 1e-1.  Round 5: until then exactly
@@ -1061,7 +1064,7 @@ __attribute__((optimize("no-tree-vectorize"))) static int polish_rounds(prob_t* 
     for (int j = 0; j < S; ++j) {
       if (q->heldl[j]) {
         if (!(fabs(p->lmb[j]) <= POLISH_FEAS)) bad = 1;
-        if (q->yl[j] < -POLISH_DUAL) {
+        if (q->yl[j] < -POLISH_DUAL_L) {
           anyneg = 1;
           if (p->ll[j] < POLISH_STRONG * p->tl[j]) anyweak = 1;
         }
@@ -1111,7 +1114,7 @@ __attribute__((optimize("no-tree-vectorize"))) static int polish_rounds(prob_t* 
     for (int j = 0; j < S; ++j) {
       if (q->heldl[j]) {
         const int weak = p->ll[j] < POLISH_STRONG * p->tl[j];
-        if (q->yl[j] < -POLISH_DUAL && (anyweak ? weak : q->yl[j] <= 0.5 * ymin)) {
+        if (q->yl[j] < -POLISH_DUAL_L && (anyweak ? weak : q->yl[j] <= 0.5 * ymin)) {
           q->heldl[j] = 0;
           changed = 1;
         }

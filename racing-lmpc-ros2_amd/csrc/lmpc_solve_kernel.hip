@@ -400,6 +400,12 @@ template <> struct polish_limits<double> {
   // pipelined rate +1.3 % -- and the KERNEL slower: 0.813 -> 0.861 ms (N = 20), 2.35 -> 2.48 (N = 40), 8.11 -> 8.65 (N = 80) per 4096:
   // more early attempts are refused, those problems pay the attempt and a second one, and a launch lasts as long as its slowest waves.
   static constexpr double theta = 1e8, feas = 1e-9, dual = 1e-7, mu_early = 1e-8, rd_early = 1e-6, step_ok = 1e-7, step_tol = 1e-6;
+  // dual_l: the same test on the SIMPLEX rows' multipliers, a decade tighter (round 6).  The learning problem is LP-like along blends of
+  // nearly exchangeable safe-set points: a wrong vertex whose pinned weights have multipliers of -2e-8 .. -1e-7 passed at -1e-7 and sat
+  // 1.4e-3 from the dense optimum in X at an objective gap below 1e-9 (the twin, one problem of the 3.9 M of the large dispatch sweeps:
+  // N = 71, 160 points; at -1e-8 it is repaired to the optimum).  No problem of the learning fixtures has a multiplier in between: same
+  // iterations, same answers (scratch/r6/twin_mu_early.py with TWIN_MACRO=POLISH_DUAL_L).
+  static constexpr double dual_l = 1e-8;
   static constexpr int rounds = 4, steps = 6;
 };
 template <> struct polish_limits<float> {
@@ -409,6 +415,7 @@ template <> struct polish_limits<float> {
   static constexpr bool early = false;  // (an early attempt at mu ~ 1e-4 was measured on the serial twin: the iterations it saves are fewer than the rounds it adds)
   static constexpr float theta = 1e7f, feas = LMPC_F32_POL_FEAS, dual = LMPC_F32_POL_DUAL, mu_early = 0.0f, rd_early = 0.0f, step_ok = 3e-6f,
                          step_tol = LMPC_F32_POL_STEP_TOL;
+  static constexpr float dual_l = LMPC_F32_POL_DUAL;  // (the simplex rows' multipliers: the rows' own limit in single precision)
   static constexpr int rounds = 4, steps = LMPC_F32_POL_STEPS;
 };
 // 1 / scale of the quantity a slot constrains: the reference's scale vectors (racing_mpc.cpp:36-37, hard-coded there for every
@@ -2289,7 +2296,7 @@ __device__ __forceinline__ PolishResult<real, KS> lmpc_polish(const PolishArgs<r
 #pragma unroll
       for (int q = 0; q < KS; ++q) {
         const bool hq = (held >> (28 + q)) & 1, fr = sx.on[q] && !hq;
-        const bool nq = hq && sx.p[q] < -treal(pol::dual);
+        const bool nq = hq && sx.p[q] < -treal(pol::dual_l);
         bad = bad || (hq && !(fabs(sx.lm[q]) <= treal(pol::feas)));
         neg = neg || nq;
         weakneg = weakneg || (nq && sx.l[q] < treal(POLISH_STRONG) * sx.t[q]);
@@ -2339,7 +2346,7 @@ __device__ __forceinline__ PolishResult<real, KS> lmpc_polish(const PolishArgs<r
 #pragma unroll
       for (int q = 0; q < KS; ++q) {
         const bool hq = (held >> (28 + q)) & 1, fr = sx.on[q] && !hq;
-        const bool dq = hq && sx.p[q] < -treal(pol::dual) && (anyweak ? sx.l[q] < treal(POLISH_STRONG) * sx.t[q] : real(sx.p[q]) <= ycut);
+        const bool dq = hq && sx.p[q] < -treal(pol::dual_l) && (anyweak ? sx.l[q] < treal(POLISH_STRONG) * sx.t[q] : real(sx.p[q]) <= ycut);
         const bool aq = !anyneg && fr && !(-sx.lm[q] <= treal(pol::feas));
         held = (held & ~((dq ? 1 : 0) << (28 + q))) | ((aq ? 1 : 0) << (28 + q));
       }

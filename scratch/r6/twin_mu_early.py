@@ -15,7 +15,7 @@ from __graft_entry__ import load_package
 pkg = load_package()
 for mu in sys.argv[2:]:
     so = f"/tmp/twin_mu_{mu}.so"
-    subprocess.check_call(["gcc", "-O3", "-march=x86-64-v3", "-fPIC", "-std=c11", f"-I{ROOT}/include", "-shared", "-o", so, str(ROOT / "oracle/c/lmpc_oracle.c"), "-lm", f"-DPOLISH_MU={mu}"])
+    subprocess.check_call(["gcc", "-O3", "-march=x86-64-v3", "-fPIC", "-std=c11", f"-I{ROOT}/include", "-shared", "-o", so, str(ROOT / "oracle/c/lmpc_oracle.c"), "-lm", f"-D{os.environ.get('TWIN_MACRO', 'POLISH_MU')}={mu}"])
     cbind._LIB = None
     cbind._lib = None
     lib = ctypes.CDLL(so)
@@ -33,4 +33,4 @@ for mu in sys.argv[2:]:
         ok = (tw["status"] == 0) & (d["status"] == 0)
         exu, ed = per_problem_err({k: tw[k][..., ok] for k in ("X_optm", "U_optm", "dU_optm")}, {k: d[k][..., ok] for k in ("X_optm", "U_optm", "dU_optm")})
         it = tw["iters"][ok]
-        print(f"POLISH_MU {mu} {name}: solved {ok.sum()} of {ok.size}; iters mean {it.mean():.3f} max {it.max()}; vs dense X/U max {exu.max():.1e} dU max {ed.max():.1e}", flush=True)
+        print(f"{os.environ.get('TWIN_MACRO', 'POLISH_MU')} {mu} {name}: solved {ok.sum()} of {ok.size}; iters mean {it.mean():.3f} max {it.max()}; vs dense X/U max {exu.max():.1e} dU max {ed.max():.1e}", flush=True)
